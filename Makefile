@@ -1,0 +1,23 @@
+# Build of the MI355X ring engine (gfx950 only) and of the CPU oracle used by the tests.
+HIPCC ?= hipcc
+ARCH  ?= gfx950
+PKG   := matrix-fhe-lattigo_amd
+CSRC  := $(PKG)/csrc
+LIB   := $(PKG)/lib/libringhip.so
+SRCS  := $(CSRC)/engine.hip $(CSRC)/ntt3n.hip $(CSRC)/bext.hip
+HDRS  := $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.hpp) $(wildcard include/*.h)
+
+all: $(LIB) oracle
+
+$(LIB): $(SRCS) $(HDRS)
+	@mkdir -p $(PKG)/lib
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Iinclude $(SRCS) -o $@
+
+oracle: oracle/libring_oracle.so
+oracle/libring_oracle.so: oracle/ring_oracle.c oracle/ring_oracle.h include/ringhip_ops.h
+	gcc -O3 -march=native -fno-fast-math -ffp-contract=off -fPIC -shared -pthread oracle/ring_oracle.c -o $@
+
+clean:
+	rm -f $(LIB) oracle/libring_oracle.so
+
+.PHONY: all oracle clean

@@ -1,0 +1,116 @@
+/*
+ * ringhip.h -- C ABI of the MI355X-native full-RNS polynomial-ring engine.
+ *
+ * Drop-in boundary for the `ring` hot path of swanhong/matrix-fhe-lattigo (paths below are relative to the reference
+ * root).  Plain pointers and sizes only; no C++/torch types.  Every entry point returns 0 on success or a negative
+ * rh_status; rh_last_error() returns a thread-local message.  Nothing aborts or throws across this boundary: the Go
+ * wrapper turns a non-zero status into the same panic/error the reference raises (ring/ntt.go:212-214,
+ * ring/ring.go:321-331).  The cgo binding a maintainer adds is shown in INTEGRATION.md.
+ *
+ * Data model.  A "limb" is N uint64 residues; device polynomials are (poly, limb, coefficient) contiguous blocks:
+ * word index ((poly*L)+limb)*N + j.  This replaces Poly.Coeffs [][]uint64 (ring/poly.go:13-24) for device-resident
+ * data; host-pointer entry points take one limb at a time exactly like the NumberTheoreticTransformer interface.
+ */
+#ifndef RINGHIP_H
+#define RINGHIP_H
+#include <stddef.h>
+#include <stdint.h>
+#include "ringhip_ops.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rh_status {
+  RH_OK = 0,
+  RH_ERR_ARG = -1,        /* bad argument (short slice / bad level / N not supported) -> Go side panics like ntt.go:212 */
+  RH_ERR_MODULUS = -2,    /* modulus not prime / not 1 mod NthRoot (ring/subring.go:139-145)                          */
+  RH_ERR_DEVICE = -3,     /* HIP runtime error                                                                        */
+  RH_ERR_NOMEM = -4,
+  RH_ERR_UNSUPPORTED = -5
+} rh_status;
+
+typedef enum rh_ring_kind {
+  RH_RING_STANDARD = 0,   /* Z_q[X]/(X^N+1), NumberTheoreticTransformerStandard (ring/ntt.go:31-78)                    */
+  RH_RING_3N = 2          /* Z_q[X]/(X^N-X^(N/2)+1), NumberTheoreticTransformer3N (ring/ntt_3n.go:21-156)             */
+} rh_ring_kind;
+
+typedef struct rh_ring rh_ring;   /* replaces ring.Ring + its SubRings' NTT state (ring/ring.go:76-89, subring.go:35-55) */
+
+const char* rh_last_error(void);
+int rh_device_count(void);
+
+/* ---- ring construction -------------------------------------------------------------------------------------------
+ * rh_ring_create: the constants handoff of NewRingWithCustomNTT / NewSubRingWithCustomNTT (ring/ring.go:314-356,
+ * ring/subring.go:74-111, generateNTTConstants :129-214).  The engine never re-derives roots: it receives what the Go
+ * side generated, so it is bit-identical to that Ring, including the random omega of a 3N ring.
+ *   moduli[L], mred[L] (MRedConstant), bred[2L] (BRedConstant hi,lo), ninv[L] (NTTTable.NInv, Montgomery form),
+ *   roots_fwd/roots_bwd: L tables of N words (NTTTable.RootsForward/RootsBackward), STANDARD rings only,
+ *   omega3n[L]: primitive 3N-th root per limb (NumberTheoreticTransformer3N.psi3N), 3N rings only.            */
+int rh_ring_create(rh_ring** out, int device, int kind, int N, int L, const uint64_t* moduli, const uint64_t* mred,
+                   const uint64_t* bred, const uint64_t* ninv, const uint64_t* roots_fwd, const uint64_t* roots_bwd,
+                   const uint64_t* omega3n);
+/* rh_ring_create_auto: NewRing(N, moduli) (ring/ring.go:264-272): generates every constant on the host with the
+ * reference's rules (smallest primitive root g >= 3, psi = g^((q-1)/2N), bit-reversed Montgomery tables).  For a 3N
+ * ring omega = g^((q-1)/3N) (Find3NPrimitiveRoot, ring/subring.go:255-290) unless omega3n != NULL.               */
+int rh_ring_create_auto(rh_ring** out, int device, int kind, int N, int L, const uint64_t* moduli,
+                        const uint64_t* omega3n);
+void rh_ring_destroy(rh_ring* r);
+int rh_ring_n(const rh_ring* r);
+int rh_ring_limbs(const rh_ring* r);
+/* copies the per-limb constants back (any pointer may be NULL): what SubRing exposes (Modulus, MRedConstant,
+ * BRedConstant, NInv, RootsForward, RootsBackward / omega) */
+int rh_ring_get_constants(const rh_ring* r, uint64_t* moduli, uint64_t* mred, uint64_t* bred, uint64_t* ninv,
+                          uint64_t* roots_fwd, uint64_t* roots_bwd, uint64_t* omega3n);
+/* all device work of this ring is enqueued on `hip_stream` (a hipStream_t; NULL = the null stream) */
+int rh_ring_set_stream(rh_ring* r, void* hip_stream);
+int rh_ring_sync(rh_ring* r);
+
+/* ---- device memory (plain hipMalloc'd words; any device pointer from another allocator, e.g. torch, is accepted) */
+int rh_dev_alloc(rh_ring* r, size_t words, uint64_t** dptr);
+int rh_dev_free(rh_ring* r, uint64_t* dptr);
+int rh_dev_upload(rh_ring* r, uint64_t* dst_dev, const uint64_t* src_host, size_t words);
+int rh_dev_download(rh_ring* r, uint64_t* dst_host, const uint64_t* src_dev, size_t words);
+
+/* ---- NumberTheoreticTransformer interface, one limb, host pointers (ring/ntt.go:17-22; SubRing.NTT/NTTLazy/INTT/
+ * INTTLazy ring/subring_ops.go:235-252).  p1 and p2 hold N words each and may alias.  Synchronous.
+ *   Forward      -> canonical [0,q)                       (NTTStandard, ntt.go:174-177 / 3N Forward ntt_3n.go:82-109)
+ *   ForwardLazy  -> exactly the reference's lazy representatives in [0,6q-2] (NTTStandardLazy :180-182)
+ *   Backward, BackwardLazy -> canonical [0,q)             (INTTStandard :185-194, INTTStandardLazy :197-206, N>=16) */
+int rh_ntt_forward(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2);
+int rh_ntt_forward_lazy(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2);
+int rh_ntt_backward(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2);
+int rh_ntt_backward_lazy(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2);
+
+/* ---- Ring.NTT / NTTLazy / INTT / INTTLazy on device-resident batches (ring/ntt.go:127-152).
+ * in/out: npoly polys of (level+1) limbs each, limbs 0..level of the ring (Ring.AtLevel view); may alias.
+ * Asynchronous on the ring's stream. */
+int rh_ring_ntt(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int lazy);
+int rh_ring_intt(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int lazy);
+
+/* ---- element-wise family (ring/vec_ops.go via ring/operations.go loops): p3 = op(p1, p2 [, p3]) on npoly polys of
+ * (level+1) limbs.  s0/s1: per-limb scalar arrays of level+1 words on the HOST (NULL = unused), e.g. the RNSScalar of
+ * MulRNSScalarMontgomery (ring/operations.go).  Asynchronous. */
+int rh_ring_vec_op(rh_ring* r, int opcode, const uint64_t* p1_dev, const uint64_t* p2_dev, uint64_t* p3_dev, int npoly,
+                   int level, const uint64_t* s0_host, const uint64_t* s1_host);
+
+/* ---- RNS basis extension (ring/basis_extension.go).  A basis extender pairs a Q ring and a P ring
+ * (NewBasisExtender :52-79).  All polys device-resident, limbs 0..levelQ / 0..levelP, npoly polys.  Asynchronous. */
+typedef struct rh_bext rh_bext;
+int rh_bext_create(rh_bext** out, rh_ring* ringQ, rh_ring* ringP);
+void rh_bext_destroy(rh_bext* be);
+int rh_bext_modup_q_to_p(rh_bext* be, int levelQ, int levelP, const uint64_t* polQ, uint64_t* polP, int npoly);   /* :188-200 */
+int rh_bext_modup_p_to_q(rh_bext* be, int levelP, int levelQ, const uint64_t* polP, uint64_t* polQ, int npoly);   /* :205-217 */
+int rh_bext_moddown_qp_to_q(rh_bext* be, int levelQ, int levelP, const uint64_t* p1Q, const uint64_t* p1P,
+                            uint64_t* p2Q, int npoly);                                                            /* :223-234 */
+int rh_bext_moddown_qp_to_q_ntt(rh_bext* be, int levelQ, int levelP, const uint64_t* p1Q, const uint64_t* p1P,
+                                uint64_t* p2Q, int npoly);                                                        /* :241-258 */
+int rh_bext_moddown_qp_to_p(rh_bext* be, int levelQ, int levelP, const uint64_t* p1Q, const uint64_t* p1P,
+                            uint64_t* p2P, int npoly);                                                            /* :264-278 */
+/* Decomposer.DecomposeAndSplit (:381-502): digit `digit` of p0Q -> p1Q (levelQ+1 limbs), p1P (levelP+1 limbs) */
+int rh_bext_decompose_and_split(rh_bext* be, int levelQ, int levelP, int nbPi, int digit, const uint64_t* p0Q,
+                                uint64_t* p1Q, uint64_t* p1P, int npoly);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

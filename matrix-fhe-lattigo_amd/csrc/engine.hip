@@ -1,0 +1,381 @@
+// engine.hip -- C-ABI implementation (include/ringhip.h): ring construction, twiddle-table layout, kernel launches.
+//
+// Host logic here replaces, for device-resident data, the per-limb dispatch loops of the reference
+// (Ring.NTT ring/ntt.go:127-152, SubRing ops ring/subring_ops.go, Ring ops ring/operations.go) with one batched
+// launch over (poly, limb) -- limbs and polys are independent, so the batch IS the parallelism.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+#include <new>
+#include "../../include/ringhip.h"
+#include "hostmath.hpp"
+#include "ntt_kernels.cuh"
+#include "vec_kernels.cuh"
+#include "engine_internal.hpp"
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+int rh_fail(int code, const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+  return code;
+}
+extern "C" const char* rh_last_error(void) { return g_err; }
+extern "C" int rh_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+// ------------------------------------------------------------------------------------------------ table layout
+// natural order -> the order ntt_fwd_tile / ntt_inv_tile read (ntt_kernels.cuh): per 4096-tile T
+//   [slot]                 round A, slot = (2^u - 1) + g          <- nat[2^(S1+u)   + T*2^u     + g]
+//   [16 + slot*16 + hi4]   round B                                <- nat[2^(S1+4+u) + T*2^(4+u) + (hi4<<u) + g]
+//   [256 + slot*256 + tid] round C                                <- nat[2^(S1+8+u) + T*2^(8+u) + (tid<<u) + g]
+template <class T>
+static void build_kernel_order(const T* nat, T* out, int logN) {
+  const int S1 = logN - LT;
+  const size_t ntiles = (size_t)1 << S1;
+  for (size_t t = 0; t < ntiles; ++t) {
+    T* o = out + (t << LT);
+    memset(o, 0, sizeof(T) * TILE);
+    for (int u = 0; u < 4; ++u)
+      for (int g = 0; g < (1 << u); ++g) {
+        const int slot = (1 << u) - 1 + g;
+        o[slot] = nat[((size_t)1 << (S1 + u)) + (t << u) + g];
+        for (int h = 0; h < 16; ++h) o[16 + slot * 16 + h] = nat[((size_t)1 << (S1 + 4 + u)) + (t << (4 + u)) + ((size_t)h << u) + g];
+        for (int i = 0; i < 256; ++i) o[256 + slot * 256 + i] = nat[((size_t)1 << (S1 + 8 + u)) + (t << (8 + u)) + ((size_t)i << u) + g];
+      }
+  }
+}
+
+template <class T>
+static int upload(T** dptr, const std::vector<T>& h) {
+  if (hipMalloc((void**)dptr, h.size() * sizeof(T)) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc(%zu) failed", h.size() * sizeof(T));
+  if (hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "hipMemcpy H2D failed");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ ring construction
+static int validate_degree(int kind, int N) {
+  if (kind == RH_RING_STANDARD) {
+    if (N < 16 || (N & (N - 1)) != 0 || N > (1 << 17)) return rh_fail(RH_ERR_ARG, "invalid ring degree: N=%d must be a power of two in [16, 2^17]", N);
+    return 0;
+  }
+  if (kind == RH_RING_3N) {
+    int m = N; int a = 0, b = 0;
+    while (m % 2 == 0) { m /= 2; ++a; }
+    while (m % 3 == 0) { m /= 3; ++b; }
+    if (m != 1 || a < 1 || b < 1) return rh_fail(RH_ERR_ARG, "invalid 3N ring degree: N=%d must be 2^a*3^b with a,b>=1", N);
+    return 0;
+  }
+  return rh_fail(RH_ERR_ARG, "unknown ring kind %d", kind);
+}
+
+extern "C" int rh_ring_create(rh_ring** out, int device, int kind, int N, int L, const uint64_t* moduli, const uint64_t* mred,
+                              const uint64_t* bred, const uint64_t* ninv, const uint64_t* roots_fwd, const uint64_t* roots_bwd,
+                              const uint64_t* omega3n) {
+  if (!out || !moduli || !mred || !bred || L < 1 || L > RH_MAX_LIMBS) return rh_fail(RH_ERR_ARG, "rh_ring_create: bad arguments (L=%d)", L);
+  if (int e = validate_degree(kind, N)) return e;
+  for (int i = 0; i < L; ++i) {
+    if (moduli[i] >= ((u64)1 << 61) || (moduli[i] & 1) == 0) return rh_fail(RH_ERR_MODULUS, "modulus %d (%llu) must be odd and < 2^61", i, (unsigned long long)moduli[i]);
+    for (int j = 0; j < i; ++j) if (moduli[i] == moduli[j]) return rh_fail(RH_ERR_MODULUS, "invalid moduli: duplicate modulus %llu", (unsigned long long)moduli[i]);
+  }
+  if (hipSetDevice(device) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "hipSetDevice(%d) failed", device);
+  rh_ring* r = new (std::nothrow) rh_ring();
+  if (!r) return rh_fail(RH_ERR_NOMEM, "out of host memory");
+  r->device = device; r->kind = kind; r->N = N; r->L = L;
+  r->moduli.assign(moduli, moduli + L); r->mred.assign(mred, mred + L); r->bred.assign(bred, bred + 2 * L);
+  int rc = 0;
+  std::vector<LimbConsts> hc(L);
+  for (int i = 0; i < L; ++i) {
+    LimbConsts& c = hc[i];
+    c.q = moduli[i]; c.qinv = mred[i]; c.bred0 = bred[2 * i]; c.bred1 = bred[2 * i + 1]; c.nq = (u64)0 - moduli[i];
+    c.ninv_mont = 0; c.ninv_w = 0; c.ninv_wp = 0;
+  }
+  if (kind == RH_RING_STANDARD) {
+    if (!ninv || !roots_fwd || !roots_bwd) { delete r; return rh_fail(RH_ERR_ARG, "rh_ring_create: standard ring needs ninv and root tables"); }
+    int logN = 0; while ((1 << logN) < N) ++logN;
+    r->logN = logN;
+    r->ninv.assign(ninv, ninv + L);
+    r->roots_fwd.assign(roots_fwd, roots_fwd + (size_t)L * N);
+    r->roots_bwd.assign(roots_bwd, roots_bwd + (size_t)L * N);
+    std::vector<tw2> fs((size_t)L * N), is((size_t)L * N), lastw(L);
+    for (int i = 0; i < L; ++i) {
+      const u64 q = moduli[i];
+      LimbConsts& c = hc[i];
+      c.ninv_mont = ninv[i];
+      c.ninv_w = rh::imform(ninv[i], q); c.ninv_wp = rh::shoup_quotient(c.ninv_w, q);
+      // one modular inverse of 2^64 per limb, then a multiply per root
+      const u64 rinv = rh::imform(1, q);
+      for (int j = 0; j < N; ++j) {
+        u64 wf = rh::mulmod(roots_fwd[(size_t)i * N + j] % q, rinv, q), wb = rh::mulmod(roots_bwd[(size_t)i * N + j] % q, rinv, q);
+        fs[(size_t)i * N + j] = tw2{wf, rh::shoup_quotient(wf, q)};
+        is[(size_t)i * N + j] = tw2{wb, rh::shoup_quotient(wb, q)};
+      }
+      u64 lw = rh::mulmod(is[(size_t)i * N + 1].w, c.ninv_w, q);
+      lastw[i] = tw2{lw, rh::shoup_quotient(lw, q)};
+    }
+    if (!rc) rc = upload(&r->d_tw_fwd, fs);
+    if (!rc) rc = upload(&r->d_tw_inv, is);
+    if (!rc) rc = upload(&r->d_tw_fwd_mont, r->roots_fwd);
+    if (!rc) rc = upload(&r->d_lastw, lastw);
+    if (!rc && logN >= LT) {
+      std::vector<tw2> kf((size_t)L * N), ki((size_t)L * N);
+      std::vector<u64> km((size_t)L * N);
+      for (int i = 0; i < L; ++i) {
+        build_kernel_order(fs.data() + (size_t)i * N, kf.data() + (size_t)i * N, logN);
+        build_kernel_order(is.data() + (size_t)i * N, ki.data() + (size_t)i * N, logN);
+        build_kernel_order(r->roots_fwd.data() + (size_t)i * N, km.data() + (size_t)i * N, logN);
+      }
+      if (!rc) rc = upload(&r->d_twk_fwd, kf);
+      if (!rc) rc = upload(&r->d_twk_inv, ki);
+      if (!rc) rc = upload(&r->d_twk_fwd_mont, km);
+    }
+  } else {
+    if (!omega3n) { delete r; return rh_fail(RH_ERR_ARG, "rh_ring_create: 3N ring needs omega3n"); }
+    r->omega3n.assign(omega3n, omega3n + L);
+    rc = rh_ring3n_setup(r, hc);
+  }
+  if (!rc) rc = upload(&r->d_consts, hc);
+  if (!rc && hipMalloc((void**)&r->d_scratch, (size_t)2 * N * sizeof(u64)) != hipSuccess) rc = rh_fail(RH_ERR_NOMEM, "hipMalloc scratch failed");
+  if (rc) { rh_ring_destroy(r); return rc; }
+  r->hconsts = hc;
+  *out = r;
+  return RH_OK;
+}
+
+extern "C" int rh_ring_create_auto(rh_ring** out, int device, int kind, int N, int L, const uint64_t* moduli, const uint64_t* omega3n) {
+  if (!out || !moduli || L < 1 || L > RH_MAX_LIMBS) return rh_fail(RH_ERR_ARG, "rh_ring_create_auto: bad arguments");
+  if (int e = validate_degree(kind, N)) return e;
+  std::vector<u64> mred(L), bred(2 * L), ninv(L), rf, rb, om;
+  const u64 nthroot = (kind == RH_RING_STANDARD) ? (u64)2 * N : (u64)3 * N;
+  if (kind == RH_RING_STANDARD) { rf.resize((size_t)L * N); rb.resize((size_t)L * N); }
+  else om.resize(L);
+  for (int i = 0; i < L; ++i) {
+    const u64 q = moduli[i];
+    if (!rh::is_prime(q)) return rh_fail(RH_ERR_MODULUS, "invalid modulus: %llu is not prime)", (unsigned long long)q);
+    if (q % nthroot != 1) return rh_fail(RH_ERR_MODULUS, "invalid modulus: %llu != 1 mod NthRoot)", (unsigned long long)q);
+    mred[i] = rh::gen_mred_constant(q);
+    rh::gen_bred_constant(q, &bred[2 * i]);
+    if (kind == RH_RING_STANDARD) {
+      if (rh::gen_ntt_tables(q, nthroot, &rf[(size_t)i * N], &rb[(size_t)i * N], &ninv[i])) return rh_fail(RH_ERR_MODULUS, "table generation failed for modulus %llu", (unsigned long long)q);
+    } else {
+      ninv[i] = rh::mform(rh::invmod_prime((u64)N % q, q), q);
+      om[i] = omega3n ? omega3n[i] : rh::powmod(rh::primitive_root(q), (q - 1) / nthroot, q);
+    }
+  }
+  return rh_ring_create(out, device, kind, N, L, moduli, mred.data(), bred.data(), ninv.data(),
+                        kind == RH_RING_STANDARD ? rf.data() : nullptr, kind == RH_RING_STANDARD ? rb.data() : nullptr,
+                        kind == RH_RING_3N ? om.data() : nullptr);
+}
+
+extern "C" void rh_ring_destroy(rh_ring* r) {
+  if (!r) return;
+  (void)hipSetDevice(r->device);
+  void* ptrs[] = {r->d_consts, r->d_tw_fwd, r->d_tw_inv, r->d_tw_fwd_mont, r->d_twk_fwd, r->d_twk_inv, r->d_twk_fwd_mont, r->d_lastw, r->d_scratch};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  rh_ring3n_teardown(r);
+  delete r;
+}
+extern "C" int rh_ring_n(const rh_ring* r) { return r ? r->N : 0; }
+extern "C" int rh_ring_limbs(const rh_ring* r) { return r ? r->L : 0; }
+extern "C" int rh_ring_get_constants(const rh_ring* r, uint64_t* moduli, uint64_t* mred, uint64_t* bred, uint64_t* ninv,
+                                     uint64_t* roots_fwd, uint64_t* roots_bwd, uint64_t* omega3n) {
+  if (!r) return rh_fail(RH_ERR_ARG, "null ring");
+  if (moduli) memcpy(moduli, r->moduli.data(), r->moduli.size() * 8);
+  if (mred) memcpy(mred, r->mred.data(), r->mred.size() * 8);
+  if (bred) memcpy(bred, r->bred.data(), r->bred.size() * 8);
+  if (ninv && !r->ninv.empty()) memcpy(ninv, r->ninv.data(), r->ninv.size() * 8);
+  if (roots_fwd && !r->roots_fwd.empty()) memcpy(roots_fwd, r->roots_fwd.data(), r->roots_fwd.size() * 8);
+  if (roots_bwd && !r->roots_bwd.empty()) memcpy(roots_bwd, r->roots_bwd.data(), r->roots_bwd.size() * 8);
+  if (omega3n && !r->omega3n.empty()) memcpy(omega3n, r->omega3n.data(), r->omega3n.size() * 8);
+  return RH_OK;
+}
+extern "C" int rh_ring_set_stream(rh_ring* r, void* s) { if (!r) return rh_fail(RH_ERR_ARG, "null ring"); r->stream = (hipStream_t)s; return RH_OK; }
+extern "C" int rh_ring_sync(rh_ring* r) {
+  if (!r) return rh_fail(RH_ERR_ARG, "null ring");
+  hipError_t e = hipStreamSynchronize(r->stream);
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "hipStreamSynchronize: %s", hipGetErrorString(e));
+  return RH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ device memory
+extern "C" int rh_dev_alloc(rh_ring* r, size_t words, uint64_t** dptr) {
+  if (!r || !dptr) return rh_fail(RH_ERR_ARG, "rh_dev_alloc: null argument");
+  (void)hipSetDevice(r->device);
+  if (hipMalloc((void**)dptr, words * 8) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc(%zu words) failed", words);
+  return RH_OK;
+}
+extern "C" int rh_dev_free(rh_ring* r, uint64_t* dptr) { if (r) (void)hipSetDevice(r->device); if (dptr) (void)hipFree(dptr); return RH_OK; }
+extern "C" int rh_dev_upload(rh_ring* r, uint64_t* dst, const uint64_t* src, size_t words) {
+  if (!r || !dst || !src) return rh_fail(RH_ERR_ARG, "rh_dev_upload: null argument");
+  hipError_t e = hipMemcpyAsync(dst, src, words * 8, hipMemcpyHostToDevice, r->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "upload: %s", hipGetErrorString(e));
+  return RH_OK;
+}
+extern "C" int rh_dev_download(rh_ring* r, uint64_t* dst, const uint64_t* src, size_t words) {
+  if (!r || !dst || !src) return rh_fail(RH_ERR_ARG, "rh_dev_download: null argument");
+  hipError_t e = hipMemcpyAsync(dst, src, words * 8, hipMemcpyDeviceToHost, r->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "download: %s", hipGetErrorString(e));
+  return RH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ NTT launches
+static int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "%s launch failed: %s", what, hipGetErrorString(e));
+  return RH_OK;
+}
+
+template <class P>
+static void launch_fwd_cols(int S1, dim3 grid, hipStream_t st, const u64* in, u64* out, const typename P::tw_t* tw,
+                            const LimbConsts* c, int L, int logN) {
+  switch (S1) {
+    case 1: ntt_fwd_cols<P, 1><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
+    case 2: ntt_fwd_cols<P, 2><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
+    case 3: ntt_fwd_cols<P, 3><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
+    case 4: ntt_fwd_cols<P, 4><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
+    case 5: ntt_fwd_cols<P, 5><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
+  }
+}
+static void launch_inv_cols(int S1, dim3 grid, hipStream_t st, u64* data, const tw2* tw, const tw2* lastw,
+                            const LimbConsts* c, int L, int logN) {
+  switch (S1) {
+    case 1: ntt_inv_cols<1><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN); break;
+    case 2: ntt_inv_cols<2><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN); break;
+    case 3: ntt_inv_cols<3><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN); break;
+    case 4: ntt_inv_cols<4><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN); break;
+    case 5: ntt_inv_cols<5><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN); break;
+  }
+}
+
+// limb0: first limb of the table set to use (host-pointer single-limb path); rows = npoly * Lrows
+int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy) {
+  const int logN = r->logN, N = r->N;
+  const size_t toff = (size_t)limb0 * N;
+  const LimbConsts* c = r->d_consts + limb0;
+  hipStream_t st = r->stream;
+  const unsigned rows = (unsigned)npoly * (unsigned)Lrows;
+  if (rows == 0) return RH_OK;
+  if (logN < LT) {
+    if (!inverse) {
+      if (lazy) ntt_fwd_small<MontPolicy><<<rows, 256, 0, st>>>(in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN, 0);
+      else      ntt_fwd_small<ShoupPolicy><<<rows, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, logN, 1);
+    } else {
+      ntt_inv_small<<<rows, 256, 0, st>>>(in, out, r->d_tw_inv + toff, c, Lrows, logN);
+    }
+    return check_launch("ntt_small");
+  }
+  const int S1 = logN - LT;
+  const unsigned tiles = rows << S1;
+  if (!inverse) {
+    const u64* src = in;
+    if (S1 > 0) {
+      dim3 g1(rows * 16);
+      if (lazy) launch_fwd_cols<MontPolicy>(S1, g1, st, in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN);
+      else      launch_fwd_cols<ShoupPolicy>(S1, g1, st, in, out, r->d_tw_fwd + toff, c, Lrows, logN);
+      src = out;
+    }
+    if (lazy) ntt_fwd_tile<MontPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd_mont + toff, c, Lrows, logN, 0);
+    else      ntt_fwd_tile<ShoupPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, 1);
+  } else {
+    ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, S1 == 0 ? 1 : 0);
+    if (S1 > 0) launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, logN);
+  }
+  return check_launch("ntt");
+}
+
+static int ntt_batch(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, bool inverse, bool lazy) {
+  if (!r || !in || !out) return rh_fail(RH_ERR_ARG, "ntt: null argument");
+  if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "ntt: level %d out of range [0,%d)", level, r->L);
+  if (npoly < 0) return rh_fail(RH_ERR_ARG, "ntt: npoly < 0");
+  (void)hipSetDevice(r->device);
+  if (r->kind == RH_RING_3N) return rh_ring3n_ntt_launch(r, in, out, npoly, level + 1, 0, inverse);
+  return rh_std_ntt_launch(r, in, out, npoly, level + 1, 0, inverse, lazy);
+}
+extern "C" int rh_ring_ntt(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, int lazy) { return ntt_batch(r, in, out, npoly, level, false, lazy != 0); }
+extern "C" int rh_ring_intt(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, int lazy) { return ntt_batch(r, in, out, npoly, level, true, lazy != 0); }
+
+// one limb, host pointers: the NumberTheoreticTransformer interface
+static int ntt_host_limb(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2, bool inverse, bool lazy) {
+  if (!r) return rh_fail(RH_ERR_ARG, "null ring");
+  if (!p1 || !p2) return rh_fail(RH_ERR_ARG, "cannot NTT: nil slice (len(p1), len(p2) must be >= N=%d)", r->N);
+  if (limb < 0 || limb >= r->L) return rh_fail(RH_ERR_ARG, "limb %d out of range [0,%d)", limb, r->L);
+  (void)hipSetDevice(r->device);
+  const size_t bytes = (size_t)r->N * 8;
+  hipError_t e = hipMemcpyAsync(r->d_scratch, p1, bytes, hipMemcpyHostToDevice, r->stream);
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "H2D: %s", hipGetErrorString(e));
+  int rc = (r->kind == RH_RING_3N) ? rh_ring3n_ntt_launch(r, r->d_scratch, r->d_scratch, 1, 1, limb, inverse)
+                                   : rh_std_ntt_launch(r, r->d_scratch, r->d_scratch, 1, 1, limb, inverse, lazy);
+  if (rc) return rc;
+  e = hipMemcpyAsync(p2, r->d_scratch, bytes, hipMemcpyDeviceToHost, r->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "D2H: %s", hipGetErrorString(e));
+  return RH_OK;
+}
+extern "C" int rh_ntt_forward(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2) { return ntt_host_limb(r, limb, p1, p2, false, false); }
+extern "C" int rh_ntt_forward_lazy(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2) { return ntt_host_limb(r, limb, p1, p2, false, true); }
+extern "C" int rh_ntt_backward(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2) { return ntt_host_limb(r, limb, p1, p2, true, false); }
+extern "C" int rh_ntt_backward_lazy(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2) { return ntt_host_limb(r, limb, p1, p2, true, true); }
+
+// ------------------------------------------------------------------------------------------------ element-wise
+struct ScalarPack { u64 s[RH_MAX_LIMBS]; };
+
+template <int OP>
+__global__ void __launch_bounds__(256)
+vec_op_packed(const u64* p1, const u64* p2, u64* p3, unsigned n, ScalarPack s0, ScalarPack s1,
+              const LimbConsts* __restrict__ consts, int L) {
+  const u32 row = blockIdx.x;
+  const u32 limb = row % (u32)L;
+  const LimbConsts c = consts[limb];
+  const u64 a0 = s0.s[limb], a1 = s1.s[limb];
+  const size_t rowoff = (size_t)row * n;
+  const unsigned npairs = n >> 1;
+  for (unsigned i = blockIdx.y * blockDim.x + threadIdx.x; i < npairs; i += gridDim.y * blockDim.x) {
+    const size_t o = rowoff + 2 * (size_t)i;
+    ulonglong2 x = make_ulonglong2(0, 0), y = x, z = x;
+    if (op_reads_x(OP)) x = *reinterpret_cast<const ulonglong2*>(p1 + o);
+    if (op_reads_y(OP)) y = *reinterpret_cast<const ulonglong2*>(p2 + o);
+    if (op_reads_z(OP)) z = *reinterpret_cast<const ulonglong2*>(p3 + o);
+    ulonglong2 w;
+    w.x = vec_apply<OP>(x.x, y.x, z.x, a0, a1, c);
+    w.y = vec_apply<OP>(x.y, y.y, z.y, a0, a1, c);
+    *reinterpret_cast<ulonglong2*>(p3 + o) = w;
+  }
+}
+
+typedef void (*vec_fn)(const u64*, const u64*, u64*, unsigned, ScalarPack, ScalarPack, const LimbConsts*, int);
+template <int... I>
+static const vec_fn* vec_table(std::integer_sequence<int, I...>) {
+  static const vec_fn t[] = {vec_op_packed<I>...};
+  return t;
+}
+
+int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3, int npoly, int Lrows, int limb0,
+                  const u64* s0, const u64* s1) {
+  static const vec_fn* table = vec_table(std::make_integer_sequence<int, RH_OP_COUNT>());
+  ScalarPack a, b;
+  memset(&a, 0, sizeof(a)); memset(&b, 0, sizeof(b));
+  if (s0) memcpy(a.s, s0, (size_t)Lrows * 8);
+  if (s1) memcpy(b.s, s1, (size_t)Lrows * 8);
+  const unsigned rows = (unsigned)npoly * (unsigned)Lrows;
+  if (rows == 0) return RH_OK;
+  const unsigned n = (unsigned)r->N;
+  unsigned chunks = (n / 2 + 256 * 4 - 1) / (256 * 4);
+  if (chunks < 1) chunks = 1;
+  if (chunks > 64) chunks = 64;
+  hipLaunchKernelGGL(table[opcode], dim3(rows, chunks), dim3(256), 0, r->stream, p1, p2, p3, n, a, b, r->d_consts + limb0, Lrows);
+  return check_launch("vec_op");
+}
+
+extern "C" int rh_ring_vec_op(rh_ring* r, int opcode, const uint64_t* p1, const uint64_t* p2, uint64_t* p3, int npoly, int level,
+                              const uint64_t* s0, const uint64_t* s1) {
+  if (!r || !p3) return rh_fail(RH_ERR_ARG, "vec_op: null argument");
+  if (opcode < 0 || opcode >= RH_OP_COUNT) return rh_fail(RH_ERR_ARG, "vec_op: unknown opcode %d", opcode);
+  if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "vec_op: level %d out of range [0,%d)", level, r->L);
+  if (npoly < 0) return rh_fail(RH_ERR_ARG, "vec_op: npoly < 0");
+  if (op_reads_x(opcode) && !p1) return rh_fail(RH_ERR_ARG, "vec_op %d: p1 is null", opcode);
+  if (op_reads_y(opcode) && !p2) return rh_fail(RH_ERR_ARG, "vec_op %d: p2 is null", opcode);
+  (void)hipSetDevice(r->device);
+  return rh_vec_launch(r, opcode, p1, p2, p3, npoly, level + 1, 0, s0, s1);
+}

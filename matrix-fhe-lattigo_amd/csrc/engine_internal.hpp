@@ -1,0 +1,40 @@
+// engine_internal.hpp -- shared between the translation units of libringhip (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <cstdint>
+#include "../../include/ringhip.h"
+#include "ring_types.cuh"
+
+#define RH_MAX_LIMBS 64
+
+int rh_fail(int code, const char* fmt, ...);
+
+struct rh_ring3n_state;   // ntt3n.hip
+
+struct rh_ring {
+  int device = 0, kind = 0, N = 0, logN = 0, L = 0;
+  hipStream_t stream = nullptr;
+  // host copies of what the Go side handed over (SubRing fields)
+  std::vector<uint64_t> moduli, mred, bred, ninv, roots_fwd, roots_bwd, omega3n;
+  std::vector<LimbConsts> hconsts;
+  // device tables
+  LimbConsts* d_consts = nullptr;
+  tw2* d_tw_fwd = nullptr;        // natural order, Shoup pairs of RootsForward (standard form)
+  tw2* d_tw_inv = nullptr;        // natural order, Shoup pairs of RootsBackward
+  u64* d_tw_fwd_mont = nullptr;   // natural order, RootsForward as given (Montgomery form)
+  tw2* d_twk_fwd = nullptr;       // kernel order (logN >= 12)
+  tw2* d_twk_inv = nullptr;
+  u64* d_twk_fwd_mont = nullptr;
+  tw2* d_lastw = nullptr;         // psi_bwd[1] * N^-1 per limb
+  u64* d_scratch = nullptr;       // 2N words for the host-pointer single-limb path
+  rh_ring3n_state* s3n = nullptr;
+};
+
+int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy);
+int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3, int npoly, int Lrows, int limb0,
+                  const u64* s0, const u64* s1);
+// 3N-cyclotomic transform (ntt3n.hip)
+int rh_ring3n_setup(rh_ring* r, std::vector<LimbConsts>& hc);
+void rh_ring3n_teardown(rh_ring* r);
+int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse);

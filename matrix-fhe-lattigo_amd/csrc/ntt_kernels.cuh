@@ -1,0 +1,347 @@
+// ntt_kernels.cuh -- negacyclic NTT / INTT over Z_q[X]/(X^N+1) for gfx950.
+//
+// Replaces ring/ntt.go: nttCoreLazy (:209-552), inttCoreLazy (:554-714) and the NTTStandard*/INTTStandard* wrappers
+// (:174-206) of the reference.  Data layout in HBM: (poly, limb, coefficient) contiguous u64, one launch covers a
+// whole batch.  Stage numbering follows the reference: forward stage s has m = 2^s blocks of 2t = N/2^s coefficients
+// and block i uses RootsForward[m+i] (:240-255); inverse stages run t = 1,2,4.. and use RootsBackward[h+i] (:590-605).
+//
+// Decomposition for N >= 4096 (LT = 12):
+//   forward:  K1 = the first S1 = log2(N)-12 stages, register radix-2^S1, each thread owns one column
+//             {c + 4096*k}: every load/store instruction of a wave is one contiguous 512 B segment; twiddles are
+//             wave-uniform (scalar loads).
+//             K2 = the last 12 stages on one contiguous 4096-coefficient tile (32 KiB) per 256-thread workgroup:
+//             three register radix-16 rounds, two exchanges through LDS (padded: bank-conflict free), a final LDS
+//             transpose so global stores are contiguous.  Twiddles come from a per-limb table already permuted
+//             into "kernel order" (engine.cpp: build_kernel_order) so every twiddle load is lane-contiguous.
+//   inverse:  the mirror image (K2 first, then K1 with N^-1 folded into the last stage's twiddles).
+// N < 4096: one workgroup per limb, all stages in LDS (ntt_small_*).
+//
+// Arithmetic policies (modarith.cuh):
+//   ShoupPolicy  -- fast path; values kept < 8q, outputs canonical.  Used by Forward, Backward, BackwardLazy
+//                   (all canonical in the reference for N >= 16).
+//   MontPolicy   -- the reference's MRedLazy butterfly with its reduce schedule (:315-318, :500-517); reproduces
+//                   ForwardLazy's exact representatives.
+#pragma once
+#include "modarith.cuh"
+
+#include "ring_types.cuh"
+
+// ---------------------------------------------------------------------------------------------------------------
+// policies
+// ---------------------------------------------------------------------------------------------------------------
+struct ShoupPolicy {
+  typedef tw2 tw_t;
+  u64 q, nq, q4;
+  RH_DEV void init(const LimbConsts& c) { q = c.q; nq = c.nq; q4 = 4 * c.q; }
+  // forward: U < 8q, V any -> X,Y < 8q
+  RH_DEV void fwd(u64& U, u64& V, const tw_t& w, bool /*reduce*/) const {
+    u64 u = csub(U, q4);
+    u64 X = shoup_mul_acc(V, w.w, w.wp, nq, u);      // u + r, r < 4q
+    V = ((u << 1) + q4) - X;                         // u + 4q - r
+    U = X;
+  }
+  // inverse: U,V < 4q -> X,Y < 4q
+  RH_DEV void inv(u64& U, u64& V, const tw_t& w) const {
+    u64 d = U + q4 - V;
+    U = csub(U + V, q4);
+    V = shoup_mul(d, w.w, w.wp, nq);
+  }
+  RH_DEV u64 fwd_final(u64 x, bool canonical) const { return canonical ? canon8(x, q) : x; }
+};
+
+struct MontPolicy {
+  typedef u64 tw_t;
+  u64 q, qinv, q2, q4;
+  RH_DEV void init(const LimbConsts& c) { q = c.q; qinv = c.qinv; q2 = 2 * c.q; q4 = 4 * c.q; }
+  RH_DEV void fwd(u64& U, u64& V, const tw_t& w, bool reduce) const {     // butterfly, ring/ntt.go:155-161
+    u64 u = U;
+    if (reduce) { if (u >= q4) u -= q4; }
+    u64 r = mred_lazy(V, w, q, qinv);
+    U = u + r; V = u + q2 - r;
+  }
+  RH_DEV void inv(u64& U, u64& V, const tw_t& w) const {                  // invbutterfly, ring/ntt.go:164-171
+    u64 x = U + V;
+    if (x >= q2) x -= q2;
+    V = mred_lazy(U + q4 - V, w, q, qinv);
+    U = x;
+  }
+  RH_DEV u64 fwd_final(u64 x, bool) const { return x; }
+};
+
+// reduce schedule of the reference for forward stage s (ring/ntt.go:223-257 for N<16, :271-310, :315-318, :500-517)
+RH_DEV bool ref_reduce(int s, int logN) {
+  if (logN < 4) return true;
+  if (s == 0) return false;
+  if (s == logN - 1) return true;
+  return (s & 1) == 0;          // bit-length(2^s) = s+1 odd
+}
+
+// one register radix-16 round: 4 stages over x[16]; stage u pairs (k, k + (8>>u)); twiddle slot (2^u - 1) + (k >> (4-u)).
+// TW(slot) yields the twiddle.  s0 = global index of the round's first stage (for the reduce schedule).
+template <class P, class TWF>
+RH_DEV void round16_fwd(const P& p, u64 (&x)[16], TWF TW, int s0, int logN) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int h = 8 >> u;
+    const bool red = ref_reduce(s0 + u, logN);
+#pragma unroll
+    for (int g = 0; g < (1 << u); ++g) {
+      typename P::tw_t w = TW((1 << u) - 1 + g);
+#pragma unroll
+      for (int e = 0; e < h; ++e) {
+        const int k = g * 2 * h + e;
+        p.fwd(x[k], x[k + h], w, red);
+      }
+    }
+  }
+}
+template <class P, class TWF>
+RH_DEV void round16_inv(const P& p, u64 (&x)[16], TWF TW) {
+#pragma unroll
+  for (int u = 3; u >= 0; --u) {
+    const int h = 8 >> u;
+#pragma unroll
+    for (int g = 0; g < (1 << u); ++g) {
+      typename P::tw_t w = TW((1 << u) - 1 + g);
+#pragma unroll
+      for (int e = 0; e < h; ++e) {
+        const int k = g * 2 * h + e;
+        p.inv(x[k], x[k + h], w);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2 forward: last 12 stages on a 4096-tile.  twk: kernel-order table, per limb N entries, per tile 4096 entries:
+//   [0,15) round A slots (uniform) | [16,256) round B: slot*16 + hi4 | [256,4096) round C: slot*256 + tid
+// ---------------------------------------------------------------------------------------------------------------
+template <class P>
+__global__ void __launch_bounds__(256)
+ntt_fwd_tile(const u64* in, u64* out, const typename P::tw_t* __restrict__ twk,
+             const LimbConsts* __restrict__ consts, int L, int logN, int canonical) {
+  __shared__ u64 lds[LDS_WORDS];
+  const int tid = threadIdx.x;
+  const u32 b = blockIdx.x;
+  const u32 limb = b % (u32)L;
+  const u32 r = b / (u32)L;
+  const int S1 = logN - LT;
+  const u32 tile = r & ((1u << S1) - 1);
+  const u32 poly = r >> S1;
+  const size_t base = (((size_t)poly * L + limb) << logN) + ((size_t)tile << LT);
+  const typename P::tw_t* tw = twk + ((size_t)limb << logN) + ((size_t)tile << LT);
+  P p; p.init(consts[limb]);
+
+  u64 x[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = in[base + tid + 256 * k];
+  // round A: in-tile bits 11..8 (k); twiddles wave-uniform
+  round16_fwd(p, x, [&](int slot) { return tw[slot]; }, S1, logN);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[LDS_PAD(tid + 256 * k)] = x[k];
+  __syncthreads();
+  // round B: j = (hi4<<8) | (k<<4) | lo4
+  const int hi4 = tid >> 4, lo4 = tid & 15;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = lds[LDS_PAD((hi4 << 8) | (k << 4) | lo4)];
+  round16_fwd(p, x, [&](int slot) { return tw[16 + slot * 16 + hi4]; }, S1 + 4, logN);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[LDS_PAD((hi4 << 8) | (k << 4) | lo4)] = x[k];
+  __syncthreads();
+  // round C: j = tid*16 + k
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = lds[LDS_PAD(tid * 16 + k)];
+  round16_fwd(p, x, [&](int slot) { return tw[256 + slot * 256 + tid]; }, S1 + 8, logN);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[LDS_PAD(tid * 16 + k)] = p.fwd_final(x[k], canonical != 0);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) out[base + tid + 256 * k] = lds[LDS_PAD(tid + 256 * k)];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2 inverse: first 12 stages (t = 1..2048) on a 4096-tile.  If `last` (logN == 12) the N^-1 scaling and the
+// canonical reduction happen here, else values leave < 4q for K1 inverse.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+ntt_inv_tile(const u64* in, u64* out, const tw2* __restrict__ twk,
+             const LimbConsts* __restrict__ consts, int L, int logN, int last) {
+  __shared__ u64 lds[LDS_WORDS];
+  const int tid = threadIdx.x;
+  const u32 b = blockIdx.x;
+  const u32 limb = b % (u32)L;
+  const u32 r = b / (u32)L;
+  const int S1 = logN - LT;
+  const u32 tile = r & ((1u << S1) - 1);
+  const u32 poly = r >> S1;
+  const size_t base = (((size_t)poly * L + limb) << logN) + ((size_t)tile << LT);
+  const tw2* tw = twk + ((size_t)limb << logN) + ((size_t)tile << LT);
+  const LimbConsts c = consts[limb];
+  ShoupPolicy p; p.init(c);
+
+  u64 x[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[LDS_PAD(tid + 256 * k)] = in[base + tid + 256 * k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = lds[LDS_PAD(tid * 16 + k)];
+  round16_inv(p, x, [&](int slot) { return tw[256 + slot * 256 + tid]; });
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[LDS_PAD(tid * 16 + k)] = x[k];
+  __syncthreads();
+  const int hi4 = tid >> 4, lo4 = tid & 15;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = lds[LDS_PAD((hi4 << 8) | (k << 4) | lo4)];
+  round16_inv(p, x, [&](int slot) { return tw[16 + slot * 16 + hi4]; });
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[LDS_PAD((hi4 << 8) | (k << 4) | lo4)] = x[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = lds[LDS_PAD(tid + 256 * k)];
+  round16_inv(p, x, [&](int slot) { return tw[slot]; });
+  if (last) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = canon4(shoup_mul(x[k], c.ninv_w, c.ninv_wp, c.nq), c.q);
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) out[base + tid + 256 * k] = x[k];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1 forward: first S1 stages, R = 2^S1 coefficients per thread at stride 4096.  twn: natural-order table
+// (RootsForward index), entries [1, R) are used and are wave-uniform.
+// ---------------------------------------------------------------------------------------------------------------
+template <class P, int S1>
+__global__ void __launch_bounds__(256)
+ntt_fwd_cols(const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
+             const LimbConsts* __restrict__ consts, int L, int logN) {
+  constexpr int R = 1 << S1;
+  const u32 b = blockIdx.x;
+  const u32 limb = b % (u32)L;
+  const u32 r = b / (u32)L;
+  const u32 cb = r & 15;            // 16 blocks of 256 columns per limb
+  const u32 poly = r >> 4;
+  const size_t base = (((size_t)poly * L + limb) << logN) + cb * 256 + threadIdx.x;
+  const typename P::tw_t* tw = twn + ((size_t)limb << logN);
+  P p; p.init(consts[limb]);
+  u64 x[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) x[k] = in[base + ((size_t)k << LT)];
+#pragma unroll
+  for (int s = 0; s < S1; ++s) {
+    const int h = R >> (s + 1);
+    const bool red = ref_reduce(s, logN);
+#pragma unroll
+    for (int g = 0; g < (1 << s); ++g) {
+      typename P::tw_t w = tw[(1 << s) + g];
+#pragma unroll
+      for (int e = 0; e < h; ++e) p.fwd(x[g * 2 * h + e], x[g * 2 * h + e + h], w, red);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) out[base + ((size_t)k << LT)] = x[k];
+}
+
+// K1 inverse: last S1 stages (t = 4096 .. N/2), in natural-order RootsBackward indexing, then N^-1 and canonical
+// reduction.  The last stage (h = 1) folds N^-1 into both outputs: X = (U+V)*ninv, Y = (U-V)*(psi*ninv);
+// lastw = Shoup pair of psi_bwd[1]*N^-1.
+template <int S1>
+__global__ void __launch_bounds__(256)
+ntt_inv_cols(u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
+             const LimbConsts* __restrict__ consts, int L, int logN) {
+  constexpr int R = 1 << S1;
+  const u32 b = blockIdx.x;
+  const u32 limb = b % (u32)L;
+  const u32 r = b / (u32)L;
+  const u32 cb = r & 15;
+  const u32 poly = r >> 4;
+  const size_t base = (((size_t)poly * L + limb) << logN) + cb * 256 + threadIdx.x;
+  const tw2* tw = twn + ((size_t)limb << logN);
+  const LimbConsts c = consts[limb];
+  ShoupPolicy p; p.init(c);
+  u64 x[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) x[k] = data[base + ((size_t)k << LT)];
+#pragma unroll
+  for (int s = S1 - 1; s >= 1; --s) {          // stage with h = 2^s blocks
+    const int hh = R >> (s + 1);
+#pragma unroll
+    for (int g = 0; g < (1 << s); ++g) {
+      tw2 w = tw[(1 << s) + g];
+#pragma unroll
+      for (int e = 0; e < hh; ++e) p.inv(x[g * 2 * hh + e], x[g * 2 * hh + e + hh], w);
+    }
+  }
+  {
+    const tw2 wl = lastw[limb];
+    constexpr int hh = R >> 1;
+#pragma unroll
+    for (int e = 0; e < hh; ++e) {
+      u64 U = x[e], V = x[e + hh];
+      u64 d = U + p.q4 - V;
+      x[e] = canon4(shoup_mul(U + V, c.ninv_w, c.ninv_wp, c.nq), c.q);
+      x[e + hh] = canon4(shoup_mul(d, wl.w, wl.wp, c.nq), c.q);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) data[base + ((size_t)k << LT)] = x[k];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// small rings (16 <= N <= 2048, also usable up to 4096): one workgroup per (poly, limb), all stages in LDS, natural-
+// order tables.  Not a throughput path (configs use N >= 4096); it exists so every ring size the reference's tests
+// use (N = 16..512, ring/ntt_test.go) runs on the device.
+// ---------------------------------------------------------------------------------------------------------------
+template <class P>
+__global__ void __launch_bounds__(256)
+ntt_fwd_small(const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
+              const LimbConsts* __restrict__ consts, int L, int logN, int canonical) {
+  __shared__ u64 lds[TILE];
+  const int N = 1 << logN;
+  const u32 limb = blockIdx.x % (u32)L;
+  const size_t base = (size_t)blockIdx.x << logN;
+  const typename P::tw_t* tw = twn + ((size_t)limb << logN);
+  P p; p.init(consts[limb]);
+  for (int j = threadIdx.x; j < N; j += blockDim.x) lds[j] = in[base + j];
+  __syncthreads();
+  for (int s = 0; s < logN; ++s) {
+    const int lt = logN - 1 - s;           // log2(t)
+    const bool red = ref_reduce(s, logN);
+    for (int bf = threadIdx.x; bf < (N >> 1); bf += blockDim.x) {
+      const int i = bf >> lt;
+      const int j = (i << (lt + 1)) + (bf & ((1 << lt) - 1));
+      u64 U = lds[j], V = lds[j + (1 << lt)];
+      p.fwd(U, V, tw[(1 << s) + i], red);
+      lds[j] = U; lds[j + (1 << lt)] = V;
+    }
+    __syncthreads();
+  }
+  for (int j = threadIdx.x; j < N; j += blockDim.x) out[base + j] = p.fwd_final(lds[j], canonical != 0);
+}
+
+__global__ void __launch_bounds__(256)
+ntt_inv_small(const u64* in, u64* out, const tw2* __restrict__ twn,
+              const LimbConsts* __restrict__ consts, int L, int logN) {
+  __shared__ u64 lds[TILE];
+  const int N = 1 << logN;
+  const u32 limb = blockIdx.x % (u32)L;
+  const size_t base = (size_t)blockIdx.x << logN;
+  const tw2* tw = twn + ((size_t)limb << logN);
+  const LimbConsts c = consts[limb];
+  ShoupPolicy p; p.init(c);
+  for (int j = threadIdx.x; j < N; j += blockDim.x) lds[j] = in[base + j];
+  __syncthreads();
+  for (int lt = 0; lt < logN; ++lt) {      // t = 2^lt, h = N/(2t)
+    const int h = N >> (lt + 1);
+    for (int bf = threadIdx.x; bf < (N >> 1); bf += blockDim.x) {
+      const int i = bf >> lt;
+      const int j = (i << (lt + 1)) + (bf & ((1 << lt) - 1));
+      u64 U = lds[j], V = lds[j + (1 << lt)];
+      p.inv(U, V, tw[h + i]);
+      lds[j] = U; lds[j + (1 << lt)] = V;
+    }
+    __syncthreads();
+  }
+  for (int j = threadIdx.x; j < N; j += blockDim.x)
+    out[base + j] = canon4(shoup_mul(lds[j], c.ninv_w, c.ninv_wp, c.nq), c.q);
+}

@@ -1,0 +1,17 @@
+// ring_types.cuh -- per-limb constant block, twiddle pair and tile geometry shared by host and device code.
+#pragma once
+#include "modarith.cuh"
+
+struct LimbConsts {
+  u64 q, qinv, bred0, bred1;   // Modulus, MRedConstant, BRedConstant[0], [1]
+  u64 nq;                      // 2^64 - q
+  u64 ninv_w, ninv_wp;         // N^-1 mod q (standard form) and its Shoup quotient
+  u64 ninv_mont;               // NInv as the reference stores it (Montgomery form)
+};
+
+struct tw2 { u64 w, wp; };     // Shoup pair: root in standard form, floor(root*2^64/q)
+
+#define LT 12
+#define TILE (1 << LT)
+#define LDS_PAD(j) ((j) + ((j) >> 4))
+#define LDS_WORDS (TILE + (TILE >> 4))
