@@ -1,0 +1,326 @@
+"""ctypes binding of libringhip.so + thin mirror of the reference's ring.Ring API.
+
+Names follow the reference (ring/ring.go, ring/ntt.go, ring/operations.go, ring/basis_extension.go):
+Ring.NTT / NTTLazy / INTT / INTTLazy, Ring.Add / Sub / Neg / Reduce / MulCoeffsMontgomery / ..., SubRing.NTT etc.
+Polynomials live on the device as (npoly, level+1, N) uint64 blocks (DevicePoly)."""
+import ctypes as C
+import os
+import re
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+U64P = C.POINTER(C.c_uint64)
+
+Standard = 0   # ring.Standard (ring/ring.go Type)
+Matrix3N = 2   # 3N-cyclotomic ring (ring.Matrix, ring/ring.go:299-304)
+
+
+class RingHipError(RuntimeError):
+    """Raised for any non-zero rh_status; the Go wrapper panics / returns error at the same places."""
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "libringhip.so")
+
+
+_lib = None
+
+
+def _opcodes():
+    txt = open(os.path.join(_ROOT, "include", "ringhip_ops.h")).read()
+    return {m.group(1): int(m.group(2)) for m in re.finditer(r"RH_OP_([A-Z0-9_]+)\s*=\s*(\d+)", txt)}
+
+
+OPS = _opcodes()
+
+
+def lib():
+    """Loads the HIP library.  No fallback: a missing library is a hard error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RingHipError("libringhip.so not built (%s): run `make` or __graft_entry__.build()" % path)
+    L = C.CDLL(path)
+    i, vp, sz = C.c_int, C.c_void_p, C.c_size_t
+    sig = {
+        "rh_last_error": (C.c_char_p, []),
+        "rh_device_count": (i, []),
+        "rh_ring_create": (i, [C.POINTER(vp), i, i, i, i, U64P, U64P, U64P, U64P, U64P, U64P, U64P]),
+        "rh_ring_create_auto": (i, [C.POINTER(vp), i, i, i, i, U64P, U64P]),
+        "rh_ring_destroy": (None, [vp]),
+        "rh_ring_n": (i, [vp]), "rh_ring_limbs": (i, [vp]),
+        "rh_ring_get_constants": (i, [vp, U64P, U64P, U64P, U64P, U64P, U64P, U64P]),
+        "rh_ring_set_stream": (i, [vp, vp]), "rh_ring_sync": (i, [vp]),
+        "rh_dev_alloc": (i, [vp, sz, C.POINTER(vp)]), "rh_dev_free": (i, [vp, vp]),
+        "rh_dev_upload": (i, [vp, vp, U64P, sz]), "rh_dev_download": (i, [vp, U64P, vp, sz]),
+        "rh_ntt_forward": (i, [vp, i, U64P, U64P]), "rh_ntt_forward_lazy": (i, [vp, i, U64P, U64P]),
+        "rh_ntt_backward": (i, [vp, i, U64P, U64P]), "rh_ntt_backward_lazy": (i, [vp, i, U64P, U64P]),
+        "rh_ring_ntt": (i, [vp, vp, vp, i, i, i]), "rh_ring_intt": (i, [vp, vp, vp, i, i, i]),
+        "rh_ring_vec_op": (i, [vp, i, vp, vp, vp, i, i, U64P, U64P]),
+        "rh_bext_create": (i, [C.POINTER(vp), vp, vp]), "rh_bext_destroy": (None, [vp]),
+        "rh_bext_modup_q_to_p": (i, [vp, i, i, vp, vp, i]), "rh_bext_modup_p_to_q": (i, [vp, i, i, vp, vp, i]),
+        "rh_bext_moddown_qp_to_q": (i, [vp, i, i, vp, vp, vp, i]),
+        "rh_bext_moddown_qp_to_q_ntt": (i, [vp, i, i, vp, vp, vp, i]),
+        "rh_bext_moddown_qp_to_p": (i, [vp, i, i, vp, vp, vp, i]),
+        "rh_bext_decompose_and_split": (i, [vp, i, i, i, i, vp, vp, vp, i]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise RingHipError("ringhip status %d: %s" % (rc, lib().rh_last_error().decode()))
+
+
+def _u64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
+
+
+def _p(a):
+    return a.ctypes.data_as(U64P) if a is not None else None
+
+
+class DevicePoly:
+    """Device-resident block of `npoly` polynomials with `limbs` limbs of N words: replaces Poly.Coeffs [][]uint64
+    (ring/poly.go:13-24).  Either owns hipMalloc'd memory or wraps an external device pointer (e.g. a torch tensor)."""
+
+    def __init__(self, ring, npoly, limbs, ptr=None, owner=None):
+        self.ring, self.npoly, self.limbs = ring, int(npoly), int(limbs)
+        self.words = self.npoly * self.limbs * ring.N
+        self._own = ptr is None
+        self._owner = owner
+        if ptr is None:
+            p = C.c_void_p()
+            _check(lib().rh_dev_alloc(ring._h, max(self.words, 1), C.byref(p)))
+            ptr = p.value
+        self.ptr = int(ptr)
+
+    @classmethod
+    def from_numpy(cls, ring, arr):
+        arr = _u64(arr)
+        if arr.ndim == 2:
+            arr = arr[None]
+        assert arr.ndim == 3 and arr.shape[2] == ring.N, arr.shape
+        p = cls(ring, arr.shape[0], arr.shape[1])
+        _check(lib().rh_dev_upload(ring._h, p.ptr, _p(arr), arr.size))
+        return p
+
+    @classmethod
+    def from_torch(cls, ring, t):
+        """wraps an int64/uint64 CUDA tensor of shape (npoly, limbs, N) without copying"""
+        assert t.is_cuda and t.is_contiguous() and t.element_size() == 8 and t.dim() == 3 and t.shape[2] == ring.N
+        return cls(ring, t.shape[0], t.shape[1], ptr=t.data_ptr(), owner=t)
+
+    def numpy(self):
+        out = np.empty((self.npoly, self.limbs, self.ring.N), dtype=np.uint64)
+        _check(lib().rh_dev_download(self.ring._h, _p(out), self.ptr, out.size))
+        return out
+
+    def free(self):
+        if self._own and self.ptr:
+            lib().rh_dev_free(self.ring._h, self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class SubRing:
+    """One modulus of a Ring: the NumberTheoreticTransformer seam (ring/ntt.go:17-22, ring/subring_ops.go:235-252).
+    Host slices in, host slices out, one limb per call -- the call shape the Go interface has."""
+
+    def __init__(self, ring, idx):
+        self.ring, self.idx = ring, idx
+        self.N = ring.N
+        self.Modulus = int(ring.moduli[idx])
+
+    def _call(self, fn, p1):
+        p1 = _u64(p1)
+        if p1.size < self.N:
+            raise RingHipError("cannot NTT: ensure that len(p1)=%d >= N=%d" % (p1.size, self.N))
+        p2 = np.empty(self.N, dtype=np.uint64)
+        _check(fn(self.ring._h, self.idx, _p(p1), _p(p2)))
+        return p2
+
+    def NTT(self, p1):
+        return self._call(lib().rh_ntt_forward, p1)
+
+    def NTTLazy(self, p1):
+        return self._call(lib().rh_ntt_forward_lazy, p1)
+
+    def INTT(self, p1):
+        return self._call(lib().rh_ntt_backward, p1)
+
+    def INTTLazy(self, p1):
+        return self._call(lib().rh_ntt_backward_lazy, p1)
+
+
+class Ring:
+    """ring.Ring (ring/ring.go:76-89) on one MI355X.  NewRing(N, moduli) == Ring(N, moduli);
+    NewRingFromType(N, moduli, ring.Matrix) == Ring(N, moduli, kind=Matrix3N).
+    `constants` (dict with mred, bred, ninv, roots_fwd, roots_bwd / omega3n) plays the role of the SubRing fields the
+    Go shim hands over through rh_ring_create; without it the engine generates them (rh_ring_create_auto)."""
+
+    def __init__(self, N, moduli, kind=Standard, device=0, constants=None, omega3n=None):
+        self.N, self.kind, self.device = int(N), kind, device
+        self.moduli = _u64(moduli)
+        self.L = len(self.moduli)
+        h = C.c_void_p()
+        if constants is None:
+            om = _u64(omega3n) if omega3n is not None else None
+            _check(lib().rh_ring_create_auto(C.byref(h), device, kind, self.N, self.L, _p(self.moduli), _p(om)))
+        else:
+            g = lambda k: _u64(constants[k]) if constants.get(k) is not None else None
+            keep = [g(k) for k in ("mred", "bred", "ninv", "roots_fwd", "roots_bwd", "omega3n")]
+            _check(lib().rh_ring_create(C.byref(h), device, kind, self.N, self.L, _p(self.moduli), *[_p(a) for a in keep]))
+        self._h = h
+        self.level = self.L - 1
+        self.SubRings = [SubRing(self, i) for i in range(self.L)]
+
+    # ---- construction helpers -------------------------------------------------------------------------------
+    def constants(self):
+        mred = np.zeros(self.L, dtype=np.uint64); bred = np.zeros(2 * self.L, dtype=np.uint64)
+        ninv = np.zeros(self.L, dtype=np.uint64)
+        out = {"mred": mred, "bred": bred.reshape(self.L, 2), "ninv": ninv}
+        if self.kind == Standard:
+            rf = np.zeros((self.L, self.N), dtype=np.uint64); rb = np.zeros((self.L, self.N), dtype=np.uint64)
+            _check(lib().rh_ring_get_constants(self._h, None, _p(mred), _p(bred), _p(ninv), _p(rf), _p(rb), None))
+            out.update(roots_fwd=rf, roots_bwd=rb)
+        else:
+            om = np.zeros(self.L, dtype=np.uint64)
+            _check(lib().rh_ring_get_constants(self._h, None, _p(mred), _p(bred), None, None, None, _p(om)))
+            out.update(omega3n=om)
+        return out
+
+    def AtLevel(self, level):
+        """view restricted to limbs 0..level (ring/ring.go:194-213): the same engine handle, smaller loops"""
+        if level < 0 or level >= self.L:
+            raise RingHipError("level %d out of range" % level)
+        v = object.__new__(Ring)
+        v.__dict__.update(self.__dict__)
+        v.level = level
+        v._view = True
+        return v
+
+    def NewPoly(self, npoly=1):
+        return DevicePoly(self, npoly, self.level + 1)
+
+    def set_stream(self, stream_ptr):
+        _check(lib().rh_ring_set_stream(self._h, stream_ptr))
+
+    def sync(self):
+        _check(lib().rh_ring_sync(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) and not getattr(self, "_view", False):
+            lib().rh_ring_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- NTT (ring/ntt.go:127-152) -----------------------------------------------------------------------------
+    def _chk(self, *polys):
+        for p in polys:
+            if p is not None and (p.limbs < self.level + 1):
+                raise RingHipError("poly has %d limbs, ring level needs %d" % (p.limbs, self.level + 1))
+
+    def NTT(self, p1, p2):
+        self._chk(p1, p2); _check(lib().rh_ring_ntt(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 0))
+
+    def NTTLazy(self, p1, p2):
+        self._chk(p1, p2); _check(lib().rh_ring_ntt(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 1))
+
+    def INTT(self, p1, p2):
+        self._chk(p1, p2); _check(lib().rh_ring_intt(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 0))
+
+    def INTTLazy(self, p1, p2):
+        self._chk(p1, p2); _check(lib().rh_ring_intt(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 1))
+
+    # ---- element-wise (ring/operations.go -> ring/vec_ops.go) --------------------------------------------------
+    def vec_op(self, op, p1, p2, p3, s0=None, s1=None):
+        code = OPS[op] if isinstance(op, str) else int(op)
+        self._chk(p1, p2, p3)
+        a = _u64(s0) if s0 is not None else None
+        b = _u64(s1) if s1 is not None else None
+        _check(lib().rh_ring_vec_op(self._h, code, p1.ptr if p1 is not None else None, p2.ptr if p2 is not None else None,
+                                    p3.ptr, p3.npoly, self.level, _p(a), _p(b)))
+
+    def Add(self, p1, p2, p3): self.vec_op("ADD", p1, p2, p3)
+    def AddLazy(self, p1, p2, p3): self.vec_op("ADD_LAZY", p1, p2, p3)
+    def Sub(self, p1, p2, p3): self.vec_op("SUB", p1, p2, p3)
+    def SubLazy(self, p1, p2, p3): self.vec_op("SUB_LAZY", p1, p2, p3)
+    def Neg(self, p1, p2): self.vec_op("NEG", p1, None, p2)
+    def Reduce(self, p1, p2): self.vec_op("REDUCE", p1, None, p2)
+    def ReduceLazy(self, p1, p2): self.vec_op("REDUCE_LAZY", p1, None, p2)
+    def MulCoeffsBarrett(self, p1, p2, p3): self.vec_op("MUL_BARRETT", p1, p2, p3)
+    def MulCoeffsBarrettLazy(self, p1, p2, p3): self.vec_op("MUL_BARRETT_LAZY", p1, p2, p3)
+    def MulCoeffsBarrettThenAdd(self, p1, p2, p3): self.vec_op("MUL_BARRETT_THEN_ADD", p1, p2, p3)
+    def MulCoeffsBarrettThenAddLazy(self, p1, p2, p3): self.vec_op("MUL_BARRETT_THEN_ADD_LAZY", p1, p2, p3)
+    def MulCoeffsMontgomery(self, p1, p2, p3): self.vec_op("MUL_MONT", p1, p2, p3)
+    def MulCoeffsMontgomeryLazy(self, p1, p2, p3): self.vec_op("MUL_MONT_LAZY", p1, p2, p3)
+    def MulCoeffsMontgomeryThenAdd(self, p1, p2, p3): self.vec_op("MUL_MONT_THEN_ADD", p1, p2, p3)
+    def MulCoeffsMontgomeryThenAddLazy(self, p1, p2, p3): self.vec_op("MUL_MONT_THEN_ADD_LAZY", p1, p2, p3)
+    def MulCoeffsMontgomeryLazyThenAddLazy(self, p1, p2, p3): self.vec_op("MUL_MONT_LAZY_THEN_ADD_LAZY", p1, p2, p3)
+    def MulCoeffsMontgomeryThenSub(self, p1, p2, p3): self.vec_op("MUL_MONT_THEN_SUB", p1, p2, p3)
+    def MulCoeffsMontgomeryThenSubLazy(self, p1, p2, p3): self.vec_op("MUL_MONT_THEN_SUB_LAZY", p1, p2, p3)
+    def MulCoeffsMontgomeryLazyThenSubLazy(self, p1, p2, p3): self.vec_op("MUL_MONT_LAZY_THEN_SUB_LAZY", p1, p2, p3)
+    def MulCoeffsMontgomeryLazyThenNeg(self, p1, p2, p3): self.vec_op("MUL_MONT_LAZY_THEN_NEG", p1, p2, p3)
+    def MForm(self, p1, p2): self.vec_op("MFORM", p1, None, p2)
+    def MFormLazy(self, p1, p2): self.vec_op("MFORM_LAZY", p1, None, p2)
+    def IMForm(self, p1, p2): self.vec_op("IMFORM", p1, None, p2)
+    def MulRNSScalarMontgomery(self, p1, scalar, p2): self.vec_op("MUL_SCALAR_MONT", p1, None, p2, s0=scalar)
+    def AddScalar(self, p1, scalar, p2): self.vec_op("ADD_SCALAR", p1, None, p2, s0=scalar)
+    def SubScalar(self, p1, scalar, p2): self.vec_op("SUB_SCALAR", p1, None, p2, s0=scalar)
+
+
+class BasisExtender:
+    """ring.BasisExtender (ring/basis_extension.go:13-79) over a (ringQ, ringP) pair on the same device."""
+
+    def __init__(self, ringQ, ringP):
+        self.ringQ, self.ringP = ringQ, ringP
+        h = C.c_void_p()
+        _check(lib().rh_bext_create(C.byref(h), ringQ._h, ringP._h))
+        self._h = h
+
+    def ModUpQtoP(self, levelQ, levelP, polQ, polP):
+        _check(lib().rh_bext_modup_q_to_p(self._h, levelQ, levelP, polQ.ptr, polP.ptr, polQ.npoly))
+
+    def ModUpPtoQ(self, levelP, levelQ, polP, polQ):
+        _check(lib().rh_bext_modup_p_to_q(self._h, levelP, levelQ, polP.ptr, polQ.ptr, polP.npoly))
+
+    def ModDownQPtoQ(self, levelQ, levelP, p1Q, p1P, p2Q):
+        _check(lib().rh_bext_moddown_qp_to_q(self._h, levelQ, levelP, p1Q.ptr, p1P.ptr, p2Q.ptr, p1Q.npoly))
+
+    def ModDownQPtoQNTT(self, levelQ, levelP, p1Q, p1P, p2Q):
+        _check(lib().rh_bext_moddown_qp_to_q_ntt(self._h, levelQ, levelP, p1Q.ptr, p1P.ptr, p2Q.ptr, p1Q.npoly))
+
+    def ModDownQPtoP(self, levelQ, levelP, p1Q, p1P, p2P):
+        _check(lib().rh_bext_moddown_qp_to_p(self._h, levelQ, levelP, p1Q.ptr, p1P.ptr, p2P.ptr, p1Q.npoly))
+
+    def DecomposeAndSplit(self, levelQ, levelP, nbPi, digit, p0Q, p1Q, p1P):
+        _check(lib().rh_bext_decompose_and_split(self._h, levelQ, levelP, nbPi, digit, p0Q.ptr, p1Q.ptr, p1P.ptr, p0Q.npoly))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rh_bext_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

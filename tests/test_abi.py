@@ -1,0 +1,47 @@
+"""CPU: the C-ABI library loads and exports every symbol include/ringhip.h declares; host-side argument checks
+that need no device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "ringhip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rh_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(rh):
+    lib = rh.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), "libringhip.so does not export %s" % s
+
+
+def test_opcode_table_matches_reference_count(rh):
+    ops = {k: v for k, v in rh.OPS.items() if k != "COUNT"}
+    assert rh.OPS["COUNT"] == 38 == len(ops)          # 38 functions in ring/vec_ops.go
+    assert sorted(ops.values()) == list(range(38))
+
+
+def test_argument_errors_without_device(rh):
+    lib = rh.lib()
+    h = C.c_void_p()
+    q = np.array([0x1fffffffffe00001], dtype=np.uint64)
+    qp = q.ctypes.data_as(rh.ringhip.U64P)
+    # invalid degree -> error code + message, never a crash (constructors return error in the reference: ring.go:321-331)
+    assert lib.rh_ring_create_auto(C.byref(h), 0, rh.Standard, 24, 1, qp, None) == -1
+    assert b"invalid ring degree" in lib.rh_last_error()
+    bad = np.array([0x1fffffffffe00003], dtype=np.uint64)
+    assert lib.rh_ring_create_auto(C.byref(h), 0, rh.Standard, 4096, 1, bad.ctypes.data_as(rh.ringhip.U64P), None) == -2
+    assert b"not prime" in lib.rh_last_error()
+    notfriendly = np.array([1000003], dtype=np.uint64)
+    assert lib.rh_ring_create_auto(C.byref(h), 0, rh.Standard, 4096, 1, notfriendly.ctypes.data_as(rh.ringhip.U64P), None) == -2
+    assert b"!= 1 mod NthRoot" in lib.rh_last_error()
+    assert lib.rh_ring_ntt(None, None, None, 1, 0, 0) == -1

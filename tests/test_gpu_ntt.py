@@ -1,0 +1,141 @@
+"""GPU: negacyclic NTT parity through the C ABI -- bit-exact against the reference's KATs and the pinned oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import QI60, uniform_mod
+
+pytestmark = pytest.mark.gpu
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ntt_kat.json")))["vectors"]
+
+
+@pytest.mark.parametrize("vec", KAT, ids=lambda v: "N=%d" % v["N"])
+def test_kat_through_transformer_interface(rh, vec):
+    # TestNTT (ring/ntt_test.go:91-121) through the per-limb NumberTheoreticTransformer seam, engine-generated tables
+    ring = rh.Ring(vec["N"], vec["Qis"])
+    for i, (a, b) in enumerate(zip(vec["poly"], vec["polyNTT"])):
+        y = ring.SubRings[i].NTT(a)
+        assert np.array_equal(y, np.array(b, dtype=np.uint64))
+        assert np.array_equal(ring.SubRings[i].INTT(y), np.array(a, dtype=np.uint64))
+        assert np.array_equal(ring.SubRings[i].INTTLazy(y), np.array(a, dtype=np.uint64))
+    ring.close()
+
+
+@pytest.mark.parametrize("vec", KAT, ids=lambda v: "N=%d" % v["N"])
+def test_kat_batched_ring_ntt(rh, vec):
+    # Ring.NTT on a device-resident 2-limb poly, batch of 3 copies
+    ring = rh.Ring(vec["N"], vec["Qis"])
+    a = np.array(vec["poly"], dtype=np.uint64)
+    p = rh.DevicePoly.from_numpy(ring, np.stack([a, a, a]))
+    ring.NTT(p, p)                       # in place, like ring/ntt_benchmark_test.go:42
+    out = p.numpy()
+    for k in range(3):
+        assert np.array_equal(out[k], np.array(vec["polyNTT"], dtype=np.uint64))
+    ring.INTT(p, p)
+    assert np.array_equal(p.numpy()[1], a)
+    ring.close()
+
+
+@pytest.mark.parametrize("logN", [4, 6, 9, 11, 12, 13, 14, 15, 16])
+def test_forward_inverse_lazy_vs_oracle(rh, oracle, logN):
+    N = 1 << logN
+    mods = QI60[:3]
+    rng = np.random.default_rng(100 + logN)
+    srs = [oracle.SubRingConsts(N, q) for q in mods]
+    # hand the engine the oracle's (= reference-rule) constants, the way the Go shim hands over SubRing fields
+    consts = dict(mred=[s.mred for s in srs], bred=np.stack([s.bred for s in srs]), ninv=[s.ninv for s in srs],
+                  roots_fwd=np.stack([s.roots_fwd for s in srs]), roots_bwd=np.stack([s.roots_bwd for s in srs]))
+    ring = rh.Ring(N, mods, constants=consts)
+    npoly = 2
+    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(npoly)])
+    # edge values in the first poly
+    a[0, :, 0] = 0; a[0, :, 1] = np.array(mods, dtype=np.uint64) - np.uint64(1); a[0, :, 2] = 1
+    p = rh.DevicePoly.from_numpy(ring, a)
+    o = ring.NewPoly(npoly)
+    ring.NTT(p, o)
+    got = o.numpy()
+    exp = np.stack([np.stack([oracle.ntt(a[k, i], srs[i]) for i in range(len(mods))]) for k in range(npoly)])
+    assert np.array_equal(got, exp)
+    # NTTLazy: exactly the reference's representatives (reduce schedule of nttUnrolled16Lazy)
+    ring.NTTLazy(p, o)
+    expl = np.stack([np.stack([oracle.ntt(a[k, i], srs[i], lazy=True) for i in range(len(mods))]) for k in range(npoly)])
+    assert np.array_equal(o.numpy(), expl)
+    # INTT / INTTLazy from the canonical NTT values
+    pn = rh.DevicePoly.from_numpy(ring, exp)
+    ring.INTT(pn, o)
+    assert np.array_equal(o.numpy(), a)
+    ring.INTTLazy(pn, o)
+    assert np.array_equal(o.numpy(), a)
+    # INTT accepts lazy inputs (< 2q): NTTLazy output reduced once is < 2q? use exp + q on some entries
+    lazy_in = exp.copy()
+    lazy_in[:, :, ::3] += np.array(mods, dtype=np.uint64)[None, :, None]
+    pl = rh.DevicePoly.from_numpy(ring, lazy_in)
+    ring.INTT(pl, o)
+    assert np.array_equal(o.numpy(), a)
+    # engine-generated constants are the same as the oracle's
+    c = ring.constants()
+    ring2 = rh.Ring(N, mods)
+    c2 = ring2.constants()
+    for k in ("mred", "bred", "ninv", "roots_fwd", "roots_bwd"):
+        assert np.array_equal(np.asarray(c[k], dtype=np.uint64).reshape(-1), np.asarray(c2[k], dtype=np.uint64).reshape(-1)), k
+    ring.close(); ring2.close()
+
+
+def test_levels_use_leading_limbs(rh, oracle):
+    # Ring.AtLevel(level).NTT touches limbs 0..level only (ring/ntt.go:127-131)
+    N, mods = 4096, QI60[:4]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(7)
+    a = np.stack([uniform_mod(rng, q, N) for q in mods[:2]])[None]
+    p = rh.DevicePoly.from_numpy(ring, a)
+    ring.AtLevel(1).NTT(p, p)
+    srs = [oracle.SubRingConsts(N, q) for q in mods[:2]]
+    assert np.array_equal(p.numpy()[0], np.stack([oracle.ntt(a[0, i], srs[i]) for i in range(2)]))
+    ring.close()
+
+
+def test_metric_size_properties(rh, oracle):
+    # BASELINE metric size: N = 2^16, 16 limbs, batch of 4.  Full-size checks through size-independent properties:
+    # (1) INTT(NTT(a)) == a, (2) linearity NTT(a+b) == NTT(a)+NTT(b) mod q, (3) one limb of one poly against the oracle,
+    # (4) negacyclic convolution theorem on a sparse pair.
+    N, mods = 1 << 16, QI60[:16]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(2026)
+    B = 4
+    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    b = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    pa, pb = rh.DevicePoly.from_numpy(ring, a), rh.DevicePoly.from_numpy(ring, b)
+    na, nb, ns = ring.NewPoly(B), ring.NewPoly(B), ring.NewPoly(B)
+    ring.NTT(pa, na); ring.NTT(pb, nb)
+    ring.Add(pa, pb, ns); ring.NTT(ns, ns)
+    ring.Add(na, nb, na)
+    assert np.array_equal(ns.numpy(), na.numpy())
+    ring.INTT(nb, nb)
+    assert np.array_equal(nb.numpy(), b)
+    sr = oracle.SubRingConsts(N, mods[5])
+    ring.NTT(pb, nb)
+    assert np.array_equal(nb.numpy()[2, 5], oracle.ntt(b[2, 5], sr))
+    assert np.array_equal(nb.numpy()[3, 15], oracle.ntt(b[3, 15], oracle.SubRingConsts(N, mods[15])))
+    # X^i * X^j = X^(i+j) with sign flip past N (negacyclic): MForm + MulCoeffsMontgomery as schemes/ckks/evaluator.go:821-834
+    x = np.zeros((1, 16, N), dtype=np.uint64); y = np.zeros((1, 16, N), dtype=np.uint64)
+    x[0, :, N - 3] = 5; y[0, :, 7] = 11
+    px, py = rh.DevicePoly.from_numpy(ring, x), rh.DevicePoly.from_numpy(ring, y)
+    ring.NTT(px, px); ring.NTT(py, py); ring.MForm(px, px); ring.MulCoeffsMontgomery(px, py, px); ring.INTT(px, px)
+    z = px.numpy()[0]
+    for i, q in enumerate(mods):
+        exp = np.zeros(N, dtype=np.uint64); exp[4] = q - 55
+        assert np.array_equal(z[i], exp)
+    ring.close()
+
+
+def test_errors_match_reference_behaviour(rh):
+    ring = rh.Ring(64, QI60[:1])
+    with pytest.raises(rh.RingHipError):          # short slice -> panic in ring/ntt.go:212-214
+        ring.SubRings[0].NTT(np.zeros(10, dtype=np.uint64))
+    with pytest.raises(rh.RingHipError):
+        ring.AtLevel(3)
+    ring.close()
+    with pytest.raises(rh.RingHipError):          # duplicate moduli rejected (ring/ring.go:326-331)
+        rh.Ring(64, [QI60[0], QI60[0]])

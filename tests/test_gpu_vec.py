@@ -1,0 +1,67 @@
+"""GPU: every element-wise kernel of ring/vec_ops.go, bit-exact against the oracle (formulas incl. the lazy forms)."""
+import numpy as np
+import pytest
+
+from conftest import QI60, uniform_mod
+
+pytestmark = pytest.mark.gpu
+
+
+def ops_table(rh):
+    return sorted((v, k) for k, v in rh.OPS.items() if k != "COUNT")
+
+
+@pytest.mark.parametrize("N", [16, 4096, 1 << 15])
+def test_all_vec_ops_vs_oracle(rh, oracle, N):
+    mods = QI60[:3]
+    ring = rh.Ring(N, mods) if N >= 16 else None
+    rng = np.random.default_rng(N)
+    npoly = 2
+    shape = (npoly, len(mods), N)
+    qs = np.array(mods, dtype=np.uint64)[None, :, None]
+    x = rng.integers(0, 1 << 62, size=shape, dtype=np.uint64) % qs
+    y = rng.integers(0, 1 << 62, size=shape, dtype=np.uint64) % qs
+    z = rng.integers(0, 1 << 62, size=shape, dtype=np.uint64) % qs
+    # edge operands (ring/ring_test.go:534-670 style): 0, 1, q-1
+    x[0, :, 0] = 0; x[0, :, 1] = 1; x[0, :, 2] = qs[0, :, 0] - np.uint64(1)
+    y[0, :, 0] = qs[0, :, 0] - np.uint64(1); y[0, :, 1] = qs[0, :, 0] - np.uint64(1); y[0, :, 2] = qs[0, :, 0] - np.uint64(1)
+    s0 = np.array([int(rng.integers(1, q)) for q in mods], dtype=np.uint64)
+    s1 = np.array([int(rng.integers(1, q)) for q in mods], dtype=np.uint64)
+    px, py = rh.DevicePoly.from_numpy(ring, x), rh.DevicePoly.from_numpy(ring, y)
+    for code, name in ops_table(rh):
+        a0, a1 = s0, s1
+        if name == "MASK":
+            a0 = np.array([7, 13, 0], dtype=np.uint64); a1 = np.array([(1 << 20) - 1, 0xffff, (1 << 61) - 1], dtype=np.uint64)
+        pz = rh.DevicePoly.from_numpy(ring, z)
+        ring.vec_op(name, px, py, pz, s0=a0, s1=a1)
+        got = pz.numpy()
+        for k in range(npoly):
+            for i, q in enumerate(mods):
+                exp = oracle.vec_op(code, x[k, i], y[k, i], z[k, i], a0[i], a1[i], q)
+                assert np.array_equal(got[k, i], exp), (name, k, i)
+        pz.free()
+    # in-place use (p1 is p3), as the reference's callers do
+    pz = rh.DevicePoly.from_numpy(ring, x)
+    ring.MulCoeffsMontgomery(pz, py, pz)
+    exp = np.stack([np.stack([oracle.vec_op(rh.OPS["MUL_MONT"], x[k, i], y[k, i], x[k, i], 0, 0, mods[i]) for i in range(3)]) for k in range(npoly)])
+    assert np.array_equal(pz.numpy(), exp)
+    ring.close()
+
+
+def test_lazy_inputs_full_range(rh, oracle):
+    # lazy kernels take any 64-bit operand; check wrap-around behaviour is identical
+    N, mods = 64, QI60[:2]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 1 << 64, size=(1, 2, N), dtype=np.uint64)
+    y = rng.integers(0, 1 << 64, size=(1, 2, N), dtype=np.uint64)
+    z = rng.integers(0, 1 << 64, size=(1, 2, N), dtype=np.uint64)
+    px, py = rh.DevicePoly.from_numpy(ring, x), rh.DevicePoly.from_numpy(ring, y)
+    for name in ["ADD_LAZY", "SUB_LAZY", "MUL_LAZY", "MUL_LAZY_THEN_ADD_LAZY", "REDUCE", "REDUCE_LAZY", "MUL_BARRETT",
+                 "MUL_BARRETT_LAZY", "MUL_MONT_LAZY", "MUL_MONT_LAZY_THEN_ADD_LAZY", "MFORM_LAZY", "MUL_MONT_LAZY_THEN_NEG"]:
+        pz = rh.DevicePoly.from_numpy(ring, z)
+        ring.vec_op(name, px, py, pz)
+        got = pz.numpy()
+        for i, q in enumerate(mods):
+            assert np.array_equal(got[0, i], oracle.vec_op(rh.OPS[name], x[0, i], y[0, i], z[0, i], 0, 0, q)), name
+    ring.close()
