@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py -- forward NTT throughput at the BASELINE metric size (N = 2^16, 16 RNS limbs) on N MI355X GPUs.
+
+A step = Ring.NTT (forward, canonical output: ring/ntt.go:127-131) over one device-resident batch of `--batch` polys
+of 16 limbs (Qi60[0:16], ring/test_params.go:15-22), in place.  value = polys transformed per second over all ranks
+(weak scaling: every rank owns its own batch; limbs and polys are independent so there is no data-path collective).
+
+One JSON line on stdout (rank 0).  `roofline` is measured live with HIP events on the launch stream over the timed
+region; `cpu_baseline` times the oracle's C restatement of nttUnrolled16Lazy+reducevec on the host cores (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+QI60 = [0x1fffffffffe00001, 0x1fffffffffc80001, 0x1fffffffffb40001, 0x1fffffffff500001,
+        0x1fffffffff380001, 0x1fffffffff000001, 0x1ffffffffef00001, 0x1ffffffffee80001,
+        0x1ffffffffeb40001, 0x1ffffffffe780001, 0x1ffffffffe600001, 0x1ffffffffe4c0001,
+        0x1ffffffffdf40001, 0x1ffffffffdac0001, 0x1ffffffffda40001, 0x1ffffffffc680001]
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="polys per GPU per step (1024 -> 8 GiB, >> 256 MiB Infinity Cache)")
+    ap.add_argument("--logn", type=int, default=16)
+    ap.add_argument("--limbs", type=int, default=16)
+    ap.add_argument("--chunk", type=int, default=-1, help="polys per (column,tile) kernel pair; -1 = engine default")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import matrix_fhe_lattigo_amd as rh
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    N, L, B = 1 << args.logn, args.limbs, args.batch
+    mods = QI60[:L]
+    ring = rh.Ring(N, mods, device=local_rank)
+    stream = torch.cuda.current_stream()
+    ring.set_stream(stream.cuda_stream)
+    if args.chunk >= 0:
+        ring.set_tuning("chunk_polys", args.chunk)
+
+    # synthetic input: i.i.d. residues in [0, q_i), seeded, generated on the device
+    g = torch.Generator(device=dev); g.manual_seed(0x5eed + rank)
+    data = torch.empty((B, L, N), dtype=torch.int64, device=dev)
+    qs = torch.tensor(mods, dtype=torch.int64, device=dev).view(1, L, 1)
+    for b0 in range(0, B, 64):
+        blk = torch.randint(0, 1 << 62, (min(64, B - b0), L, N), dtype=torch.int64, device=dev, generator=g)
+        data[b0:b0 + blk.shape[0]] = blk % qs
+    poly = rh.DevicePoly.from_torch(ring, data)
+
+    def step():
+        ring.NTT(poly, poly)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(args.steps):
+        step()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    dev_ms = e0.elapsed_time(e1)
+    if dist is not None:
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(t[0]), float(t[1])
+
+    # per-kernel device time (HIP events on the same stream), outside the timed region
+    kern = {}
+    if rank == 0 and args.logn > 12:
+        for name, phase in (("ntt_fwd_cols", 1), ("ntt_fwd_tile", 2)):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ring.ntt_phase(poly, poly, phase=phase)
+            torch.cuda.synchronize()
+            reps = max(3, min(args.steps, 10))
+            a.record(stream)
+            for _ in range(reps):
+                ring.ntt_phase(poly, poly, phase=phase)
+            b.record(stream)
+            torch.cuda.synchronize()
+            kern[name] = a.elapsed_time(b) / reps
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = wall * 1e3 / args.steps
+    value = world * B * args.steps / wall
+    alg_bytes = 16.0 * N * L * B                        # 16*N bytes per limb transform (8 in + 8 out)
+    launch_ms = dev_ms / args.steps                     # device time of one whole forward transform of the batch
+    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "forward-NTT/s at N=2^16, 16 RNS limbs; achieved HBM GB/s vs peak",
+        "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "Ring.NTT forward, N=2^%d, %d limbs (Qi60[0:%d]), batch %d polys/GPU, in place, device-resident" % (args.logn, L, L, B),
+                   "parallelism": "batch-shard x%d, no collective" % world, "limb_ntt_per_s": value * L},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "kernel": "ntt_fwd_cols+ntt_fwd_tile (one forward transform = both)",
+                     "algorithmic_bytes_per_step": alg_bytes, "device_ms_per_step": launch_ms, "kernel_ms": kern},
+    }
+    if world == 1 and not args.no_cpu:
+        import oracle
+        ncpu = os.cpu_count() or 1
+        t_probe = oracle.time_ntt_forward(N, mods, 1, 1)            # one 16-limb poly, one thread
+        reps = max(1, int(args.cpu_seconds / max(t_probe, 1e-6)))
+        t_cpu = oracle.time_ntt_forward(N, mods, reps, 1)
+        out["cpu_baseline"] = {"value": reps / t_cpu, "unit": "NTT/s", "cores": 1, "kind": "port",
+                               "sample": "%d forward NTTs of one 16-limb N=2^%d poly, single thread (the Go loop is single-threaded), "
+                                         "C restatement of nttUnrolled16Lazy+reducevec (oracle/ring_oracle.c), host has %d cores" % (reps, args.logn, ncpu)}
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -87,6 +87,11 @@ int rh_ntt_backward_lazy(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2)
 int rh_ring_ntt(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int lazy);
 int rh_ring_intt(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int lazy);
 
+/* profiling aid: phase 0 = whole transform, 1 = column kernel only, 2 = tile kernel only (N >= 8192) */
+int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int inverse, int phase);
+/* tuning knobs (performance only, never results): "chunk_polys" = polys per pipelined (column, tile) kernel span: -1 auto, 0 = whole batch */
+int rh_ring_set_tuning(rh_ring* r, const char* key, long value);
+
 /* ---- element-wise family (ring/vec_ops.go via ring/operations.go loops): p3 = op(p1, p2 [, p3]) on npoly polys of
  * (level+1) limbs.  s0/s1: per-limb scalar arrays of level+1 words on the HOST (NULL = unused), e.g. the RNSScalar of
  * MulRNSScalarMontgomery (ring/operations.go).  Asynchronous. */

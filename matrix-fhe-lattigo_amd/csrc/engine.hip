@@ -172,6 +172,10 @@ extern "C" void rh_ring_destroy(rh_ring* r) {
   (void)hipSetDevice(r->device);
   void* ptrs[] = {r->d_consts, r->d_tw_fwd, r->d_tw_inv, r->d_tw_fwd_mont, r->d_twk_fwd, r->d_twk_inv, r->d_twk_fwd_mont, r->d_lastw, r->d_scratch};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (r->aux_ready) {
+    for (int i = 0; i < 2; ++i) (void)hipStreamDestroy(r->aux[i]);
+    for (int i = 0; i < RH_NEVENTS; ++i) (void)hipEventDestroy(r->ev[i]);
+  }
   rh_ring3n_teardown(r);
   delete r;
 }
@@ -249,8 +253,9 @@ static void launch_inv_cols(int S1, dim3 grid, hipStream_t st, u64* data, const 
   }
 }
 
-// limb0: first limb of the table set to use (host-pointer single-limb path); rows = npoly * Lrows
-int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy) {
+// limb0: first limb of the table set to use (host-pointer single-limb path); rows = npoly * Lrows.
+// phase: 0 = whole transform, 1 = column kernel only, 2 = tile kernel only (profiling aid, rh_ring_ntt_phase).
+static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase) {
   const int logN = r->logN, N = r->N;
   const size_t toff = (size_t)limb0 * N;
   const LimbConsts* c = r->d_consts + limb0;
@@ -272,29 +277,94 @@ int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows,
     const u64* src = in;
     if (S1 > 0) {
       dim3 g1(rows * 16);
-      if (lazy) launch_fwd_cols<MontPolicy>(S1, g1, st, in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN);
-      else      launch_fwd_cols<ShoupPolicy>(S1, g1, st, in, out, r->d_tw_fwd + toff, c, Lrows, logN);
+      if (phase != 2) {
+        if (lazy) launch_fwd_cols<MontPolicy>(S1, g1, st, in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN);
+        else      launch_fwd_cols<ShoupPolicy>(S1, g1, st, in, out, r->d_tw_fwd + toff, c, Lrows, logN);
+      }
       src = out;
     }
-    if (lazy) ntt_fwd_tile<MontPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd_mont + toff, c, Lrows, logN, 0);
-    else      ntt_fwd_tile<ShoupPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, 1);
+    if (phase != 1) {
+      if (lazy) ntt_fwd_tile<MontPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd_mont + toff, c, Lrows, logN, 0);
+      else      ntt_fwd_tile<ShoupPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, 1);
+    }
   } else {
-    ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, S1 == 0 ? 1 : 0);
-    if (S1 > 0) launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, logN);
+    if (phase != 1) ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, S1 == 0 ? 1 : 0);
+    if (S1 > 0 && phase != 2) launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, logN);
   }
   return check_launch("ntt");
 }
 
-static int ntt_batch(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, bool inverse, bool lazy) {
+// Large batches are cut into spans of `chunk_polys` polys and software-pipelined over two internal streams: the
+// column kernel of span i+1 (HBM-bound) runs beside the tile kernel of span i (VALU-bound), and what the column
+// kernel wrote is still in the 256 MiB Infinity Cache when the tile kernel reads it back.  The caller's stream
+// ordering is preserved by a fork event at entry and a join at exit.
+static int ensure_aux(rh_ring* r) {
+  if (r->aux_ready) return RH_OK;
+  for (int i = 0; i < 2; ++i)
+    if (hipStreamCreateWithFlags(&r->aux[i], hipStreamNonBlocking) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "hipStreamCreate failed");
+  for (int i = 0; i < RH_NEVENTS; ++i)
+    if (hipEventCreateWithFlags(&r->ev[i], hipEventDisableTiming) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "hipEventCreate failed");
+  r->aux_ready = true;
+  return RH_OK;
+}
+
+int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase) {
+  int chunk = r->chunk_polys;
+  if (chunk < 0) {                                   // auto: ~64 MiB of coefficients per span
+    const size_t poly_bytes = (size_t)Lrows * r->N * 8;
+    chunk = (int)(((size_t)64 << 20) / poly_bytes);
+    if (chunk < 1) chunk = 1;
+  }
+  const bool two_pass = r->logN > LT;
+  if (chunk <= 0 || !two_pass || phase != 0 || npoly <= chunk) return std_ntt_launch_span(r, in, out, npoly, Lrows, limb0, inverse, lazy, phase);
+  if (int rc = ensure_aux(r)) return rc;
+  const size_t stride = (size_t)Lrows * r->N;
+  hipStream_t user = r->stream, sA = r->aux[0], sB = r->aux[1];
+  hipEvent_t fork = r->ev[0], joinA = r->ev[1], joinB = r->ev[2];
+  hipEvent_t* ring_ev = r->ev + 3;                   // RH_NEVENTS-3 rotating events for span hand-offs
+  const int nrot = RH_NEVENTS - 3;
+  if (hipEventRecord(fork, user) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "hipEventRecord failed");
+  (void)hipStreamWaitEvent(sA, fork, 0); (void)hipStreamWaitEvent(sB, fork, 0);
+  int rc = RH_OK, k = 0;
+  // first-pass kernel on sA, second-pass kernel on sB (forward: cols then tile; inverse: tile then cols)
+  const int first = inverse ? 2 : 1, second = inverse ? 1 : 2;
+  for (int p0 = 0; p0 < npoly && !rc; p0 += chunk, ++k) {
+    const int n = (npoly - p0 < chunk) ? (npoly - p0) : chunk;
+    const u64* src = in + p0 * stride; u64* dst = out + p0 * stride;
+    r->stream = sA;
+    rc = std_ntt_launch_span(r, src, dst, n, Lrows, limb0, inverse, lazy, first);
+    hipEvent_t e = ring_ev[k % nrot];
+    (void)hipEventRecord(e, sA);
+    (void)hipStreamWaitEvent(sB, e, 0);
+    r->stream = sB;
+    // the second pass always reads what the first wrote (dst)
+    if (!rc) rc = std_ntt_launch_span(r, dst, dst, n, Lrows, limb0, inverse, lazy, second);
+  }
+  r->stream = user;
+  (void)hipEventRecord(joinA, sA); (void)hipEventRecord(joinB, sB);
+  (void)hipStreamWaitEvent(user, joinA, 0); (void)hipStreamWaitEvent(user, joinB, 0);
+  return rc;
+}
+
+static int ntt_batch(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, bool inverse, bool lazy, int phase = 0) {
   if (!r || !in || !out) return rh_fail(RH_ERR_ARG, "ntt: null argument");
   if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "ntt: level %d out of range [0,%d)", level, r->L);
   if (npoly < 0) return rh_fail(RH_ERR_ARG, "ntt: npoly < 0");
   (void)hipSetDevice(r->device);
   if (r->kind == RH_RING_3N) return rh_ring3n_ntt_launch(r, in, out, npoly, level + 1, 0, inverse);
-  return rh_std_ntt_launch(r, in, out, npoly, level + 1, 0, inverse, lazy);
+  return rh_std_ntt_launch(r, in, out, npoly, level + 1, 0, inverse, lazy, phase);
 }
 extern "C" int rh_ring_ntt(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, int lazy) { return ntt_batch(r, in, out, npoly, level, false, lazy != 0); }
 extern "C" int rh_ring_intt(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, int lazy) { return ntt_batch(r, in, out, npoly, level, true, lazy != 0); }
+extern "C" int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, int inverse, int phase) {
+  if (phase < 0 || phase > 2) return rh_fail(RH_ERR_ARG, "phase must be 0, 1 or 2");
+  return ntt_batch(r, in, out, npoly, level, inverse != 0, false, phase);
+}
+extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
+  if (!r || !key) return rh_fail(RH_ERR_ARG, "set_tuning: null argument");
+  if (!strcmp(key, "chunk_polys")) { r->chunk_polys = (int)value; return RH_OK; }
+  return rh_fail(RH_ERR_ARG, "set_tuning: unknown key %s", key);
+}
 
 // one limb, host pointers: the NumberTheoreticTransformer interface
 static int ntt_host_limb(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2, bool inverse, bool lazy) {
@@ -306,7 +376,7 @@ static int ntt_host_limb(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2,
   hipError_t e = hipMemcpyAsync(r->d_scratch, p1, bytes, hipMemcpyHostToDevice, r->stream);
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "H2D: %s", hipGetErrorString(e));
   int rc = (r->kind == RH_RING_3N) ? rh_ring3n_ntt_launch(r, r->d_scratch, r->d_scratch, 1, 1, limb, inverse)
-                                   : rh_std_ntt_launch(r, r->d_scratch, r->d_scratch, 1, 1, limb, inverse, lazy);
+                                   : rh_std_ntt_launch(r, r->d_scratch, r->d_scratch, 1, 1, limb, inverse, lazy, 0);
   if (rc) return rc;
   e = hipMemcpyAsync(p2, r->d_scratch, bytes, hipMemcpyDeviceToHost, r->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(r->stream);

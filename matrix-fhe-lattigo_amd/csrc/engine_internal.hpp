@@ -7,6 +7,7 @@
 #include "ring_types.cuh"
 
 #define RH_MAX_LIMBS 64
+#define RH_NEVENTS 11
 
 int rh_fail(int code, const char* fmt, ...);
 
@@ -29,9 +30,13 @@ struct rh_ring {
   tw2* d_lastw = nullptr;         // psi_bwd[1] * N^-1 per limb
   u64* d_scratch = nullptr;       // 2N words for the host-pointer single-limb path
   rh_ring3n_state* s3n = nullptr;
+  hipStream_t aux[2] = {nullptr, nullptr};
+  hipEvent_t ev[RH_NEVENTS] = {};
+  bool aux_ready = false;
+  int chunk_polys = -1;           // -1 = auto (~64 MiB spans), 0 = whole batch per launch, >0 = polys per span
 };
 
-int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy);
+int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase = 0);
 int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3, int npoly, int Lrows, int limb0,
                   const u64* s0, const u64* s1);
 // 3N-cyclotomic transform (ntt3n.hip)

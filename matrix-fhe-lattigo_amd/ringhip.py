@@ -59,6 +59,8 @@ def lib():
         "rh_ntt_forward": (i, [vp, i, U64P, U64P]), "rh_ntt_forward_lazy": (i, [vp, i, U64P, U64P]),
         "rh_ntt_backward": (i, [vp, i, U64P, U64P]), "rh_ntt_backward_lazy": (i, [vp, i, U64P, U64P]),
         "rh_ring_ntt": (i, [vp, vp, vp, i, i, i]), "rh_ring_intt": (i, [vp, vp, vp, i, i, i]),
+        "rh_ring_ntt_phase": (i, [vp, vp, vp, i, i, i, i]),
+        "rh_ring_set_tuning": (i, [vp, C.c_char_p, C.c_long]),
         "rh_ring_vec_op": (i, [vp, i, vp, vp, vp, i, i, U64P, U64P]),
         "rh_bext_create": (i, [C.POINTER(vp), vp, vp]), "rh_bext_destroy": (None, [vp]),
         "rh_bext_modup_q_to_p": (i, [vp, i, i, vp, vp, i]), "rh_bext_modup_p_to_q": (i, [vp, i, i, vp, vp, i]),
@@ -217,6 +219,12 @@ class Ring:
 
     def set_stream(self, stream_ptr):
         _check(lib().rh_ring_set_stream(self._h, stream_ptr))
+
+    def set_tuning(self, key, value):
+        _check(lib().rh_ring_set_tuning(self._h, key.encode(), int(value)))
+
+    def ntt_phase(self, p1, p2, inverse=False, phase=0):
+        _check(lib().rh_ring_ntt_phase(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, int(inverse), int(phase)))
 
     def sync(self):
         _check(lib().rh_ring_sync(self._h))
