@@ -53,6 +53,33 @@ static int upload(T** dptr, const std::vector<T>& h) {
   return 0;
 }
 
+// uploads natural-order Shoup tables (+ optional Montgomery forward table) and, for N >= 4096, their kernel-order copies
+int rh_std_upload_tables(rh_ring* r, const std::vector<tw2>& fs, const std::vector<tw2>& is, const std::vector<u64>* mont,
+                         const std::vector<tw2>& lastw) {
+  const int L = r->L, N = r->N, logN = r->logN;
+  int rc = 0;
+  if (!rc) rc = upload(&r->d_tw_fwd, fs);
+  if (!rc) rc = upload(&r->d_tw_inv, is);
+  if (!rc && mont) rc = upload(&r->d_tw_fwd_mont, *mont);
+  if (!rc) rc = upload(&r->d_lastw, lastw);
+  if (!rc && logN >= LT) {
+    std::vector<tw2> kf((size_t)L * N), ki((size_t)L * N);
+    for (int i = 0; i < L; ++i) {
+      build_kernel_order(fs.data() + (size_t)i * N, kf.data() + (size_t)i * N, logN);
+      build_kernel_order(is.data() + (size_t)i * N, ki.data() + (size_t)i * N, logN);
+    }
+    if (!rc) rc = upload(&r->d_twk_fwd, kf);
+    if (!rc) rc = upload(&r->d_twk_inv, ki);
+    if (!rc && mont) {
+      std::vector<u64> km((size_t)L * N);
+      for (int i = 0; i < L; ++i) build_kernel_order(mont->data() + (size_t)i * N, km.data() + (size_t)i * N, logN);
+      rc = upload(&r->d_twk_fwd_mont, km);
+    }
+  }
+  return rc;
+}
+int rh_upload_consts(rh_ring* r, const std::vector<LimbConsts>& hc) { return upload(&r->d_consts, hc); }
+
 // ------------------------------------------------------------------------------------------------ ring construction
 static int validate_degree(int kind, int N) {
   if (kind == RH_RING_STANDARD) {
@@ -113,22 +140,7 @@ extern "C" int rh_ring_create(rh_ring** out, int device, int kind, int N, int L,
       u64 lw = rh::mulmod(is[(size_t)i * N + 1].w, c.ninv_w, q);
       lastw[i] = tw2{lw, rh::shoup_quotient(lw, q)};
     }
-    if (!rc) rc = upload(&r->d_tw_fwd, fs);
-    if (!rc) rc = upload(&r->d_tw_inv, is);
-    if (!rc) rc = upload(&r->d_tw_fwd_mont, r->roots_fwd);
-    if (!rc) rc = upload(&r->d_lastw, lastw);
-    if (!rc && logN >= LT) {
-      std::vector<tw2> kf((size_t)L * N), ki((size_t)L * N);
-      std::vector<u64> km((size_t)L * N);
-      for (int i = 0; i < L; ++i) {
-        build_kernel_order(fs.data() + (size_t)i * N, kf.data() + (size_t)i * N, logN);
-        build_kernel_order(is.data() + (size_t)i * N, ki.data() + (size_t)i * N, logN);
-        build_kernel_order(r->roots_fwd.data() + (size_t)i * N, km.data() + (size_t)i * N, logN);
-      }
-      if (!rc) rc = upload(&r->d_twk_fwd, kf);
-      if (!rc) rc = upload(&r->d_twk_inv, ki);
-      if (!rc) rc = upload(&r->d_twk_fwd_mont, km);
-    }
+    if (!rc) rc = rh_std_upload_tables(r, fs, is, &r->roots_fwd, lastw);
   } else {
     if (!omega3n) { delete r; return rh_fail(RH_ERR_ARG, "rh_ring_create: 3N ring needs omega3n"); }
     r->omega3n.assign(omega3n, omega3n + L);
@@ -243,13 +255,13 @@ static void launch_fwd_cols(int S1, dim3 grid, hipStream_t st, const u64* in, u6
   }
 }
 static void launch_inv_cols(int S1, dim3 grid, hipStream_t st, u64* data, const tw2* tw, const tw2* lastw,
-                            const LimbConsts* c, int L, int logN) {
+                            const LimbConsts* c, int L, int logN, int scale) {
   switch (S1) {
-    case 1: ntt_inv_cols<1><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN); break;
-    case 2: ntt_inv_cols<2><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN); break;
-    case 3: ntt_inv_cols<3><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN); break;
-    case 4: ntt_inv_cols<4><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN); break;
-    case 5: ntt_inv_cols<5><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN); break;
+    case 1: ntt_inv_cols<1><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN, scale); break;
+    case 2: ntt_inv_cols<2><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN, scale); break;
+    case 3: ntt_inv_cols<3><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN, scale); break;
+    case 4: ntt_inv_cols<4><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN, scale); break;
+    case 5: ntt_inv_cols<5><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN, scale); break;
   }
 }
 
@@ -267,7 +279,7 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
       if (lazy) ntt_fwd_small<MontPolicy><<<rows, 256, 0, st>>>(in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN, 0);
       else      ntt_fwd_small<ShoupPolicy><<<rows, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, logN, 1);
     } else {
-      ntt_inv_small<<<rows, 256, 0, st>>>(in, out, r->d_tw_inv + toff, c, Lrows, logN);
+      ntt_inv_small<<<rows, 256, 0, st>>>(in, out, r->d_tw_inv + toff, c, Lrows, logN, r->inv_scale ? 1 : 0);
     }
     return check_launch("ntt_small");
   }
@@ -288,8 +300,8 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
       else      ntt_fwd_tile<ShoupPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, 1);
     }
   } else {
-    if (phase != 1) ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, S1 == 0 ? 1 : 0);
-    if (S1 > 0 && phase != 2) launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, logN);
+    if (phase != 1) ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, (S1 == 0 && r->inv_scale) ? 1 : 0);
+    if (S1 > 0 && phase != 2) launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, logN, r->inv_scale ? 1 : 0);
   }
   return check_launch("ntt");
 }

@@ -33,12 +33,16 @@ struct rh_ring {
   hipStream_t aux[2] = {nullptr, nullptr};
   hipEvent_t ev[RH_NEVENTS] = {};
   bool aux_ready = false;
+  bool inv_scale = true;          // false: inverse leaves values < 4q without the N^-1 factor (3N sub-transform)
   int chunk_polys = -1;           // -1 = auto (~64 MiB spans), 0 = whole batch per launch, >0 = polys per span
 };
 
 int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase = 0);
 int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3, int npoly, int Lrows, int limb0,
                   const u64* s0, const u64* s1);
+int rh_std_upload_tables(rh_ring* r, const std::vector<tw2>& fs, const std::vector<tw2>& is, const std::vector<u64>* mont,
+                         const std::vector<tw2>& lastw);
+int rh_upload_consts(rh_ring* r, const std::vector<LimbConsts>& hc);
 // 3N-cyclotomic transform (ntt3n.hip)
 int rh_ring3n_setup(rh_ring* r, std::vector<LimbConsts>& hc);
 void rh_ring3n_teardown(rh_ring* r);

@@ -1,5 +1,320 @@
-// ntt3n.hip -- 3N-cyclotomic transform (placeholder until the kernels land in this round)
+// ntt3n.hip -- 3N-cyclotomic transform over Z_q[X]/(X^N - X^(N/2) + 1), N = 2^a 3^b (a,b >= 1).
+//
+// Replaces NumberTheoreticTransformer3N (ring/ntt_3n.go:21-156): Forward(p)[k] = p(omega^E[k]) with E the ascending
+// totatives of 3N (:82-109, :235-243); Backward = the exact inverse (:118-151).  The reference evaluates by Horner
+// (O(N^2)) and interpolates by Gaussian elimination (O(N^3)); both maps are unique, so an O(N log N) factorisation
+// that lands in [0,q) is bit-identical.  Factorisation (math of references/integer_dft.py:150-183, 266-432):
+//     X^N - X^(N/2) + 1 = (X^(N/2) - z)(X^(N/2) - z^5),   z = omega^(N/2)             "split" layer
+//     X^(3m) - w^e      = prod_{k<3} (X^m - w^(e/3 + kN))                              b radix-3 layers
+//     X^(2m) - w^e      = (X^m - w^(e/2))(X^m - w^(e/2 + 3N/2))                        a-1 radix-2 layers
+// After the split and radix-3 layers a limb is nb = 2*3^b independent twisted power-of-two transforms of length
+// n2 = 2^(a-1); they run on the SAME radix-2 kernels as the negacyclic NTT (ntt_kernels.cuh) by presenting each
+// (limb, block) as a "virtual limb" of a sub-ring with its own twiddle table.  Slot j of block c holds the value at
+// omega^e, e = e0_c + 2*3^(b+1)*bitrev(j); its rank among the totatives is nb*bitrev(j) + rank(e0_c), which is the
+// final permutation (ntt3n_perm_*).
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <cstring>
 #include "engine_internal.hpp"
-int rh_ring3n_setup(rh_ring*, std::vector<LimbConsts>&) { return rh_fail(RH_ERR_UNSUPPORTED, "3N ring not built yet"); }
-void rh_ring3n_teardown(rh_ring*) {}
-int rh_ring3n_ntt_launch(rh_ring*, const u64*, u64*, int, int, int, bool) { return rh_fail(RH_ERR_UNSUPPORTED, "3N ring not built yet"); }
+#include "hostmath.hpp"
+
+struct Limb3N {          // per-limb constants of the non-radix-2 layers (Shoup pairs, standard form)
+  tw2 zeta;              // omega^(N/2)
+  tw2 w3;                // omega^N (primitive cube root)
+  tw2 inv_b1;            // (z^5 - z)^-1 * (N/2)^-1
+  tw2 inv_b0z;           // z * (z^5 - z)^-1 * (N/2)^-1
+  tw2 inv_s;             // (N/2)^-1
+};
+
+struct rh_ring3n_state {
+  int a = 0, b = 0, nb = 0, n2 = 0, log_n2 = 0;
+  rh_ring* sub = nullptr;             // radix-2 part: L*nb virtual limbs of length n2
+  Limb3N* d_l3 = nullptr;             // [L]
+  tw2* d_r3_fwd = nullptr;            // radix-3 twiddles: per limb, per layer blocks: (z1, z2) pairs, forward
+  tw2* d_r3_inv = nullptr;            //                                             (z1^-1, z2^-1)
+  std::vector<int> r3_off;            // offset (in pairs of tw2) of layer l inside a limb's radix-3 table
+  int r3_stride = 0;                  // tw2 entries per limb
+  int* d_rank = nullptr;              // [nb] rank(e0_c)
+  int* d_block_of_rank = nullptr;     // [nb] inverse map
+  u64* d_tmp = nullptr; size_t tmp_words = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernels.  Rows are (poly, limb) pairs, grid.x = rows, grid.y = chunks over the butterflies of the layer.
+// All layer kernels keep values < 4q (inputs < 4q accepted).
+// ---------------------------------------------------------------------------------------------------------------
+RH_DEV u64 add4(u64 x, u64 y, u64 q4) { return csub(x + y, q4); }          // x,y < 4q -> < 4q
+RH_DEV u64 sub4(u64 x, u64 y, u64 q4) { return csub(x + q4 - y, q4); }     // x,y < 4q -> < 4q
+
+__global__ void __launch_bounds__(256)
+ntt3n_split_fwd(const u64* in, u64* out, int N, const Limb3N* __restrict__ l3, const LimbConsts* __restrict__ consts, int L) {
+  const u32 row = blockIdx.x, limb = row % (u32)L;
+  const LimbConsts c = consts[limb]; const Limb3N k = l3[limb];
+  const u64 q4 = 4 * c.q;
+  const size_t base = (size_t)row * N;
+  const int h = N >> 1;
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < h; i += gridDim.y * blockDim.x) {
+    u64 b0 = csub(in[base + i], q4), b1 = csub(in[base + i + h], q4);     // tolerate inputs < 8q
+    u64 t = shoup_mul(b1, k.zeta.w, k.zeta.wp, c.nq);
+    out[base + i] = add4(b0, t, q4);                                      // f mod (X^h - z)
+    out[base + i + h] = sub4(add4(b0, b1, q4), t, q4);                    // f mod (X^h - z^5), z^5 = 1 - z
+  }
+}
+
+// radix-3 layer: `cnt` blocks of 3*step; block blk uses (z1, z2) = tw[blk*2], tw[blk*2+1]
+__global__ void __launch_bounds__(256)
+ntt3n_radix3_fwd(u64* data, int N, int step, int cnt, const tw2* __restrict__ tw, int tw_stride,
+                 const Limb3N* __restrict__ l3, const LimbConsts* __restrict__ consts, int L) {
+  const u32 row = blockIdx.x, limb = row % (u32)L;
+  const LimbConsts c = consts[limb]; const tw2 w3 = l3[limb].w3;
+  const u64 q4 = 4 * c.q;
+  const size_t base = (size_t)row * N;
+  const tw2* t = tw + (size_t)limb * tw_stride;
+  const int nbf = cnt * step;
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < nbf; i += gridDim.y * blockDim.x) {
+    const int blk = i / step, e = i - blk * step;
+    const size_t j = base + (size_t)blk * 3 * step + e;
+    const tw2 z1 = t[2 * blk], z2 = t[2 * blk + 1];
+    u64 b0 = data[j], b1 = data[j + step], b2 = data[j + 2 * step];
+    u64 t1 = shoup_mul(b1, z1.w, z1.wp, c.nq), t2 = shoup_mul(b2, z2.w, z2.wp, c.nq);
+    u64 t3 = shoup_mul(t1 + q4 - t2, w3.w, w3.wp, c.nq);
+    data[j] = add4(add4(b0, t1, q4), t2, q4);
+    data[j + step] = add4(sub4(b0, t2, q4), t3, q4);
+    data[j + 2 * step] = sub4(sub4(b0, t1, q4), t3, q4);
+  }
+}
+// inverse radix-3 (un-normalised, factor 3): s0 = B0+B1+B2, t = w3*(B1-B2), b1 = (B0-B1-t)/z1, b2 = (B0-B2+t)/z2
+__global__ void __launch_bounds__(256)
+ntt3n_radix3_inv(u64* data, int N, int step, int cnt, const tw2* __restrict__ tw, int tw_stride,
+                 const Limb3N* __restrict__ l3, const LimbConsts* __restrict__ consts, int L) {
+  const u32 row = blockIdx.x, limb = row % (u32)L;
+  const LimbConsts c = consts[limb]; const tw2 w3 = l3[limb].w3;
+  const u64 q4 = 4 * c.q;
+  const size_t base = (size_t)row * N;
+  const tw2* t = tw + (size_t)limb * tw_stride;
+  const int nbf = cnt * step;
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < nbf; i += gridDim.y * blockDim.x) {
+    const int blk = i / step, e = i - blk * step;
+    const size_t j = base + (size_t)blk * 3 * step + e;
+    const tw2 z1 = t[2 * blk], z2 = t[2 * blk + 1];
+    u64 B0 = data[j], B1 = data[j + step], B2 = data[j + 2 * step];
+    u64 tt = shoup_mul(B1 + q4 - B2, w3.w, w3.wp, c.nq);
+    u64 s1 = sub4(sub4(B0, B1, q4), tt, q4), s2 = add4(sub4(B0, B2, q4), tt, q4);
+    data[j] = add4(add4(B0, B1, q4), B2, q4);
+    data[j + step] = shoup_mul(s1, z1.w, z1.wp, c.nq);
+    data[j + 2 * step] = shoup_mul(s2, z2.w, z2.wp, c.nq);
+  }
+}
+// inverse split + scaling by (N/2)^-1 + canonical reduction:
+//   lo = b0 + z b1, hi = b0 + z^5 b1  =>  b1 = (hi-lo)/(z^5-z), b0 = lo - z b1
+__global__ void __launch_bounds__(256)
+ntt3n_split_inv(const u64* in, u64* out, int N, const Limb3N* __restrict__ l3, const LimbConsts* __restrict__ consts, int L) {
+  const u32 row = blockIdx.x, limb = row % (u32)L;
+  const LimbConsts c = consts[limb]; const Limb3N k = l3[limb];
+  const u64 q4 = 4 * c.q;
+  const size_t base = (size_t)row * N;
+  const int h = N >> 1;
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < h; i += gridDim.y * blockDim.x) {
+    u64 lo = in[base + i], hi = in[base + i + h];
+    u64 d = hi + q4 - lo;
+    u64 b1 = shoup_mul(d, k.inv_b1.w, k.inv_b1.wp, c.nq);
+    u64 zb1 = shoup_mul(d, k.inv_b0z.w, k.inv_b0z.wp, c.nq);
+    u64 los = shoup_mul(lo, k.inv_s.w, k.inv_s.wp, c.nq);
+    out[base + i] = canon8(los + q4 - zb1, c.q);
+    out[base + i + h] = canon4(b1, c.q);
+  }
+}
+
+RH_DEV u32 brev(u32 x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+// forward permutation: out[nb*bitrev(j) + rank[c]] = in[c*n2 + j]; thread per OUTPUT element (contiguous writes)
+__global__ void __launch_bounds__(256)
+ntt3n_perm_fwd(const u64* in, u64* out, int N, int nb, int log_n2, const int* __restrict__ block_of_rank,
+               const LimbConsts* __restrict__ consts, int L, int canon) {
+  const size_t base = (size_t)blockIdx.x * N;
+  const u64 q = consts[blockIdx.x % (u32)L].q;
+  for (int o = blockIdx.y * blockDim.x + threadIdx.x; o < N; o += gridDim.y * blockDim.x) {
+    const int jb = o / nb, rk = o - jb * nb;
+    const int c = block_of_rank[rk];
+    u64 v = in[base + ((size_t)c << log_n2) + brev((u32)jb, log_n2)];
+    out[base + o] = canon ? canon4(v, q) : v;     // canon: only when there is no radix-2 part (a == 1), values < 4q
+  }
+}
+// inverse permutation: out[c*n2 + j] = in[nb*bitrev(j) + rank[c]]; thread per INPUT element (contiguous reads)
+__global__ void __launch_bounds__(256)
+ntt3n_perm_inv(const u64* in, u64* out, int N, int nb, int log_n2, const int* __restrict__ block_of_rank) {
+  const size_t base = (size_t)blockIdx.x * N;
+  for (int o = blockIdx.y * blockDim.x + threadIdx.x; o < N; o += gridDim.y * blockDim.x) {
+    const int jb = o / nb, rk = o - jb * nb;
+    const int c = block_of_rank[rk];
+    out[base + ((size_t)c << log_n2) + brev((u32)jb, log_n2)] = in[base + o];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host: twiddle tree and tables
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+static int up(T** d, const std::vector<T>& h) {
+  if (hipMalloc((void**)d, (h.size() ? h.size() : 1) * sizeof(T)) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc failed");
+  if (!h.empty() && hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "hipMemcpy failed");
+  return 0;
+}
+static tw2 pair_of(u64 w, u64 q) { return tw2{w, rh::shoup_quotient(w, q)}; }
+
+int rh_ring3n_setup(rh_ring* r, std::vector<LimbConsts>& hc) {
+  const int N = r->N, L = r->L;
+  rh_ring3n_state* s = new rh_ring3n_state();
+  r->s3n = s;
+  int m = N; while (m % 2 == 0) { m /= 2; s->a++; } while (m % 3 == 0) { m /= 3; s->b++; }
+  s->log_n2 = s->a - 1; s->n2 = 1 << s->log_n2;
+  s->nb = 2; for (int i = 0; i < s->b; ++i) s->nb *= 3;
+  const int a = s->a, b = s->b, nb = s->nb, n2 = s->n2;
+  const long long threeN = 3LL * N;
+
+  // block exponents after the split and the radix-3 layers (tree of references/integer_dft.py:157-175)
+  std::vector<std::vector<long long>> lvl(b + 2);
+  lvl[1] = {threeN / 6, 5 * threeN / 6};
+  s->r3_off.assign(b + 1, 0);
+  int off = 0;
+  for (int l = 1; l <= b; ++l) {
+    s->r3_off[l] = off; off += 2 * (int)lvl[l].size();
+    for (long long e : lvl[l]) { lvl[l + 1].push_back(e / 3); lvl[l + 1].push_back(e / 3 + N); lvl[l + 1].push_back(e / 3 + 2 * (long long)N); }
+  }
+  s->r3_stride = off;
+  const std::vector<long long>& E = lvl[b + 1];      // nb block exponents, each divisible by n2
+  std::vector<int> rank(nb), block_of_rank(nb);
+  for (int c = 0; c < nb; ++c) {
+    long long e0 = E[c] / n2;
+    rank[c] = (int)(2 * (e0 / 6) + ((e0 % 6) == 5 ? 1 : 0));
+    if (rank[c] < 0 || rank[c] >= nb) return rh_fail(RH_ERR_ARG, "3N setup: internal rank error");
+    block_of_rank[rank[c]] = c;
+  }
+
+  std::vector<Limb3N> l3(L);
+  std::vector<tw2> r3f((size_t)L * s->r3_stride), r3i((size_t)L * s->r3_stride);
+  // sub-ring tables: virtual limb v = limb*nb + c, natural order index m+i (m = 2^s) holds w^(E(s,i)/2)
+  const int Lv = L * nb;
+  std::vector<tw2> fs, is, lastw(Lv);
+  if (s->log_n2 >= 1) { fs.assign((size_t)Lv * n2, tw2{0, 0}); is.assign((size_t)Lv * n2, tw2{0, 0}); }
+  std::vector<LimbConsts> hcv(Lv);
+  std::vector<u64> pw((size_t)threeN);
+  for (int i = 0; i < L; ++i) {
+    const u64 q = r->moduli[i], om = r->omega3n[i] % q;
+    if ((q - 1) % (u64)threeN != 0) return rh_fail(RH_ERR_MODULUS, "failed to find primitive 3N-th root: (q-1) not divisible by 3N for modulus %llu", (unsigned long long)q);
+    if (rh::powmod(om, (u64)threeN, q) != 1 || rh::powmod(om, (u64)threeN / 2, q) == 1 || rh::powmod(om, (u64)threeN / 3, q) == 1)
+      return rh_fail(RH_ERR_MODULUS, "omega for modulus %llu is not a primitive 3N-th root", (unsigned long long)q);
+    pw[0] = 1; for (long long e = 1; e < threeN; ++e) pw[e] = rh::mulmod(pw[e - 1], om, q);
+    auto W = [&](long long e) { e %= threeN; if (e < 0) e += threeN; return pw[e]; };
+    const u64 z = W(N / 2), z5 = W(5LL * N / 2);
+    const u64 dinv = rh::invmod_prime((z5 + q - z) % q, q), sinv = rh::invmod_prime((u64)(N / 2) % q, q);
+    l3[i].zeta = pair_of(z, q); l3[i].w3 = pair_of(W(N), q);
+    l3[i].inv_b1 = pair_of(rh::mulmod(dinv, sinv, q), q);
+    l3[i].inv_b0z = pair_of(rh::mulmod(z, rh::mulmod(dinv, sinv, q), q), q);
+    l3[i].inv_s = pair_of(sinv, q);
+    hc[i].ninv_mont = rh::mform(rh::invmod_prime((u64)N % q, q), q);
+    for (int l = 1; l <= b; ++l)
+      for (size_t k = 0; k < lvl[l].size(); ++k) {
+        const long long e = lvl[l][k] / 3;
+        const size_t o = (size_t)i * s->r3_stride + s->r3_off[l] + 2 * k;
+        r3f[o] = pair_of(W(e), q); r3f[o + 1] = pair_of(W(2 * e), q);
+        r3i[o] = pair_of(W(-e), q); r3i[o + 1] = pair_of(W(-2 * e), q);
+      }
+    for (int c = 0; c < nb; ++c) {
+      const int v = i * nb + c;
+      hcv[v] = hc[i];
+      if (s->log_n2 < 1) continue;
+      tw2* tf = fs.data() + (size_t)v * n2; tw2* ti = is.data() + (size_t)v * n2;
+      std::vector<long long> cur{E[c]}, nxt;
+      tf[0] = pair_of(1 % q, q); ti[0] = tf[0];
+      for (int st = 0; st < s->log_n2; ++st) {
+        nxt.clear();
+        for (size_t k = 0; k < cur.size(); ++k) {
+          const long long e = cur[k] / 2;
+          tf[((size_t)1 << st) + k] = pair_of(W(e), q);
+          ti[((size_t)1 << st) + k] = pair_of(W(-e), q);
+          nxt.push_back(e); nxt.push_back(e + threeN / 2);
+        }
+        cur.swap(nxt);
+      }
+      lastw[v] = ti[1];
+    }
+  }
+  int rc = 0;
+  if (!rc) rc = up(&s->d_l3, l3);
+  if (!rc) rc = up(&s->d_r3_fwd, r3f);
+  if (!rc) rc = up(&s->d_r3_inv, r3i);
+  if (!rc) rc = up(&s->d_rank, rank);
+  if (!rc) rc = up(&s->d_block_of_rank, block_of_rank);
+  if (!rc && s->log_n2 >= 1) {
+    rh_ring* sub = new rh_ring();
+    s->sub = sub;
+    sub->device = r->device; sub->kind = RH_RING_STANDARD; sub->N = n2; sub->logN = s->log_n2; sub->L = Lv;
+    sub->inv_scale = false;
+    rc = rh_std_upload_tables(sub, fs, is, nullptr, lastw);
+    if (!rc) rc = rh_upload_consts(sub, hcv);
+  }
+  (void)a;
+  return rc;
+}
+
+void rh_ring3n_teardown(rh_ring* r) {
+  rh_ring3n_state* s = r->s3n;
+  if (!s) return;
+  void* ptrs[] = {s->d_l3, s->d_r3_fwd, s->d_r3_inv, s->d_rank, s->d_block_of_rank, s->d_tmp};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (s->sub) {
+    rh_ring* b = s->sub;
+    void* q[] = {b->d_consts, b->d_tw_fwd, b->d_tw_inv, b->d_twk_fwd, b->d_twk_inv, b->d_lastw};
+    for (void* p : q) if (p) (void)hipFree(p);
+    delete b;
+  }
+  delete s; r->s3n = nullptr;
+}
+
+static int ensure_tmp(rh_ring3n_state* s, size_t words) {
+  if (s->tmp_words >= words) return 0;
+  if (s->d_tmp) (void)hipFree(s->d_tmp);
+  s->d_tmp = nullptr; s->tmp_words = 0;
+  if (hipMalloc((void**)&s->d_tmp, words * 8) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc(3N scratch, %zu words) failed", words);
+  s->tmp_words = words;
+  return 0;
+}
+
+int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse) {
+  rh_ring3n_state* s = r->s3n;
+  const int N = r->N, nb = s->nb;
+  const unsigned rows = (unsigned)npoly * (unsigned)Lrows;
+  if (rows == 0) return RH_OK;
+  if (int rc = ensure_tmp(s, (size_t)rows * N)) return rc;
+  hipStream_t st = r->stream;
+  const LimbConsts* c = r->d_consts + limb0;
+  const Limb3N* l3 = s->d_l3 + limb0;
+  const tw2* r3f = s->d_r3_fwd + (size_t)limb0 * s->r3_stride;
+  const tw2* r3i = s->d_r3_inv + (size_t)limb0 * s->r3_stride;
+  auto chunks = [](int work) { int g = (work + 255) / 256; return g < 1 ? 1 : (g > 64 ? 64 : g); };
+  u64* tmp = s->d_tmp;
+  if (s->sub) s->sub->stream = st;
+  if (!inverse) {
+    ntt3n_split_fwd<<<dim3(rows, chunks(N / 2)), 256, 0, st>>>(in, tmp, N, l3, c, Lrows);
+    int step = N / 6, cnt = 2;
+    for (int l = 1; l <= s->b; ++l, cnt *= 3, step /= 3)
+      ntt3n_radix3_fwd<<<dim3(rows, chunks(cnt * step)), 256, 0, st>>>(tmp, N, step, cnt, r3f + s->r3_off[l], s->r3_stride, l3, c, Lrows);
+    if (s->sub) {
+      // (poly, limb, block) rows of length n2: limb-major virtual limb index = limb*nb + c
+      if (int rc = rh_std_ntt_launch(s->sub, tmp, tmp, npoly, Lrows * nb, limb0 * nb, false, false, 0)) return rc;
+    }
+    ntt3n_perm_fwd<<<dim3(rows, chunks(N)), 256, 0, st>>>(tmp, out, N, nb, s->log_n2, s->d_block_of_rank, c, Lrows, s->sub ? 0 : 1);
+  } else {
+    ntt3n_perm_inv<<<dim3(rows, chunks(N)), 256, 0, st>>>(in, tmp, N, nb, s->log_n2, s->d_block_of_rank);
+    if (s->sub) {
+      if (int rc = rh_std_ntt_launch(s->sub, tmp, tmp, npoly, Lrows * nb, limb0 * nb, true, false, 0)) return rc;
+    }
+    int cnt = nb / 3, step = s->n2;
+    for (int l = s->b; l >= 1; --l, cnt /= 3, step *= 3)
+      ntt3n_radix3_inv<<<dim3(rows, chunks(cnt * step)), 256, 0, st>>>(tmp, N, step, cnt, r3i + s->r3_off[l], s->r3_stride, l3, c, Lrows);
+    ntt3n_split_inv<<<dim3(rows, chunks(N / 2)), 256, 0, st>>>(tmp, out, N, l3, c, Lrows);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "3N transform launch failed: %s", hipGetErrorString(e));
+  return RH_OK;
+}

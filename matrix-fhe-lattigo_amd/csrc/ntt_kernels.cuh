@@ -248,7 +248,7 @@ ntt_fwd_cols(const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
 template <int S1>
 __global__ void __launch_bounds__(256)
 ntt_inv_cols(u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
-             const LimbConsts* __restrict__ consts, int L, int logN) {
+             const LimbConsts* __restrict__ consts, int L, int logN, int scale) {
   constexpr int R = 1 << S1;
   const u32 b = blockIdx.x;
   const u32 limb = b % (u32)L;
@@ -272,7 +272,7 @@ ntt_inv_cols(u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ las
       for (int e = 0; e < hh; ++e) p.inv(x[g * 2 * hh + e], x[g * 2 * hh + e + hh], w);
     }
   }
-  {
+  if (scale) {
     const tw2 wl = lastw[limb];
     constexpr int hh = R >> 1;
 #pragma unroll
@@ -282,6 +282,11 @@ ntt_inv_cols(u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ las
       x[e] = canon4(shoup_mul(U + V, c.ninv_w, c.ninv_wp, c.nq), c.q);
       x[e + hh] = canon4(shoup_mul(d, wl.w, wl.wp, c.nq), c.q);
     }
+  } else {       // plain last stage (h = 1), values stay < 4q (used by the 3N transform, which scales later)
+    const tw2 w1 = tw[1];
+    constexpr int hh = R >> 1;
+#pragma unroll
+    for (int e = 0; e < hh; ++e) p.inv(x[e], x[e + hh], w1);
   }
 #pragma unroll
   for (int k = 0; k < R; ++k) data[base + ((size_t)k << LT)] = x[k];
@@ -321,7 +326,7 @@ ntt_fwd_small(const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
 
 __global__ void __launch_bounds__(256)
 ntt_inv_small(const u64* in, u64* out, const tw2* __restrict__ twn,
-              const LimbConsts* __restrict__ consts, int L, int logN) {
+              const LimbConsts* __restrict__ consts, int L, int logN, int scale) {
   __shared__ u64 lds[TILE];
   const int N = 1 << logN;
   const u32 limb = blockIdx.x % (u32)L;
@@ -343,5 +348,5 @@ ntt_inv_small(const u64* in, u64* out, const tw2* __restrict__ twn,
     __syncthreads();
   }
   for (int j = threadIdx.x; j < N; j += blockDim.x)
-    out[base + j] = canon4(shoup_mul(lds[j], c.ninv_w, c.ninv_wp, c.nq), c.q);
+    out[base + j] = scale ? canon4(shoup_mul(lds[j], c.ninv_w, c.ninv_wp, c.nq), c.q) : lds[j];
 }

@@ -1,0 +1,119 @@
+"""GPU: 3N-cyclotomic transform parity through the C ABI (NumberTheoreticTransformer3N semantics, ring/ntt_3n.go)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from test_oracle_ntt3n import VEC, find_prime_3n, omega_for, naive_mul_3n, rank
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("vec", VEC, ids=lambda v: "N=%d" % v["N"])
+def test_reference_python_vectors(rh, vec):
+    # omega handed over explicitly (the Go transformer draws it at random: SURVEY F4), 17-bit primes of the notes
+    N, p, w = vec["N"], vec["p"], vec["w"]
+    ring = rh.Ring(N, [p], kind=rh.Matrix3N, omega3n=[w])
+    exp = np.zeros(N, dtype=np.uint64)
+    for s, e in enumerate(vec["tree_last"]):
+        exp[rank(e)] = vec["dft_tree_order"][s]
+    y = ring.SubRings[0].NTT(vec["input"])
+    assert np.array_equal(y, exp)
+    assert np.array_equal(ring.SubRings[0].NTTLazy(vec["input"]), exp)          # ForwardLazy = Forward (ntt_3n.go:112-114)
+    assert np.array_equal(ring.SubRings[0].INTT(y), np.array(vec["input"], dtype=np.uint64))
+    assert np.array_equal(ring.SubRings[0].INTTLazy(y), np.array(vec["input"], dtype=np.uint64))
+    ring.close()
+
+
+@pytest.mark.parametrize("N", [6, 12, 18, 24, 36, 48, 54, 96, 192, 768, 3 * 1024, 3 * 4096, 3 * 8192, 9 * 4096])
+def test_forward_backward_vs_oracle_60bit(rh, oracle, N):
+    mods = []
+    q = find_prime_3n(N, 60)
+    mods.append(q)
+    q2 = q + 3 * N
+    while not oracle.lib().orc_is_prime(q2):
+        q2 += 3 * N
+    mods.append(q2)
+    oms = [omega_for(m, N) for m in mods]
+    ring = rh.Ring(N, mods, kind=rh.Matrix3N)          # engine derives omega = g^((q-1)/3N) like Find3NPrimitiveRoot
+    assert [int(v) for v in ring.constants()["omega3n"]] == oms
+    rng = np.random.default_rng(N)
+    npoly = 2
+    a = np.stack([np.stack([rng.integers(0, 1 << 62, size=N, dtype=np.uint64) % np.uint64(m) for m in mods]) for _ in range(npoly)])
+    a[0, :, 0] = 0
+    a[0, :, 1] = np.array(mods, dtype=np.uint64) - np.uint64(1)
+    p = rh.DevicePoly.from_numpy(ring, a)
+    o = ring.NewPoly(npoly)
+    ring.NTT(p, o)
+    got = o.numpy()
+    exp = np.stack([np.stack([oracle.ntt3n_forward(a[k, i], mods[i], oms[i]) for i in range(2)]) for k in range(npoly)])
+    assert np.array_equal(got, exp)
+    if N <= 768:
+        assert np.array_equal(got[1, 0], oracle.ntt3n_forward(a[1, 0], mods[0], oms[0], fast=False))     # Horner definition
+    else:
+        E = oracle.ntt3n_exponents(3 * N)
+        for k in (0, 1, N // 3, N - 1):
+            x = pow(oms[1], E[k], mods[1]); acc = 0
+            for cft in reversed(a[1, 1].tolist()):
+                acc = (acc * x + int(cft)) % mods[1]
+            assert int(got[1, 1, k]) == acc
+    ring.INTT(o, o)                                      # in place
+    assert np.array_equal(o.numpy(), a)
+    ring.close()
+
+
+def test_config2_size_multiplication(rh, oracle):
+    # BASELINE config 2: N = 3*2^13, one 60-bit modulus.  Sparse product checked against the reduction rule
+    # X^N = X^(N/2) - 1 (ring/ntt_3n_test.go:103-107), dense round trip.
+    N = 3 * 8192
+    q = find_prime_3n(N, 60)
+    ring = rh.Ring(N, [q], kind=rh.Matrix3N)
+    x = np.zeros((1, 1, N), dtype=np.uint64); y = np.zeros((1, 1, N), dtype=np.uint64)
+    x[0, 0, N - 2] = 3; x[0, 0, 5] = 7
+    y[0, 0, N // 2 + 4] = 11
+    px, py = rh.DevicePoly.from_numpy(ring, x), rh.DevicePoly.from_numpy(ring, y)
+    ring.NTT(px, px); ring.NTT(py, py)
+    ring.MulCoeffsBarrett(px, py, px)
+    ring.INTT(px, px)
+    # 3*11*X^(3N/2+2) + 7*11*X^(N/2+9);  X^(3N/2+2) = X^(N/2+2) * X^N = X^(N/2+2)(X^(N/2) - 1) = X^(N+2) - X^(N/2+2)
+    #   = X^2 (X^(N/2) - 1) - X^(N/2+2) = -X^2   (since X^(N/2+2) cancels)
+    exp = np.zeros(N, dtype=np.uint64)
+    exp[2] = (q - 33) % q
+    exp[N // 2 + 9] = 77
+    assert np.array_equal(px.numpy()[0, 0], exp)
+    ring.close()
+
+
+def test_config4_size_properties(rh, oracle):
+    # config 4 ring: N = 3*2^16, 3 limbs here (24 in the config), batch 2: round trip + linearity + one limb vs oracle
+    N = 3 << 16
+    mods = []
+    q = find_prime_3n(N, 60)
+    for _ in range(3):
+        mods.append(q)
+        q += 3 * N
+        while not oracle.lib().orc_is_prime(q):
+            q += 3 * N
+    ring = rh.Ring(N, mods, kind=rh.Matrix3N)
+    rng = np.random.default_rng(4)
+    a = np.stack([np.stack([rng.integers(0, 1 << 62, size=N, dtype=np.uint64) % np.uint64(m) for m in mods]) for _ in range(2)])
+    b = np.stack([np.stack([rng.integers(0, 1 << 62, size=N, dtype=np.uint64) % np.uint64(m) for m in mods]) for _ in range(2)])
+    pa, pb = rh.DevicePoly.from_numpy(ring, a), rh.DevicePoly.from_numpy(ring, b)
+    na, nb_, ns = ring.NewPoly(2), ring.NewPoly(2), ring.NewPoly(2)
+    ring.NTT(pa, na); ring.NTT(pb, nb_)
+    ring.Add(pa, pb, ns); ring.NTT(ns, ns)
+    ring.Add(na, nb_, nb_)
+    assert np.array_equal(ns.numpy(), nb_.numpy())
+    om = omega_for(mods[1], N)
+    assert np.array_equal(na.numpy()[1, 1], oracle.ntt3n_forward(a[1, 1], mods[1], om))
+    ring.INTT(na, na)
+    assert np.array_equal(na.numpy(), a)
+    ring.close()
+
+
+def test_3n_errors(rh):
+    with pytest.raises(rh.RingHipError):       # modulus without a primitive 3N-th root -> the Go ctor panics (ntt_3n.go:41)
+        rh.Ring(24, [0x1fffffffffe00001 - 0], kind=rh.Matrix3N) if (0x1fffffffffe00001 - 1) % 72 else (_ for _ in ()).throw(rh.RingHipError("skip"))
+    with pytest.raises(rh.RingHipError):
+        rh.Ring(20, [65537], kind=rh.Matrix3N)   # N not of the form 2^a 3^b
