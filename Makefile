@@ -11,7 +11,7 @@ all: $(LIB) oracle
 
 $(LIB): $(SRCS) $(HDRS)
 	@mkdir -p $(PKG)/lib
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Iinclude $(SRCS) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Iinclude $(SRCS) -o $@
 
 oracle: oracle/libring_oracle.so
 oracle/libring_oracle.so: oracle/ring_oracle.c oracle/ring_oracle.h include/ringhip_ops.h

@@ -1,10 +1,356 @@
-// bext.hip -- RNS basis extension (placeholder until the kernels land in this round)
+// bext.hip -- RNS basis extension on device-resident (poly, limb, coefficient) blocks.
+//
+// Replaces ring/basis_extension.go: GenModUpConstants (:93-164), genmodDownConstants (:25-49), ModUpQtoP/ModUpPtoQ
+// (:188-217), ModDownQPtoQ (:223-234), ModDownQPtoQNTT (:241-258), ModDownQPtoP (:264-278), ModUpExact with
+// reconstructRNS + multSum (:282-308, :550-673) and Decomposer.DecomposeAndSplit (:381-548).
+//
+// One kernel (bext_kernel) does the work of reconstructRNS(+Centered) and multSum: one thread per coefficient,
+//   y_i = MRed(x_i [+ half_i], (Q/q_i)^-1),  v = trunc(sum_i double(y_i)/double(q_i))   (sequential IEEE adds),
+//   out_j = (sum_i y_i * (Q/q_i mod p_j)) reduced once (lazy Montgomery) + vtimesqmodp[j][v]       -- NOT canonical,
+// then the caller's post step (centred subtraction, ModDown's fused subtract-multiply).  The non-canonical values are
+// reproduced exactly, so results are bit-identical to the reference even before its later Reduce.
+// The y_i live in LDS ([limb][thread], conflict-free) because the source limb count is a run-time value.
+// Traffic: 8*(nsrc + ntgt) bytes per coefficient; nsrc*ntgt 64x64->128 multiply-accumulates per coefficient.
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <map>
+#include <array>
+#include <cstring>
 #include "engine_internal.hpp"
-extern "C" int rh_bext_create(rh_bext**, rh_ring*, rh_ring*) { return rh_fail(RH_ERR_UNSUPPORTED, "basis extension not built yet"); }
-extern "C" void rh_bext_destroy(rh_bext*) {}
-extern "C" int rh_bext_modup_q_to_p(rh_bext*, int, int, const uint64_t*, uint64_t*, int) { return rh_fail(RH_ERR_UNSUPPORTED, "nyi"); }
-extern "C" int rh_bext_modup_p_to_q(rh_bext*, int, int, const uint64_t*, uint64_t*, int) { return rh_fail(RH_ERR_UNSUPPORTED, "nyi"); }
-extern "C" int rh_bext_moddown_qp_to_q(rh_bext*, int, int, const uint64_t*, const uint64_t*, uint64_t*, int) { return rh_fail(RH_ERR_UNSUPPORTED, "nyi"); }
-extern "C" int rh_bext_moddown_qp_to_q_ntt(rh_bext*, int, int, const uint64_t*, const uint64_t*, uint64_t*, int) { return rh_fail(RH_ERR_UNSUPPORTED, "nyi"); }
-extern "C" int rh_bext_moddown_qp_to_p(rh_bext*, int, int, const uint64_t*, const uint64_t*, uint64_t*, int) { return rh_fail(RH_ERR_UNSUPPORTED, "nyi"); }
-extern "C" int rh_bext_decompose_and_split(rh_bext*, int, int, int, int, const uint64_t*, uint64_t*, uint64_t*, int) { return rh_fail(RH_ERR_UNSUPPORTED, "nyi"); }
+#include "hostmath.hpp"
+
+struct BextSource { u64 q, qinv, qstar_inv /* ((Q/q_i)^-1) Montgomery form */, half /* floor(Q/2) mod q_i */; };
+struct BextTarget {
+  u64 p, pinv;
+  u64 half;        // floor(Q/2) mod p (centred subtraction), used when post >= 1
+  u64 md_scalar;   // ModDown: p - (P^-1 mod p) in Montgomery form, used when post == 2
+  int buf;         // 0 / 1: which output block
+  int limb;        // limb row inside that block
+  int post;        // 0 none, 1 CRed(x + p - half), 2 = 1 then MRed(2p - other + x, md_scalar)
+  int skip;        // 1: no extension for this limb (digit limbs of DecomposeAndSplit); post 1 applies to prior content
+};
+
+enum { BEXT_ADD_NONE = 0, BEXT_ADD_CRED = 1, BEXT_ADD_RAW = 2 };
+
+__global__ void __launch_bounds__(256)
+bext_kernel(const u64* in, int in_rows, int src_limb0, int nsrc, const BextSource* __restrict__ S,
+            int ntgt, const BextTarget* __restrict__ T, const u64* __restrict__ coef, const u64* __restrict__ vt,
+            u64* out0, int out0_rows, u64* out1, int out1_rows, const u64* other, int other_rows, int N, int add_mode) {
+  extern __shared__ u64 ylds[];                     // [nsrc][256]
+  const int tid = threadIdx.x;
+  const int k = blockIdx.x * 256 + tid;
+  const int poly = blockIdx.y;
+  const bool live = k < N;
+  double vi = 0.0;
+  for (int i = 0; i < nsrc; ++i) {
+    const BextSource s = S[i];
+    u64 x = live ? in[((size_t)poly * in_rows + src_limb0 + i) * N + k] : 0;
+    if (add_mode == BEXT_ADD_CRED) x = cred(x + s.half, s.q);            // AddScalarBigint -> addscalarvec
+    else if (add_mode == BEXT_ADD_RAW) x = x + s.half;                    // reconstructRNSCentered :522
+    const u64 y = mred(x, s.qstar_inv, s.q, s.qinv);
+    ylds[i * 256 + tid] = y;
+    vi += (double)y / (double)s.q;                                        // :576-593, one rounding per op
+  }
+  const u64 v = (u64)vi;
+  for (int j = 0; j < ntgt; ++j) {
+    const BextTarget t = T[j];
+    u64* outp = t.buf ? out1 : out0;
+    const int rows = t.buf ? out1_rows : out0_rows;
+    const size_t o = ((size_t)poly * rows + t.limb) * N + k;
+    u64 r;
+    if (t.skip) {
+      if (t.post == 0 || !live) continue;
+      r = outp[o];
+    } else {
+      const u64* cj = coef + (size_t)j * nsrc;
+      u128 acc = (u128)ylds[tid] * cj[0];
+      u64 rlo = (u64)acc, rhi = (u64)(acc >> 64);
+      for (int i = 1; i < nsrc; ++i) {                                    // multSum :612-649
+        const u128 m = (u128)ylds[i * 256 + tid] * cj[i];
+        const u64 mlo = (u64)m, mhi = (u64)(m >> 64);
+        const u64 s = rlo + mlo;
+        rhi += mhi + (u64)(s < rlo);
+        rlo = s;
+      }
+      const u64 hhi = mulhi64(rlo * t.pinv, t.p);
+      r = rhi - hhi + t.p + vt[(size_t)j * (nsrc + 1) + v];               // :651-672
+    }
+    if (t.post >= 1) r = cred(r + t.p - t.half, t.p);                     // SubScalarBigint -> subscalarvec
+    if (t.post == 2) {
+      const u64 y = live ? other[((size_t)poly * other_rows + t.limb) * N + k] : 0;
+      r = mred(2 * t.p - y + r, t.md_scalar, t.p, t.pinv);                // SubThenMulScalarMontgomeryTwoModulus
+    }
+    if (live) outp[o] = r;
+  }
+}
+
+// DecomposeAndSplit, single-prime digit (decompLvl < 0): sign-aware copy/reduce into every limb (:402-436)
+struct SignTarget { u64 p, bred0; int buf, limb; };
+__global__ void __launch_bounds__(256)
+bext_sign_copy_kernel(const u64* in, int in_rows, int src_limb, u64 qd, int ntgt, const SignTarget* __restrict__ T,
+                      u64* out0, int out0_rows, u64* out1, int out1_rows, int N) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int poly = blockIdx.y;
+  if (k >= N) return;
+  u64 coeff = in[((size_t)poly * in_rows + src_limb) * N + k];
+  u64 pos = 1, neg = 0;
+  if (coeff >= (qd >> 1)) { coeff = qd - coeff; pos = 0; neg = 1; }
+  for (int j = 0; j < ntgt; ++j) {
+    const SignTarget t = T[j];
+    const u64 tmp = bred_add(coeff, t.p, t.bred0);
+    u64* outp = t.buf ? out1 : out0;
+    const int rows = t.buf ? out1_rows : out0_rows;
+    outp[((size_t)poly * rows + t.limb) * N + k] = tmp * pos + (t.p - tmp) * neg;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+struct BextPlan {
+  int nsrc = 0, ntgt = 0;
+  BextSource* d_S = nullptr; BextTarget* d_T = nullptr; u64* d_coef = nullptr; u64* d_vt = nullptr;
+  SignTarget* d_sign = nullptr; u64 qd = 0;      // single-prime digit plan
+};
+
+struct rh_bext {
+  rh_ring* Q = nullptr; rh_ring* P = nullptr;
+  std::map<std::array<int, 5>, BextPlan> plans;
+  u64* buf[2] = {nullptr, nullptr}; size_t buf_words[2] = {0, 0};
+};
+
+template <class T>
+static int upv(T** d, const std::vector<T>& h) {
+  if (hipMalloc((void**)d, (h.size() ? h.size() : 1) * sizeof(T)) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc failed");
+  if (!h.empty() && hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "hipMemcpy failed");
+  return 0;
+}
+
+// floor(prod(M)/2) mod m, exact, by carrying the product as (value mod 2m): floor(X/2) mod m = ((X mod 2m) - (X & 1)) / 2
+static u64 half_product_mod(const std::vector<u64>& M, u64 m) {
+  const rh::u128 mm = (rh::u128)2 * m;             // < 2^62
+  rh::u128 acc = 1;
+  for (u64 f : M) acc = (acc * ((rh::u128)f % mm)) % mm;      // both factors < 2^62
+  return (u64)((acc - 1) / 2);                     // every modulus is odd, so the product (and acc) is odd
+}
+
+// GenModUpConstants (:93-164) for source basis Qs and a list of target moduli
+static void gen_modup(const std::vector<u64>& Qs, const std::vector<u64>& tg, std::vector<u64>& qstar_inv_mont,
+                      std::vector<u64>& coef, std::vector<u64>& vt) {
+  const int n = (int)Qs.size(), m = (int)tg.size();
+  qstar_inv_mont.resize(n); coef.assign((size_t)m * n, 0); vt.assign((size_t)m * (n + 1), 0);
+  for (int i = 0; i < n; ++i) {
+    const u64 qi = Qs[i];
+    u64 star = 1 % qi;
+    for (int j = 0; j < n; ++j) if (j != i) star = rh::mulmod(star, Qs[j] % qi, qi);
+    qstar_inv_mont[i] = rh::mform(rh::invmod_prime(star, qi), qi);
+    for (int j = 0; j < m; ++j) {
+      const u64 p = tg[j];
+      u64 s = 1 % p;
+      for (int u = 0; u < n; ++u) if (u != i) s = rh::mulmod(s, Qs[u] % p, p);
+      coef[(size_t)j * n + i] = rh::mform(s, p);
+    }
+  }
+  for (int j = 0; j < m; ++j) {
+    const u64 p = tg[j];
+    u64 QmodP = 1 % p;
+    for (int i = 0; i < n; ++i) QmodP = rh::mulmod(QmodP, Qs[i] % p, p);
+    const u64 v = p - QmodP;
+    u64* row = &vt[(size_t)j * (n + 1)];
+    row[0] = 0;
+    for (int i = 1; i <= n; ++i) { u64 t = row[i - 1] + v; row[i] = t >= p ? t - p : t; }
+  }
+}
+// genmodDownConstants (:25-49): prod_{j<=levelP} p_j^-1 mod q_i, Montgomery form
+static u64 moddown_const(const std::vector<u64>& Ps, u64 qi) {
+  u64 acc = 1 % qi;
+  for (u64 p : Ps) acc = rh::mulmod(acc, rh::invmod_prime(p % qi, qi), qi);
+  return rh::mform(acc, qi);
+}
+
+extern "C" int rh_bext_create(rh_bext** out, rh_ring* ringQ, rh_ring* ringP) {
+  if (!out || !ringQ) return rh_fail(RH_ERR_ARG, "rh_bext_create: null argument");
+  if (ringP && (ringP->N != ringQ->N || ringP->device != ringQ->device)) return rh_fail(RH_ERR_ARG, "rh_bext_create: rings differ in N or device");
+  rh_bext* be = new rh_bext();
+  be->Q = ringQ; be->P = ringP;
+  *out = be;
+  return RH_OK;
+}
+extern "C" void rh_bext_destroy(rh_bext* be) {
+  if (!be) return;
+  for (auto& kv : be->plans) {
+    BextPlan& p = kv.second;
+    void* ptrs[] = {p.d_S, p.d_T, p.d_coef, p.d_vt, p.d_sign};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+  }
+  for (int i = 0; i < 2; ++i) if (be->buf[i]) (void)hipFree(be->buf[i]);
+  delete be;
+}
+
+static int ensure_buf(rh_bext* be, int which, size_t words) {
+  if (be->buf_words[which] >= words) return 0;
+  if (be->buf[which]) (void)hipFree(be->buf[which]);
+  be->buf[which] = nullptr; be->buf_words[which] = 0;
+  if (hipMalloc((void**)&be->buf[which], words * 8) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc(basis-extension scratch) failed");
+  be->buf_words[which] = words;
+  return 0;
+}
+
+// plan kinds: 0 = ModUp src->tgt centred (post 1); 1 = same + fused ModDown (post 2); key = {kind, dir, lvlSrc, lvlTgt, 0}
+//   dir 0: Q -> P, dir 1: P -> Q
+static int get_modup_plan(rh_bext* be, int kind, int dir, int lvlS, int lvlT, BextPlan** out) {
+  std::array<int, 5> key{kind, dir, lvlS, lvlT, 0};
+  auto it = be->plans.find(key);
+  if (it != be->plans.end()) { *out = &it->second; return 0; }
+  rh_ring* RS = dir == 0 ? be->Q : be->P;
+  rh_ring* RT = dir == 0 ? be->P : be->Q;
+  std::vector<u64> Qs(RS->moduli.begin(), RS->moduli.begin() + lvlS + 1), tg(RT->moduli.begin(), RT->moduli.begin() + lvlT + 1);
+  std::vector<u64> qsi, coef, vt;
+  gen_modup(Qs, tg, qsi, coef, vt);
+  std::vector<BextSource> S(Qs.size()); std::vector<BextTarget> T(tg.size());
+  for (size_t i = 0; i < Qs.size(); ++i) S[i] = BextSource{Qs[i], RS->mred[i], qsi[i], half_product_mod(Qs, Qs[i])};
+  for (size_t j = 0; j < tg.size(); ++j) {
+    BextTarget t{};
+    t.p = tg[j]; t.pinv = RT->mred[j]; t.half = half_product_mod(Qs, tg[j]);
+    t.md_scalar = kind == 1 ? tg[j] - moddown_const(Qs, tg[j]) : 0;      // s.Modulus - modDownConstants[i]
+    t.buf = 0; t.limb = (int)j; t.post = kind == 1 ? 2 : 1; t.skip = 0;
+    T[j] = t;
+  }
+  BextPlan p; p.nsrc = (int)Qs.size(); p.ntgt = (int)tg.size();
+  int rc = upv(&p.d_S, S); if (!rc) rc = upv(&p.d_T, T); if (!rc) rc = upv(&p.d_coef, coef); if (!rc) rc = upv(&p.d_vt, vt);
+  if (rc) return rc;
+  auto ins = be->plans.emplace(key, p);
+  *out = &ins.first->second;
+  return 0;
+}
+
+static int launch_plan(rh_bext* be, const BextPlan& p, const u64* in, int in_rows, int src_limb0, u64* out0, int out0_rows,
+                       u64* out1, int out1_rows, const u64* other, int other_rows, int npoly, int add_mode) {
+  rh_ring* R = be->Q;
+  const int N = R->N;
+  if (npoly <= 0) return RH_OK;
+  dim3 grid((N + 255) / 256, npoly);
+  const size_t lds = (size_t)p.nsrc * 256 * 8;
+  (void)hipGetLastError();
+  bext_kernel<<<grid, 256, lds, R->stream>>>(in, in_rows, src_limb0, p.nsrc, p.d_S, p.ntgt, p.d_T, p.d_coef, p.d_vt,
+                                             out0, out0_rows, out1, out1_rows, other, other_rows, N, add_mode);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "bext_kernel launch failed: %s", hipGetErrorString(e));
+  return RH_OK;
+}
+
+static int check_levels(rh_bext* be, int levelQ, int levelP, bool needP) {
+  if (!be) return rh_fail(RH_ERR_ARG, "null basis extender");
+  if (levelQ < 0 || levelQ >= be->Q->L) return rh_fail(RH_ERR_ARG, "levelQ %d out of range [0,%d)", levelQ, be->Q->L);
+  if (needP) {
+    if (!be->P) return rh_fail(RH_ERR_ARG, "basis extender has no P ring");
+    if (levelP < 0 || levelP >= be->P->L) return rh_fail(RH_ERR_ARG, "levelP %d out of range [0,%d)", levelP, be->P->L);
+  }
+  if (levelQ + 1 > 32 || (needP && levelP + 1 > 32)) return rh_fail(RH_ERR_ARG, "basis extension supports at most 32 source limbs (ring/basis_extension.go:285)");
+  (void)hipSetDevice(be->Q->device);
+  if (be->P) be->P->stream = be->Q->stream;
+  return 0;
+}
+
+extern "C" int rh_bext_modup_q_to_p(rh_bext* be, int levelQ, int levelP, const uint64_t* polQ, uint64_t* polP, int npoly) {
+  if (int rc = check_levels(be, levelQ, levelP, true)) return rc;
+  BextPlan* p; if (int rc = get_modup_plan(be, 0, 0, levelQ, levelP, &p)) return rc;
+  return launch_plan(be, *p, polQ, levelQ + 1, 0, polP, levelP + 1, nullptr, 0, nullptr, 0, npoly, BEXT_ADD_CRED);
+}
+extern "C" int rh_bext_modup_p_to_q(rh_bext* be, int levelP, int levelQ, const uint64_t* polP, uint64_t* polQ, int npoly) {
+  if (int rc = check_levels(be, levelQ, levelP, true)) return rc;
+  BextPlan* p; if (int rc = get_modup_plan(be, 0, 1, levelP, levelQ, &p)) return rc;
+  return launch_plan(be, *p, polP, levelP + 1, 0, polQ, levelQ + 1, nullptr, 0, nullptr, 0, npoly, BEXT_ADD_CRED);
+}
+extern "C" int rh_bext_moddown_qp_to_q(rh_bext* be, int levelQ, int levelP, const uint64_t* p1Q, const uint64_t* p1P, uint64_t* p2Q, int npoly) {
+  if (int rc = check_levels(be, levelQ, levelP, true)) return rc;
+  BextPlan* p; if (int rc = get_modup_plan(be, 1, 1, levelP, levelQ, &p)) return rc;
+  return launch_plan(be, *p, p1P, levelP + 1, 0, p2Q, levelQ + 1, nullptr, 0, p1Q, levelQ + 1, npoly, BEXT_ADD_CRED);
+}
+extern "C" int rh_bext_moddown_qp_to_p(rh_bext* be, int levelQ, int levelP, const uint64_t* p1Q, const uint64_t* p1P, uint64_t* p2P, int npoly) {
+  if (int rc = check_levels(be, levelQ, levelP, true)) return rc;
+  BextPlan* p; if (int rc = get_modup_plan(be, 1, 0, levelQ, levelP, &p)) return rc;
+  return launch_plan(be, *p, p1Q, levelQ + 1, 0, p2P, levelP + 1, nullptr, 0, p1P, levelP + 1, npoly, BEXT_ADD_CRED);
+}
+
+// ModDownQPtoQNTT (:241-258): INTTLazy on P, ModUpPtoQ, NTTLazy on Q, fused subtract-multiply
+extern "C" int rh_bext_moddown_qp_to_q_ntt(rh_bext* be, int levelQ, int levelP, const uint64_t* p1Q, const uint64_t* p1P, uint64_t* p2Q, int npoly) {
+  if (int rc = check_levels(be, levelQ, levelP, true)) return rc;
+  if (be->Q->kind != RH_RING_STANDARD || be->P->kind != RH_RING_STANDARD) return rh_fail(RH_ERR_UNSUPPORTED, "ModDownQPtoQNTT needs standard rings");
+  const size_t N = be->Q->N;
+  if (int rc = ensure_buf(be, 0, (size_t)npoly * (levelQ + 1) * N)) return rc;
+  if (int rc = ensure_buf(be, 1, (size_t)npoly * (levelP + 1) * N)) return rc;
+  u64* buffQ = be->buf[0]; u64* buffP = be->buf[1];
+  if (int rc = rh_std_ntt_launch(be->P, p1P, buffP, npoly, levelP + 1, 0, true, true, 0)) return rc;          // ringP.INTTLazy
+  BextPlan* p; if (int rc = get_modup_plan(be, 0, 1, levelP, levelQ, &p)) return rc;
+  if (int rc = launch_plan(be, *p, buffP, levelP + 1, 0, buffQ, levelQ + 1, nullptr, 0, nullptr, 0, npoly, BEXT_ADD_CRED)) return rc;
+  // ringQ.NTTLazy(buffQ, buffQ): the following MRed yields the canonical residue for any representative (< 8q) of the
+  // NTT values, so the canonical forward transform is used.
+  if (int rc = rh_std_ntt_launch(be->Q, buffQ, buffQ, npoly, levelQ + 1, 0, false, false, 0)) return rc;
+  std::vector<u64> sc(levelQ + 1);
+  std::vector<u64> Ps(be->P->moduli.begin(), be->P->moduli.begin() + levelP + 1);
+  for (int i = 0; i <= levelQ; ++i) sc[i] = be->Q->moduli[i] - moddown_const(Ps, be->Q->moduli[i]);
+  return rh_vec_launch(be->Q, RH_OP_SUB_THEN_MUL_SCALAR_MONT_TWO_MODULUS, buffQ, p1Q, p2Q, npoly, levelQ + 1, 0, sc.data(), nullptr);
+}
+
+// DecomposeAndSplit (:381-502)
+extern "C" int rh_bext_decompose_and_split(rh_bext* be, int levelQ, int levelP, int nbPi, int digit, const uint64_t* p0Q,
+                                           uint64_t* p1Q, uint64_t* p1P, int npoly) {
+  if (int rc = check_levels(be, levelQ, levelP, be && be->P != nullptr)) return rc;
+  if (nbPi < 1 || digit < 0) return rh_fail(RH_ERR_ARG, "DecomposeAndSplit: bad nbPi/digit");
+  rh_ring* RQ = be->Q; rh_ring* RP = be->P;
+  const int N = RQ->N;
+  const int st = digit * nbPi;
+  if (st > levelQ) return rh_fail(RH_ERR_ARG, "DecomposeAndSplit: digit %d starts past levelQ %d", digit, levelQ);
+  int decompLvl = (levelQ > nbPi * (digit + 1) - 1) ? nbPi - 2 : (levelQ % nbPi) - 1;            // :394-399
+  const int nP = RP ? levelP + 1 : 0;
+  std::array<int, 5> key{2, levelQ, RP ? levelP : -1, nbPi, digit};
+  auto it = be->plans.find(key);
+  if (it == be->plans.end()) {
+    BextPlan p;
+    if (decompLvl < 0) {
+      std::vector<SignTarget> T;
+      for (int i = 0; i <= levelQ; ++i) T.push_back(SignTarget{RQ->moduli[i], RQ->bred[2 * i], 0, i});
+      for (int i = 0; i < nP; ++i) T.push_back(SignTarget{RP->moduli[i], RP->bred[2 * i], 1, i});
+      p.ntgt = (int)T.size(); p.qd = RQ->moduli[st];
+      if (int rc = upv(&p.d_sign, T)) return rc;
+    } else {
+      if (!RP) return rh_fail(RH_ERR_ARG, "DecomposeAndSplit: multi-prime digit needs ringP");
+      if (nbPi > RP->L) return rh_fail(RH_ERR_ARG, "DecomposeAndSplit: nbPi %d exceeds the P ring (%d limbs)", nbPi, RP->L);
+      int ed = st + nbPi; if (ed > levelQ + 1) ed = levelQ + 1;
+      std::vector<u64> Qs(RQ->moduli.begin() + st, RQ->moduli.begin() + ed);
+      // constants: GenModUpConstants(Q[st:ed], Q_all ++ P[:nbPi]) (NewDecomposer :345-372); only the rows of the
+      // limbs actually written are kept.  Row u of the reference = limb u of Q (u < len(Q)) or len(Q)+j for P_j.
+      std::vector<u64> tg; std::vector<BextTarget> T;
+      for (int j = 0; j <= levelQ; ++j) {
+        BextTarget t{}; t.p = RQ->moduli[j]; t.pinv = RQ->mred[j]; t.half = half_product_mod(Qs, t.p);
+        t.buf = 0; t.limb = j; t.post = 1; t.skip = (j >= st && j < ed) ? 1 : 0;
+        T.push_back(t); tg.push_back(t.p);
+      }
+      for (int j = 0; j < nP; ++j) {
+        BextTarget t{}; t.p = RP->moduli[j]; t.pinv = RP->mred[j]; t.half = half_product_mod(Qs, t.p);
+        t.buf = 1; t.limb = j; t.post = 1; t.skip = 0;
+        T.push_back(t); tg.push_back(t.p);
+      }
+      std::vector<u64> qsi, coef, vt;
+      gen_modup(Qs, tg, qsi, coef, vt);
+      std::vector<BextSource> S(Qs.size());
+      for (size_t i = 0; i < Qs.size(); ++i) S[i] = BextSource{Qs[i], RQ->mred[st + i], qsi[i], half_product_mod(Qs, Qs[i])};
+      p.nsrc = (int)Qs.size(); p.ntgt = (int)T.size();
+      int rc = upv(&p.d_S, S); if (!rc) rc = upv(&p.d_T, T); if (!rc) rc = upv(&p.d_coef, coef); if (!rc) rc = upv(&p.d_vt, vt);
+      if (rc) return rc;
+    }
+    it = be->plans.emplace(key, p).first;
+  }
+  const BextPlan& p = it->second;
+  if (npoly <= 0) return RH_OK;
+  if (decompLvl < 0) {
+    dim3 grid((N + 255) / 256, npoly);
+    (void)hipGetLastError();
+    bext_sign_copy_kernel<<<grid, 256, 0, RQ->stream>>>(p0Q, levelQ + 1, st, p.qd, p.ntgt, p.d_sign, p1Q, levelQ + 1, p1P, nP, N);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "bext_sign_copy_kernel launch failed: %s", hipGetErrorString(e));
+    return RH_OK;
+  }
+  return launch_plan(be, p, p0Q, levelQ + 1, st, p1Q, levelQ + 1, p1P, nP, nullptr, 0, npoly, BEXT_ADD_RAW);
+}

@@ -220,7 +220,7 @@ extern "C" int rh_dev_alloc(rh_ring* r, size_t words, uint64_t** dptr) {
   if (hipMalloc((void**)dptr, words * 8) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc(%zu words) failed", words);
   return RH_OK;
 }
-extern "C" int rh_dev_free(rh_ring* r, uint64_t* dptr) { if (r) (void)hipSetDevice(r->device); if (dptr) (void)hipFree(dptr); return RH_OK; }
+extern "C" int rh_dev_free(rh_ring* /*r: unused, may already be destroyed*/, uint64_t* dptr) { if (dptr) (void)hipFree(dptr); return RH_OK; }
 extern "C" int rh_dev_upload(rh_ring* r, uint64_t* dst, const uint64_t* src, size_t words) {
   if (!r || !dst || !src) return rh_fail(RH_ERR_ARG, "rh_dev_upload: null argument");
   hipError_t e = hipMemcpyAsync(dst, src, words * 8, hipMemcpyHostToDevice, r->stream);
@@ -268,6 +268,7 @@ static void launch_inv_cols(int S1, dim3 grid, hipStream_t st, u64* data, const 
 // limb0: first limb of the table set to use (host-pointer single-limb path); rows = npoly * Lrows.
 // phase: 0 = whole transform, 1 = column kernel only, 2 = tile kernel only (profiling aid, rh_ring_ntt_phase).
 static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase) {
+  (void)hipGetLastError();                       // drop any stale error of an unrelated earlier call
   const int logN = r->logN, N = r->N;
   const size_t toff = (size_t)limb0 * N;
   const LimbConsts* c = r->d_consts + limb0;
@@ -436,6 +437,7 @@ static const vec_fn* vec_table(std::integer_sequence<int, I...>) {
 int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3, int npoly, int Lrows, int limb0,
                   const u64* s0, const u64* s1) {
   static const vec_fn* table = vec_table(std::make_integer_sequence<int, RH_OP_COUNT>());
+  (void)hipGetLastError();
   ScalarPack a, b;
   memset(&a, 0, sizeof(a)); memset(&b, 0, sizeof(b));
   if (s0) memcpy(a.s, s0, (size_t)Lrows * 8);

@@ -286,6 +286,7 @@ int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
   const unsigned rows = (unsigned)npoly * (unsigned)Lrows;
   if (rows == 0) return RH_OK;
   if (int rc = ensure_tmp(s, (size_t)rows * N)) return rc;
+  (void)hipGetLastError();
   hipStream_t st = r->stream;
   const LimbConsts* c = r->d_consts + limb0;
   const Limb3N* l3 = s->d_l3 + limb0;

@@ -127,7 +127,7 @@ class DevicePoly:
 
     def free(self):
         if self._own and self.ptr:
-            lib().rh_dev_free(self.ring._h, self.ptr)
+            lib().rh_dev_free(None, self.ptr)      # the ring handle may already be closed; the free does not need it
             self.ptr = 0
 
     def __del__(self):
