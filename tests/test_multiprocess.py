@@ -1,0 +1,67 @@
+"""CPU, 2 processes over gloo: the N>1 path of the bench/host logic -- batch sharding without a data-path collective,
+max-over-ranks timing, final gather.  The per-rank compute stands in with the oracle (no GPU here)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import matrix_fhe_lattigo_amd  # noqa: F401  (alias module)
+    from matrix_fhe_lattigo_amd import sharding
+    import oracle
+    N, mods, B = 256, [0x1fffffffffe00001, 0x1fffffffffc80001], 5
+    rng = np.random.default_rng(7)                               # same batch on every rank, each transforms its shard
+    a = np.stack([np.stack([rng.integers(0, 1 << 62, size=N, dtype=np.uint64) % np.uint64(m) for m in mods]) for _ in range(B)])
+    lo, hi = sharding.poly_shard(B, rank, world)
+    srs = [oracle.SubRingConsts(N, m) for m in mods]
+    local = np.stack([np.stack([oracle.ntt(a[k, i], srs[i]) for i in range(2)]) for k in range(lo, hi)]) if hi > lo else np.zeros((0, 2, N), dtype=np.uint64)
+    t = sharding.max_over_ranks(1.0 + rank, dist)
+    parts = sharding.gather_shards(local, dist)
+    full = np.concatenate(parts)
+    exp = np.stack([np.stack([oracle.ntt(a[k, i], srs[i]) for i in range(2)]) for k in range(B)])
+    q.put((rank, t, bool(np.array_equal(full, exp)), (lo, hi)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_batch_shard_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == [0, 1]
+    assert all(abs(r[1] - 2.0) < 1e-9 for r in res)          # MAX over ranks of (1.0, 2.0)
+    assert all(r[2] for r in res)                             # gathered shards == whole-batch transform
+    assert res[0][3] == (0, 3) and res[1][3] == (3, 5)
+
+
+def test_shard_helpers():
+    sys.path.insert(0, ROOT)
+    import matrix_fhe_lattigo_amd  # noqa: F401
+    from matrix_fhe_lattigo_amd import sharding
+    for total in (0, 1, 7, 1024):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.poly_shard(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    assert sorted(sum((sharding.limb_shard(30, r, 8) for r in range(8)), [])) == list(range(30))
