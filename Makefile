@@ -5,11 +5,14 @@ PKG   := matrix-fhe-lattigo_amd
 CSRC  := $(PKG)/csrc
 LIB   := $(PKG)/lib/libringhip.so
 SRCS  := $(CSRC)/engine.hip $(CSRC)/ntt3n.hip $(CSRC)/bext.hip
-HDRS  := $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.hpp) $(wildcard include/*.h)
+HDRS  := $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.inc) $(wildcard $(CSRC)/*.hpp) $(wildcard include/*.h)
 
 all: $(LIB) oracle
 
-$(LIB): $(SRCS) $(HDRS)
+$(CSRC)/ntt_tile_asm.inc: tools/gen_tile_asm.py
+	python3 tools/gen_tile_asm.py $@
+
+$(LIB): $(SRCS) $(HDRS) $(CSRC)/ntt_tile_asm.inc
 	@mkdir -p $(PKG)/lib
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Iinclude $(SRCS) -o $@
 

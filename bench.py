@@ -35,6 +35,10 @@ def main():
     ap.add_argument("--chunk", type=int, default=-1, help="polys per (column,tile) kernel pair; -1 = engine default")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--persistent", type=int, default=-1)
+    ap.add_argument("--unsafe", type=int, default=0)
+    ap.add_argument("--group", type=int, default=-1, help="polys per group of the persistent pipeline")
+    ap.add_argument("--asm", type=int, default=-1, help="1/0: hand-scheduled vs C++ forward tile kernel; -1 = engine default")
     args = ap.parse_args()
 
     import numpy as np
@@ -59,6 +63,14 @@ def main():
     ring.set_stream(stream.cuda_stream)
     if args.chunk >= 0:
         ring.set_tuning("chunk_polys", args.chunk)
+    if args.asm >= 0:
+        ring.set_tuning("asm_tile", args.asm)
+    if args.persistent >= 0:
+        ring.set_tuning("persistent", args.persistent)
+    if args.unsafe:
+        ring.set_tuning("persist_unsafe_timing", 1)
+    if args.group >= 1:
+        ring.set_tuning("group_polys", args.group)
 
     # synthetic input: i.i.d. residues in [0, q_i), seeded, generated on the device
     g = torch.Generator(device=dev); g.manual_seed(0x5eed + rank)
@@ -89,6 +101,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    ring.sync()                                   # raises if the pipeline reported a hand-off time-out
     wall = t1 - t0
     dev_ms = e0.elapsed_time(e1)
     if dist is not None:

@@ -89,7 +89,7 @@ int rh_ring_intt(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npol
 
 /* profiling aid: phase 0 = whole transform, 1 = column kernel only, 2 = tile kernel only (N >= 8192) */
 int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int inverse, int phase);
-/* tuning knobs (performance only, never results): "chunk_polys" = polys per pipelined (column, tile) kernel span: -1 auto, 0 = whole batch */
+/* tuning knobs (performance only, never results): "chunk_polys" = polys per span of the fused (column+tile) forward pipeline: -1 auto, 0 = whole batch in two launches; "asm_tile", "persistent", "group_polys": see DESIGN.md */
 int rh_ring_set_tuning(rh_ring* r, const char* key, long value);
 
 /* ---- element-wise family (ring/vec_ops.go via ring/operations.go loops): p3 = op(p1, p2 [, p3]) on npoly polys of

@@ -13,6 +13,7 @@
 #include "hostmath.hpp"
 #include "ntt_kernels.cuh"
 #include "vec_kernels.cuh"
+#include "ntt_kernels_asm.cuh"
 #include "engine_internal.hpp"
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -182,12 +183,8 @@ extern "C" int rh_ring_create_auto(rh_ring** out, int device, int kind, int N, i
 extern "C" void rh_ring_destroy(rh_ring* r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
-  void* ptrs[] = {r->d_consts, r->d_tw_fwd, r->d_tw_inv, r->d_tw_fwd_mont, r->d_twk_fwd, r->d_twk_inv, r->d_twk_fwd_mont, r->d_lastw, r->d_scratch};
+  void* ptrs[] = {r->d_consts, r->d_tw_fwd, r->d_tw_inv, r->d_tw_fwd_mont, r->d_twk_fwd, r->d_twk_inv, r->d_twk_fwd_mont, r->d_lastw, r->d_scratch, r->d_rowcnt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  if (r->aux_ready) {
-    for (int i = 0; i < 2; ++i) (void)hipStreamDestroy(r->aux[i]);
-    for (int i = 0; i < RH_NEVENTS; ++i) (void)hipEventDestroy(r->ev[i]);
-  }
   rh_ring3n_teardown(r);
   delete r;
 }
@@ -210,6 +207,13 @@ extern "C" int rh_ring_sync(rh_ring* r) {
   if (!r) return rh_fail(RH_ERR_ARG, "null ring");
   hipError_t e = hipStreamSynchronize(r->stream);
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "hipStreamSynchronize: %s", hipGetErrorString(e));
+  if (r->d_rowcnt) {                      // the persistent pipeline's bounded waits report here
+    unsigned flag = 0;
+    if (hipMemcpy(&flag, r->d_rowcnt + r->err_index, sizeof(flag), hipMemcpyDeviceToHost) == hipSuccess && flag) {
+      (void)hipMemset(r->d_rowcnt + r->err_index, 0, sizeof(flag));
+      return rh_fail(RH_ERR_DEVICE, "persistent NTT pipeline: a hand-off wait timed out (results of the last batch are invalid)");
+    }
+  }
   return RH_OK;
 }
 
@@ -297,66 +301,99 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
       src = out;
     }
     if (phase != 1) {
-      if (lazy) ntt_fwd_tile<MontPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd_mont + toff, c, Lrows, logN, 0);
-      else      ntt_fwd_tile<ShoupPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, 1);
+      if (lazy) ntt_fwd_tile<MontPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd_mont + toff, c, Lrows, logN, 0, npoly);
+      else if (r->asm_tile) ntt_fwd_tile_asm<<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, npoly);
+      else      ntt_fwd_tile<ShoupPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, 1, npoly);
     }
   } else {
-    if (phase != 1) ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, (S1 == 0 && r->inv_scale) ? 1 : 0);
+    if (phase != 1) ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, (S1 == 0 && r->inv_scale) ? 1 : 0, npoly);
     if (S1 > 0 && phase != 2) launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, logN, r->inv_scale ? 1 : 0);
   }
   return check_launch("ntt");
 }
 
-// Large batches are cut into spans of `chunk_polys` polys and software-pipelined over two internal streams: the
-// column kernel of span i+1 (HBM-bound) runs beside the tile kernel of span i (VALU-bound), and what the column
-// kernel wrote is still in the 256 MiB Infinity Cache when the tile kernel reads it back.  The caller's stream
-// ordering is preserved by a fork event at entry and a join at exit.
-static int ensure_aux(rh_ring* r) {
-  if (r->aux_ready) return RH_OK;
-  for (int i = 0; i < 2; ++i)
-    if (hipStreamCreateWithFlags(&r->aux[i], hipStreamNonBlocking) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "hipStreamCreate failed");
-  for (int i = 0; i < RH_NEVENTS; ++i)
-    if (hipEventCreateWithFlags(&r->ev[i], hipEventDisableTiming) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "hipEventCreate failed");
-  r->aux_ready = true;
-  return RH_OK;
+template <int S1>
+static void launch_fused(rh_ring* r, const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n2, int npoly2,
+                         size_t toff, const LimbConsts* c, int Lrows) {
+  const unsigned grid = n1 > n2 ? n1 : n2;
+  if (r->asm_tile)
+    ntt_fwd_fused_asm<S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN);
+  else
+    ntt_fwd_fused<ShoupPolicy, S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff,
+                                                             c, Lrows, r->logN, 1);
+}
+
+// Forward canonical transform of a large batch: software pipeline over spans of `chunk` polys in ONE stream; launch j
+// runs the column stages of span j fused with the tile stages of span j-1 (ntt_fwd_fused).
+static int std_ntt_fwd_pipelined(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, int chunk) {
+  (void)hipGetLastError();
+  const int N = r->N, S1 = r->logN - LT;
+  const size_t toff = (size_t)limb0 * N, stride = (size_t)Lrows * N;
+  const LimbConsts* c = r->d_consts + limb0;
+  const int nspans = (npoly + chunk - 1) / chunk;
+  for (int j = 0; j <= nspans; ++j) {
+    const int p1 = j * chunk, n1p = j < nspans ? ((npoly - p1 < chunk) ? npoly - p1 : chunk) : 0;
+    const int p2 = (j - 1) * chunk, n2p = j >= 1 ? ((npoly - p2 < chunk) ? npoly - p2 : chunk) : 0;
+    const unsigned n1 = (unsigned)n1p * Lrows * 16, n2 = ((unsigned)n2p * Lrows) << S1;
+    const u64* i1 = in + (size_t)p1 * stride; u64* o1 = out + (size_t)p1 * stride; u64* d2 = out + (size_t)p2 * stride;
+    switch (S1) {
+      case 1: launch_fused<1>(r, i1, o1, n1, d2, n2, n2p, toff, c, Lrows); break;
+      case 2: launch_fused<2>(r, i1, o1, n1, d2, n2, n2p, toff, c, Lrows); break;
+      case 3: launch_fused<3>(r, i1, o1, n1, d2, n2, n2p, toff, c, Lrows); break;
+      case 4: launch_fused<4>(r, i1, o1, n1, d2, n2, n2p, toff, c, Lrows); break;
+      case 5: launch_fused<5>(r, i1, o1, n1, d2, n2, n2p, toff, c, Lrows); break;
+    }
+  }
+  return check_launch("ntt_fwd_fused");
+}
+
+// Single-launch persistent pipeline (ntt_fwd_persistent).  Grid = number of workgroups that are resident at once.
+template <int S1>
+static int launch_persistent(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, size_t toff, const LimbConsts* c) {
+  if (r->persist_grid == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ntt_fwd_persistent<S1>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r->device) != hipSuccess || cus < 1) cus = 1;
+    if (per_cu > 4) per_cu = 4;                     // LDS (34 KiB) and 125 VGPRs admit 4; never ask for more
+    r->persist_grid = per_cu * cus;
+  }
+  const size_t rows = (size_t)npoly * Lrows;
+  if (r->rowcnt_words < rows + 1) {
+    if (r->d_rowcnt) (void)hipFree(r->d_rowcnt);
+    r->d_rowcnt = nullptr; r->rowcnt_words = 0;
+    if (hipMalloc((void**)&r->d_rowcnt, (rows + 1) * sizeof(unsigned)) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc(row counters) failed");
+    r->rowcnt_words = rows + 1;
+    (void)hipMemsetAsync(r->d_rowcnt + rows, 0, sizeof(unsigned), r->stream);       // error word lives behind the counters
+    r->err_index = rows;
+  }
+  (void)hipMemsetAsync(r->d_rowcnt, 0, rows * sizeof(unsigned), r->stream);
+  unsigned grid = (unsigned)r->persist_grid;
+  const size_t items = rows * 16;
+  if (items < grid) grid = (unsigned)items;
+  ntt_fwd_persistent<S1><<<grid, 256, 0, r->stream>>>(in, out, npoly, r->group_polys, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows,
+                                                      r->logN, r->d_rowcnt, r->d_rowcnt + r->err_index, r->persist_unsafe);
+  return check_launch("ntt_fwd_persistent");
 }
 
 int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase) {
+  if (r->persistent && r->logN > LT && phase == 0 && !inverse && !lazy && npoly >= 1) {
+    (void)hipGetLastError();
+    const size_t toff = (size_t)limb0 * r->N;
+    const LimbConsts* c = r->d_consts + limb0;
+    switch (r->logN - LT) {
+      case 1: return launch_persistent<1>(r, in, out, npoly, Lrows, toff, c);
+      case 2: return launch_persistent<2>(r, in, out, npoly, Lrows, toff, c);
+      case 3: return launch_persistent<3>(r, in, out, npoly, Lrows, toff, c);
+      case 4: return launch_persistent<4>(r, in, out, npoly, Lrows, toff, c);
+      case 5: return launch_persistent<5>(r, in, out, npoly, Lrows, toff, c);
+    }
+  }
   int chunk = r->chunk_polys;
-  if (chunk < 0) {                                   // auto: ~64 MiB of coefficients per span
-    const size_t poly_bytes = (size_t)Lrows * r->N * 8;
-    chunk = (int)(((size_t)64 << 20) / poly_bytes);
-    if (chunk < 1) chunk = 1;
-  }
+  if (chunk < 0) chunk = npoly >= 256 ? 128 : 0;    // auto: pipeline big batches in spans of 128 polys (measured optimum)
   const bool two_pass = r->logN > LT;
-  if (chunk <= 0 || !two_pass || phase != 0 || npoly <= chunk) return std_ntt_launch_span(r, in, out, npoly, Lrows, limb0, inverse, lazy, phase);
-  if (int rc = ensure_aux(r)) return rc;
-  const size_t stride = (size_t)Lrows * r->N;
-  hipStream_t user = r->stream, sA = r->aux[0], sB = r->aux[1];
-  hipEvent_t fork = r->ev[0], joinA = r->ev[1], joinB = r->ev[2];
-  hipEvent_t* ring_ev = r->ev + 3;                   // RH_NEVENTS-3 rotating events for span hand-offs
-  const int nrot = RH_NEVENTS - 3;
-  if (hipEventRecord(fork, user) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "hipEventRecord failed");
-  (void)hipStreamWaitEvent(sA, fork, 0); (void)hipStreamWaitEvent(sB, fork, 0);
-  int rc = RH_OK, k = 0;
-  // first-pass kernel on sA, second-pass kernel on sB (forward: cols then tile; inverse: tile then cols)
-  const int first = inverse ? 2 : 1, second = inverse ? 1 : 2;
-  for (int p0 = 0; p0 < npoly && !rc; p0 += chunk, ++k) {
-    const int n = (npoly - p0 < chunk) ? (npoly - p0) : chunk;
-    const u64* src = in + p0 * stride; u64* dst = out + p0 * stride;
-    r->stream = sA;
-    rc = std_ntt_launch_span(r, src, dst, n, Lrows, limb0, inverse, lazy, first);
-    hipEvent_t e = ring_ev[k % nrot];
-    (void)hipEventRecord(e, sA);
-    (void)hipStreamWaitEvent(sB, e, 0);
-    r->stream = sB;
-    // the second pass always reads what the first wrote (dst)
-    if (!rc) rc = std_ntt_launch_span(r, dst, dst, n, Lrows, limb0, inverse, lazy, second);
-  }
-  r->stream = user;
-  (void)hipEventRecord(joinA, sA); (void)hipEventRecord(joinB, sB);
-  (void)hipStreamWaitEvent(user, joinA, 0); (void)hipStreamWaitEvent(user, joinB, 0);
-  return rc;
+  if (chunk > 0 && two_pass && phase == 0 && !inverse && !lazy && npoly > chunk)
+    return std_ntt_fwd_pipelined(r, in, out, npoly, Lrows, limb0, chunk);
+  return std_ntt_launch_span(r, in, out, npoly, Lrows, limb0, inverse, lazy, phase);
 }
 
 static int ntt_batch(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, bool inverse, bool lazy, int phase = 0) {
@@ -376,6 +413,11 @@ extern "C" int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in, uint64_t* out, 
 extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
   if (!r || !key) return rh_fail(RH_ERR_ARG, "set_tuning: null argument");
   if (!strcmp(key, "chunk_polys")) { r->chunk_polys = (int)value; return RH_OK; }
+  if (!strcmp(key, "asm_tile")) { r->asm_tile = value != 0; return RH_OK; }
+  if (!strcmp(key, "persistent")) { r->persistent = value != 0; return RH_OK; }
+  if (!strcmp(key, "group_polys")) { if (value < 1) return rh_fail(RH_ERR_ARG, "group_polys must be >= 1"); r->group_polys = (int)value; return RH_OK; }
+  if (!strcmp(key, "persist_grid")) { r->persist_grid = (int)value; return RH_OK; }
+  if (!strcmp(key, "persist_unsafe_timing")) { r->persist_unsafe = (int)value; return RH_OK; }   // timing experiments only
   return rh_fail(RH_ERR_ARG, "set_tuning: unknown key %s", key);
 }
 

@@ -7,7 +7,6 @@
 #include "ring_types.cuh"
 
 #define RH_MAX_LIMBS 64
-#define RH_NEVENTS 11
 
 int rh_fail(int code, const char* fmt, ...);
 
@@ -30,11 +29,14 @@ struct rh_ring {
   tw2* d_lastw = nullptr;         // psi_bwd[1] * N^-1 per limb
   u64* d_scratch = nullptr;       // 2N words for the host-pointer single-limb path
   rh_ring3n_state* s3n = nullptr;
-  hipStream_t aux[2] = {nullptr, nullptr};
-  hipEvent_t ev[RH_NEVENTS] = {};
-  bool aux_ready = false;
+  bool persistent = false;        // single-launch pipelined forward transform (ntt_fwd_persistent)
+  int group_polys = 8;            // polys per pipeline group of the persistent kernel
+  int persist_unsafe = 0;         // timing experiments only: plain stores and no acquire in the hand-off
+  int persist_grid = 0;           // resident workgroups (0 = query)
+  unsigned* d_rowcnt = nullptr; size_t rowcnt_words = 0, err_index = 0;
+  bool asm_tile = true;           // forward tile kernel: hand-scheduled body (ntt_kernels_asm.cuh) vs the C++ one
   bool inv_scale = true;          // false: inverse leaves values < 4q without the N^-1 factor (3N sub-transform)
-  int chunk_polys = -1;           // -1 = auto (~64 MiB spans), 0 = whole batch per launch, >0 = polys per span
+  int chunk_polys = -1;           // -1 = auto (128-poly spans for batches >= 256), 0 = whole batch in two launches, >0 = polys per span
 };
 
 int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase = 0);

@@ -117,17 +117,16 @@ RH_DEV void round16_inv(const P& p, u64 (&x)[16], TWF TW) {
 //   [0,15) round A slots (uniform) | [16,256) round B: slot*16 + hi4 | [256,4096) round C: slot*256 + tid
 // ---------------------------------------------------------------------------------------------------------------
 template <class P>
-__global__ void __launch_bounds__(256)
-ntt_fwd_tile(const u64* in, u64* out, const typename P::tw_t* __restrict__ twk,
-             const LimbConsts* __restrict__ consts, int L, int logN, int canonical) {
-  __shared__ u64 lds[LDS_WORDS];
+RH_DEV void fwd_tile_body(u64* lds, const u32 b, const u64* in, u64* out, const typename P::tw_t* __restrict__ twk,
+                          const LimbConsts* __restrict__ consts, int L, int logN, int canonical, int npoly) {
   const int tid = threadIdx.x;
-  const u32 b = blockIdx.x;
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
   const int S1 = logN - LT;
-  const u32 tile = r & ((1u << S1) - 1);
-  const u32 poly = r >> S1;
+  // poly is the fast index: workgroups resident at the same time work on the SAME tile of different polys, so that
+  // tile's twiddles (64 KiB per limb) are served by the XCD's L2 instead of being re-fetched per poly
+  const u32 poly = r % (u32)npoly;
+  const u32 tile = r / (u32)npoly;
   const size_t base = (((size_t)poly * L + limb) << logN) + ((size_t)tile << LT);
   const typename P::tw_t* tw = twk + ((size_t)limb << logN) + ((size_t)tile << LT);
   P p; p.init(consts[limb]);
@@ -158,6 +157,13 @@ ntt_fwd_tile(const u64* in, u64* out, const typename P::tw_t* __restrict__ twk,
 #pragma unroll
   for (int k = 0; k < 16; ++k) out[base + tid + 256 * k] = lds[LDS_PAD(tid + 256 * k)];
 }
+template <class P>
+__global__ void __launch_bounds__(256)
+ntt_fwd_tile(const u64* in, u64* out, const typename P::tw_t* __restrict__ twk,
+             const LimbConsts* __restrict__ consts, int L, int logN, int canonical, int npoly) {
+  __shared__ u64 lds[LDS_WORDS];
+  fwd_tile_body<P>(lds, blockIdx.x, in, out, twk, consts, L, logN, canonical, npoly);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // K2 inverse: first 12 stages (t = 1..2048) on a 4096-tile.  If `last` (logN == 12) the N^-1 scaling and the
@@ -165,15 +171,17 @@ ntt_fwd_tile(const u64* in, u64* out, const typename P::tw_t* __restrict__ twk,
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 ntt_inv_tile(const u64* in, u64* out, const tw2* __restrict__ twk,
-             const LimbConsts* __restrict__ consts, int L, int logN, int last) {
+             const LimbConsts* __restrict__ consts, int L, int logN, int last, int npoly) {
   __shared__ u64 lds[LDS_WORDS];
   const int tid = threadIdx.x;
   const u32 b = blockIdx.x;
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
   const int S1 = logN - LT;
-  const u32 tile = r & ((1u << S1) - 1);
-  const u32 poly = r >> S1;
+  // poly is the fast index: workgroups resident at the same time work on the SAME tile of different polys, so that
+  // tile's twiddles (64 KiB per limb) are served by the XCD's L2 instead of being re-fetched per poly
+  const u32 poly = r % (u32)npoly;
+  const u32 tile = r / (u32)npoly;
   const size_t base = (((size_t)poly * L + limb) << logN) + ((size_t)tile << LT);
   const tw2* tw = twk + ((size_t)limb << logN) + ((size_t)tile << LT);
   const LimbConsts c = consts[limb];
@@ -211,12 +219,11 @@ ntt_inv_tile(const u64* in, u64* out, const tw2* __restrict__ twk,
 // K1 forward: first S1 stages, R = 2^S1 coefficients per thread at stride 4096.  twn: natural-order table
 // (RootsForward index), entries [1, R) are used and are wave-uniform.
 // ---------------------------------------------------------------------------------------------------------------
-template <class P, int S1>
-__global__ void __launch_bounds__(256)
-ntt_fwd_cols(const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
-             const LimbConsts* __restrict__ consts, int L, int logN) {
+// WT: write-through (sc1) stores, for the in-launch hand-off of the persistent pipeline (ntt_kernels_asm.cuh)
+template <class P, int S1, bool WT = false>
+RH_DEV void fwd_cols_body(const u32 b, const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
+                          const LimbConsts* __restrict__ consts, int L, int logN) {
   constexpr int R = 1 << S1;
-  const u32 b = blockIdx.x;
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
   const u32 cb = r & 15;            // 16 blocks of 256 columns per limb
@@ -239,7 +246,28 @@ ntt_fwd_cols(const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
     }
   }
 #pragma unroll
-  for (int k = 0; k < R; ++k) out[base + ((size_t)k << LT)] = x[k];
+  for (int k = 0; k < R; ++k) {
+    if (WT) __hip_atomic_store(&out[base + ((size_t)k << LT)], x[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else out[base + ((size_t)k << LT)] = x[k];
+  }
+}
+template <class P, int S1>
+__global__ void __launch_bounds__(256)
+ntt_fwd_cols(const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
+             const LimbConsts* __restrict__ consts, int L, int logN) {
+  fwd_cols_body<P, S1>(blockIdx.x, in, out, twn, consts, L, logN);
+}
+// Fused launch of a software pipeline over spans of polys: the workgroup first runs the (HBM-bound) column stages of
+// one unit of span j, then the (VALU-bound) tile stages of one tile of span j-1, so that on every CU memory-phase and
+// compute-phase workgroups are co-resident.  n1/n2 = number of column units / tiles in this launch.
+template <class P, int S1>
+__global__ void __launch_bounds__(256)
+ntt_fwd_fused(const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n2, int npoly2,
+              const typename P::tw_t* __restrict__ twn, const typename P::tw_t* __restrict__ twk,
+              const LimbConsts* __restrict__ consts, int L, int logN, int canonical) {
+  __shared__ u64 lds[LDS_WORDS];
+  if (blockIdx.x < n1) fwd_cols_body<P, S1>(blockIdx.x, in1, out1, twn, consts, L, logN);
+  if (blockIdx.x < n2) fwd_tile_body<P>(lds, blockIdx.x, data2, data2, twk, consts, L, logN, canonical, npoly2);
 }
 
 // K1 inverse: last S1 stages (t = 4096 .. N/2), in natural-order RootsBackward indexing, then N^-1 and canonical

@@ -139,3 +139,67 @@ def test_errors_match_reference_behaviour(rh):
     ring.close()
     with pytest.raises(rh.RingHipError):          # duplicate moduli rejected (ring/ring.go:326-331)
         rh.Ring(64, [QI60[0], QI60[0]])
+
+
+@pytest.mark.parametrize("logN,chunk", [(13, 2), (16, 3)])
+def test_fused_pipeline_spans_give_identical_results(rh, oracle, logN, chunk):
+    # tuning knob "chunk_polys": software-pipelined spans (ntt_fwd_fused) must not change a single bit
+    N, mods = 1 << logN, QI60[:2]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(logN)
+    B = 7
+    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    p = rh.DevicePoly.from_numpy(ring, a)
+    ref = ring.NewPoly(B)
+    ring.NTT(p, ref)
+    ring.set_tuning("chunk_polys", chunk)
+    ring.NTT(p, p)                                    # in place, 7 polys in spans of `chunk`
+    assert np.array_equal(p.numpy(), ref.numpy())
+    srs = [oracle.SubRingConsts(N, q) for q in mods]
+    assert np.array_equal(p.numpy()[6, 1], oracle.ntt(a[6, 1], srs[1]))
+    ring.close()
+
+
+@pytest.mark.parametrize("logN", [12, 13, 16])
+def test_asm_tile_kernel_equals_cxx_kernel(rh, oracle, logN):
+    # the hand-scheduled forward tile kernel (default) and the C++ one must agree bit for bit, incl. worst-case inputs
+    N, mods = 1 << logN, [QI60[0], QI60[15], 0x10000000006e0001 if False else QI60[7]]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(77 + logN)
+    B = 3
+    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    a[0] = np.array(mods, dtype=np.uint64)[:, None] - np.uint64(1)       # all q-1: maximal lazy growth
+    a[1, :, ::2] = 0
+    p = rh.DevicePoly.from_numpy(ring, a)
+    o1, o2 = ring.NewPoly(B), ring.NewPoly(B)
+    ring.set_tuning("asm_tile", 1); ring.NTT(p, o1)
+    ring.set_tuning("asm_tile", 0); ring.NTT(p, o2)
+    assert np.array_equal(o1.numpy(), o2.numpy())
+    srs = [oracle.SubRingConsts(N, q) for q in mods]
+    for k in range(B):
+        for i in range(3):
+            assert np.array_equal(o1.numpy()[k, i], oracle.ntt(a[k, i], srs[i]))
+    ring.close()
+
+
+@pytest.mark.parametrize("logN,L,B,group", [(13, 2, 5, 2), (16, 3, 7, 2), (16, 16, 9, 4), (14, 4, 33, 8)])
+def test_persistent_pipeline_identical(rh, oracle, logN, L, B, group):
+    # single-launch pipelined transform with in-launch hand-offs: same bits as the two-launch path, in place and out of place
+    N, mods = 1 << logN, QI60[:L]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(logN * 31 + B)
+    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    p = rh.DevicePoly.from_numpy(ring, a)
+    ref = ring.NewPoly(B)
+    ring.NTT(p, ref)
+    ring.set_tuning("persistent", 1); ring.set_tuning("group_polys", group)
+    o = ring.NewPoly(B)
+    for _ in range(3):                               # repeat: counters are reset per launch
+        ring.NTT(p, o)
+        ring.sync()
+        assert np.array_equal(o.numpy(), ref.numpy())
+    ring.NTT(p, p); ring.sync()
+    assert np.array_equal(p.numpy(), ref.numpy())
+    sr = oracle.SubRingConsts(N, mods[-1])
+    assert np.array_equal(p.numpy()[B - 1, L - 1], oracle.ntt(a[B - 1, L - 1], sr))
+    ring.close()

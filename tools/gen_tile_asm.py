@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Generates matrix-fhe-lattigo_amd/csrc/ntt_tile_asm.inc: the body of the forward 4096-tile NTT kernel (the metric's
+dominant kernel) as ONE hand-scheduled gfx950 assembly block, wrapped by ntt_fwd_tile_asm in ntt_kernels_asm.cuh.
+
+Why assembly: the butterfly is VALU-issue bound and hipcc's code for it is ~21 slow + 3 fast
+instructions; the sequence below is 16 slow + 2 fast, uses no VCC in the hot chain, and fits 4 waves/SIMD.
+
+Butterfly (Shoup form, r = V*w - Q'*q in [0,4q), values < 8q), registers are even-aligned pairs:
+   T  = U - 4q ; M = T.hi >>s 31 ; u = M ? U : T                        (3 slow + 1 fast, no vcc)
+   Q' = V1*p1 + hi(V1*p0) + hi(V0*p1)                                    (4 slow; zero-extended pairs {a,0},{b,0})
+   h  = lo32(V0*w1 + V1*w0 + Q0*nq1 + Q1*nq0)                            (4 mads, each adds into the LOW word)
+   X  = u + (h<<32) + V0*w0 + Q0*nq0                                     (1 fast + 2 slow)
+   Y  = (2u + 4q) - X                                                    (1 + 2 slow)
+
+Same math as ShoupPolicy::fwd / shoup_mul_acc (modarith.cuh); outputs are canonical so results are bit-identical to
+the C++ kernel and to the reference's Forward.  Layouts (LDS padding j + j/16, kernel-order twiddles) as in
+ntt_kernels.cuh: fwd_tile_body.
+"""
+import sys
+
+out = []
+
+
+def emit(s):
+    out.append(s)
+
+
+# ---------------------------------------------------------------------------------------------- register map (VGPR)
+def X(k):            # data pair k (0..15)
+    return 2 * k
+
+
+TW0 = 32             # 15 twiddles x 4 VGPR (w.lo, w.hi, wp.lo, wp.hi) = v32..v91
+TMP0 = 92            # two temp sets of 12: T(2) M(1) pad(1) Q(2) H(2: lo, ZERO) G(2: lo, ZERO) R(2) -> and S(2) = 14
+NTMP = 14
+ADDR = 120           # v120..v123 address temporaries
+SCR = TMP0           # v92..v95: global offsets (only live before the first and after the last butterfly)
+NVGPR_USED = 124     # v0..v123 clobbered; the compiler keeps its own operands (tid) above that
+
+
+def pair(r):
+    return "v[%d:%d]" % (r, r + 1)
+
+
+class Tmp:
+    def __init__(self, base):
+        self.T = base
+        self.M = base + 2
+        self.Q = base + 4
+        self.H = base + 6      # H.lo = a, H.hi = 0 (kept zero)
+        self.G = base + 8      # G.lo = b, G.hi = 0 (kept zero)
+        self.R = base + 10
+        self.S = base + 12
+        self.cc = None         # carry pair name
+
+
+T0 = Tmp(TMP0)
+T1 = Tmp(TMP0 + NTMP)
+T0.cc = "s[96:97]"
+T1.cc = "s[98:99]"
+DUMMY = "s[100:101]"   # carry-out sink of v_mad_u64_u32
+
+
+def butterfly_steps(u, v, w, t, sgpr_tw=None):
+    """returns the instruction list of one forward butterfly on data pairs u (U) and v (V).
+    w: VGPR index of the twiddle quad, or None when sgpr_tw = (s_w_lo, s_w_hi, s_p_lo, s_p_hi) names SGPRs."""
+    if sgpr_tw is None:
+        w0, w1, p0, p1 = "v%d" % w, "v%d" % (w + 1), "v%d" % (w + 2), "v%d" % (w + 3)
+    else:
+        w0, w1, p0, p1 = sgpr_tw
+    U, V = pair(u), pair(v)
+    ul, uh, vl, vh = "v%d" % u, "v%d" % (u + 1), "v%d" % v, "v%d" % (v + 1)
+    T, Q, H, G, R, S = pair(t.T), pair(t.Q), pair(t.H), pair(t.G), pair(t.R), pair(t.S)
+    tl, th, m = "v%d" % t.T, "v%d" % (t.T + 1), "v%d" % t.M
+    ql, qh = "v%d" % t.Q, "v%d" % (t.Q + 1)
+    return [
+        "v_lshl_add_u64 %s, %s, 0, %%[nq4]" % (T, U),
+        "v_mul_hi_u32 v%d, %s, %s" % (t.H, vh, p0),
+        "v_mul_hi_u32 v%d, %s, %s" % (t.G, vl, p1),
+        "v_ashrrev_i32 %s, 31, %s" % (m, th),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (Q, DUMMY, vh, p1, H),
+        "v_mad_u64_u32 %s, %s, %s, %s, 0" % (R, DUMMY, vl, w1),
+        "v_bfi_b32 %s, %s, %s, %s" % (ul, m, ul, tl),
+        "v_bfi_b32 %s, %s, %s, %s" % (uh, m, uh, th),
+        "v_lshl_add_u64 %s, %s, 0, %s" % (Q, Q, G),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (S, DUMMY, vh, w0, R),
+        "v_lshl_add_u64 %s, %s, 1, %%[q4]" % (T, U),
+        "v_mad_u64_u32 %s, %s, %s, %%[nq1], %s" % (R, DUMMY, ql, S),
+        "v_mad_u64_u32 %s, %s, %s, %%[nq0], %s" % (S, DUMMY, qh, R),
+        "v_add_u32 %s, v%d, %s" % (uh, t.S, uh),                   # u + (h << 32), in place (V_LSHL_ADD_U64 shifts <= 7 only)
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (R, DUMMY, vl, w0, U),
+        "v_mad_u64_u32 %s, %s, %s, %%[nq0], %s" % (U, DUMMY, ql, R),
+        "v_sub_co_u32 %s, %s, %s, %s" % (vl, t.cc, tl, ul),
+        "@CARRY",                                                   # marker: >= 2 wait states to the consumer
+        "v_subb_co_u32 %s, %s, %s, %s, %s" % (vh, t.cc, th, uh, t.cc),
+    ]
+
+
+def interleave(a, b):
+    """instruction-wise interleave of two independent butterflies; resolves @CARRY markers (the partner's
+    instructions provide the wait states between v_sub_co and v_subb_co; pad with s_nop when they do not)"""
+    res = []
+    i = j = 0
+    while i < len(a) or j < len(b):
+        if i < len(a):
+            res.append(("a", a[i])); i += 1
+        if j < len(b):
+            res.append(("b", b[j])); j += 1
+    final = []
+    pending = {}
+    for who, ins in res:
+        if ins == "@CARRY":
+            pending[who] = 0
+            continue
+        if ins.startswith("v_subb_co_u32") and who in pending:
+            gap = pending.pop(who)
+            if gap < 2:
+                final.append("s_nop %d" % (1 - gap))
+        for k in pending:
+            pending[k] += 1
+        final.append(ins)
+    return final
+
+
+def single(a):
+    final = []
+    for ins in a:
+        if ins == "@CARRY":
+            final.append("s_nop 1")
+        else:
+            final.append(ins)
+    return final
+
+
+def round16(tw_of_slot, stage_hook=None, pair_hook=None):
+    """4 stages over x[0..15]; tw_of_slot(slot) -> (vgpr_quad_index or None, sgpr tuple or None).
+    stage_hook(u) / pair_hook(u, i) emit waits just before the first consumer (guide G15: waits at the first consumer)"""
+    for u in range(4):
+        h = 8 >> u
+        if stage_hook:
+            stage_hook(u)
+        bfs = []
+        for g in range(1 << u):
+            slot = (1 << u) - 1 + g
+            w, sg = tw_of_slot(slot)
+            for e in range(h):
+                k = g * 2 * h + e
+                bfs.append((X(k), X(k + h), w, sg))
+        for i in range(0, len(bfs), 2):
+            if pair_hook:
+                pair_hook(u, i)
+            a = butterfly_steps(bfs[i][0], bfs[i][1], bfs[i][2], T0, bfs[i][3])
+            b = butterfly_steps(bfs[i + 1][0], bfs[i + 1][1], bfs[i + 1][2], T1, bfs[i + 1][3])
+            for ins in interleave(a, b):
+                emit(ins)
+
+
+def csub_all(const_name):
+    """x[k] = csub(x[k], bound) for all 16, bound given as the SGPR pair holding -bound"""
+    for k in range(0, 16, 2):
+        for kk, t in ((k, T0), (k + 1, T1)):
+            emit("v_lshl_add_u64 %s, %s, 0, %%[%s]" % (pair(t.T), pair(X(kk)), const_name))
+        for kk, t in ((k, T0), (k + 1, T1)):
+            emit("v_ashrrev_i32 v%d, 31, v%d" % (t.M, t.T + 1))
+        for kk, t in ((k, T0), (k + 1, T1)):
+            emit("v_bfi_b32 v%d, v%d, v%d, v%d" % (X(kk), t.M, X(kk), t.T))
+            emit("v_bfi_b32 v%d, v%d, v%d, v%d" % (X(kk) + 1, t.M, X(kk) + 1, t.T + 1))
+
+
+def gen():
+    A0, A1, A2, A3 = ADDR, ADDR + 1, ADDR + 2, ADDR + 3
+    emit("; ---- prologue: zero halves of the zero-extended pairs, addresses")
+    for t in (T0, T1):
+        emit("v_mov_b32 v%d, 0" % (t.H + 1))
+        emit("v_mov_b32 v%d, 0" % (t.G + 1))
+    # round A twiddles: 15 uniform Shoup pairs -> s[36:95]
+    for slot in range(15):
+        emit("s_load_dwordx4 s[%d:%d], %%[tw], %d" % (36 + 4 * slot, 39 + 4 * slot, 16 * slot))
+    # data loads: x[k] = in[tid + 256k]; byte offset tid*8 + 2048k; 4 offset registers cover imm -4096..2048
+    emit("v_lshlrev_b32 v%d, 3, %%[tid]" % A0)
+    for j in range(4):
+        emit("v_add_u32 v%d, %d, v%d" % (SCR + j, 8192 * j + 4096, A0))
+    for kk in range(16):
+        k = (kk >> 1) + 8 * (kk & 1)
+        j, rem = divmod(k, 4)
+        emit("global_load_dwordx2 %s, v%d, %%[pin] offset:%d" % (pair(X(k)), SCR + j, rem * 2048 - 4096))
+    # round B twiddles: tw[16 + slot*16 + hi4] -> byte (16+16*slot)*16 + hi4*16
+    emit("v_lshrrev_b32 v%d, 4, %%[tid]" % A1)                # hi4
+    emit("v_lshlrev_b32 v%d, 4, v%d" % (A2, A1))              # hi4*16 bytes
+    for slot in range(15):
+        emit("global_load_dwordx4 v[%d:%d], v%d, %%[tw] offset:%d" % (TW0 + 4 * slot, TW0 + 4 * slot + 3, A2, 256 + 256 * slot))
+    # LDS addresses
+    #   A: 8*(tid + (tid>>4))          + 2176*k
+    #   B: 8*(272*hi4 + lo4)           + 136*k
+    #   C: 136*tid                     + 8*k
+    emit("v_add_u32 v%d, %%[tid], v%d" % (A3, A1))
+    emit("v_lshlrev_b32 v%d, 3, v%d" % (A3, A3))              # addrA
+    emit("v_add_u32 v%d, %%[lds], v%d" % (A3, A3))
+    emit("s_waitcnt lgkmcnt(0)")                              # round A twiddles (scalar loads)
+    emit("; ---- round A (twiddles in SGPRs)")
+
+    def a_pair_hook(u, i):
+        # stage 0, butterflies i and i+1 consume data loads 0 .. 2*i+3 of the 31 issued (16 data then 15 twiddle quads)
+        if u == 0:
+            emit("s_waitcnt vmcnt(%d)" % (31 - (2 * i + 4)))
+    round16(lambda slot: (None, ("s%d" % (36 + 4 * slot), "s%d" % (37 + 4 * slot), "s%d" % (38 + 4 * slot), "s%d" % (39 + 4 * slot))),
+            pair_hook=a_pair_hook)
+    for k in range(16):
+        emit("ds_write_b64 v%d, %s offset:%d" % (A3, pair(X(k)), 2176 * k))
+    # addrB
+    emit("v_and_b32 v%d, 15, %%[tid]" % A0)                   # lo4
+    emit("v_mul_u32_u24 v%d, 272, v%d" % (A1, A1))            # 272*hi4
+    emit("v_add_u32 v%d, v%d, v%d" % (A0, A0, A1))
+    emit("v_lshlrev_b32 v%d, 3, v%d" % (A0, A0))              # addrB
+    emit("v_add_u32 v%d, %%[lds], v%d" % (A0, A0))
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("s_barrier")
+    for k in range(16):
+        emit("ds_read_b64 %s, v%d offset:%d" % (pair(X(k)), A0, 136 * k))
+    emit("s_waitcnt vmcnt(0)")                                # round B twiddles
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("; ---- round B")
+    round16(lambda slot: (TW0 + 4 * slot, None))
+    # round C twiddles into the same registers: tw[256 + slot*256 + tid], 16 B each
+    emit("v_lshlrev_b32 v%d, 4, %%[tid]" % A2)
+    for slot in range(15):
+        emit("s_add_u32 vcc_lo, %%[twlo], %d" % ((256 + 256 * slot) * 16))
+        emit("s_addc_u32 vcc_hi, %[twhi], 0")
+        emit("global_load_dwordx4 v[%d:%d], v%d, vcc" % (TW0 + 4 * slot, TW0 + 4 * slot + 3, A2))
+    for k in range(16):
+        emit("ds_write_b64 v%d, %s offset:%d" % (A0, pair(X(k)), 136 * k))
+    emit("v_mul_u32_u24 v%d, 136, %%[tid]" % A1)              # addrC
+    emit("v_add_u32 v%d, %%[lds], v%d" % (A1, A1))
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("s_barrier")
+    for k in range(16):
+        emit("ds_read_b64 %s, v%d offset:%d" % (pair(X(k)), A1, 8 * k))
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("; ---- round C (twiddle quads arrive in slot order; stage u needs slots < 2^(u+1) - 1)")
+    round16(lambda slot: (TW0 + 4 * slot, None), stage_hook=lambda u: emit("s_waitcnt vmcnt(%d)" % (15 - ((2 << u) - 1))))
+    emit("; ---- canonical reduction: x < 8q -> [0,q)")
+    csub_all("nq4")
+    csub_all("nq2")
+    csub_all("nq")
+    for k in range(16):
+        emit("ds_write_b64 v%d, %s offset:%d" % (A1, pair(X(k)), 8 * k))
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("s_barrier")
+    for k in range(16):
+        emit("ds_read_b64 %s, v%d offset:%d" % (pair(X(k)), A3, 2176 * k))
+    emit("v_lshlrev_b32 v%d, 3, %%[tid]" % A0)
+    for j in range(4):
+        emit("v_add_u32 v%d, %d, v%d" % (SCR + j, 8192 * j + 4096, A0))
+    for k in range(16):
+        j, rem = divmod(k, 4)
+        emit("s_waitcnt lgkmcnt(%d)" % (15 - k))
+        emit("global_store_dwordx2 v%d, %s, %%[pout] offset:%d" % (SCR + j, pair(X(k)), rem * 2048 - 4096))
+    emit("s_waitcnt vmcnt(0)")
+
+
+gen()
+body = "\n".join('  "%s\\n\\t"' % l for l in out)
+clob_v = ", ".join('"v%d"' % i for i in range(NVGPR_USED))
+clob_s = ", ".join('"s%d"' % i for i in range(36, 102))
+text = '''// GENERATED by tools/gen_tile_asm.py -- do not edit.  %d instructions.
+#define NTT_TILE_ASM_BODY \\
+%s
+#define NTT_TILE_ASM_CLOBBERS %s, %s, "vcc", "memory"
+''' % (len(out), body.replace("\n", " \\\n"), clob_v, clob_s)
+path = sys.argv[1] if len(sys.argv) > 1 else "ntt_tile_asm.inc"
+open(path, "w").write(text)
+valu = sum(1 for l in out if l.startswith("v_"))
+print("wrote", path, "instructions:", len(out), "VALU:", valu)
