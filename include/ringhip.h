@@ -98,6 +98,16 @@ int rh_ring_set_tuning(rh_ring* r, const char* key, long value);
 int rh_ring_vec_op(rh_ring* r, int opcode, const uint64_t* p1_dev, const uint64_t* p2_dev, uint64_t* p3_dev, int npoly,
                    int level, const uint64_t* s0_host, const uint64_t* s1_host);
 
+/* ---- RNS rescale (ring/scaling.go): divide by the last modulus, `nb` times.  round = 0: floored, 1: rounded.
+ * p0: npoly polys of level+1 limbs; p1: npoly polys of p1_rows >= level+1-nb limbs (limbs 0..level-nb are written).
+ *   rh_ring_div_by_last_modulus_many      coefficient domain: DivFloorByLastModulus(:21-28) / DivRoundByLastModulus
+ *                                          (:112-126) and their Many forms (:56-88, :160-192); p0 is modified in
+ *                                          place exactly as the reference modifies its input / buffer
+ *   rh_ring_div_by_last_modulus_many_ntt  NTT domain: DivFloorByLastModulusManyNTT(:32-52), DivRoundByLastModulusNTT
+ *                                          (:92-108), DivRoundByLastModulusManyNTT(:130-156); p0 is not modified   */
+int rh_ring_div_by_last_modulus_many(rh_ring* r, int round, int level, int nb, uint64_t* p0_dev, uint64_t* p1_dev, int p1_rows, int npoly);
+int rh_ring_div_by_last_modulus_many_ntt(rh_ring* r, int round, int level, int nb, const uint64_t* p0_dev, uint64_t* p1_dev, int p1_rows, int npoly);
+
 /* ---- RNS basis extension (ring/basis_extension.go).  A basis extender pairs a Q ring and a P ring
  * (NewBasisExtender :52-79).  All polys device-resident, limbs 0..levelQ / 0..levelP, npoly polys.  Asynchronous. */
 typedef struct rh_bext rh_bext;

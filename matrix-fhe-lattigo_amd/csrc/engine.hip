@@ -185,6 +185,8 @@ extern "C" void rh_ring_destroy(rh_ring* r) {
   (void)hipSetDevice(r->device);
   void* ptrs[] = {r->d_consts, r->d_tw_fwd, r->d_tw_inv, r->d_tw_fwd_mont, r->d_twk_fwd, r->d_twk_inv, r->d_twk_fwd_mont, r->d_lastw, r->d_scratch, r->d_rowcnt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  rh_rescale_teardown(r);
+  for (int i = 0; i < 2; ++i) if (r->d_rs[i]) (void)hipFree(r->d_rs[i]);
   rh_ring3n_teardown(r);
   delete r;
 }

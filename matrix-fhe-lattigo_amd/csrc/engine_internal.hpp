@@ -29,6 +29,8 @@ struct rh_ring {
   tw2* d_lastw = nullptr;         // psi_bwd[1] * N^-1 per limb
   u64* d_scratch = nullptr;       // 2N words for the host-pointer single-limb path
   rh_ring3n_state* s3n = nullptr;
+  std::vector<void*> rescale_tables;      // per level, rescale.hip
+  u64* d_rs[2] = {nullptr, nullptr}; size_t rs_words[2] = {0, 0};
   bool persistent = false;        // single-launch pipelined forward transform (ntt_fwd_persistent)
   int group_polys = 8;            // polys per pipeline group of the persistent kernel
   int persist_unsafe = 0;         // timing experiments only: plain stores and no acquire in the hand-off
@@ -45,6 +47,7 @@ int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3,
 int rh_std_upload_tables(rh_ring* r, const std::vector<tw2>& fs, const std::vector<tw2>& is, const std::vector<u64>* mont,
                          const std::vector<tw2>& lastw);
 int rh_upload_consts(rh_ring* r, const std::vector<LimbConsts>& hc);
+void rh_rescale_teardown(rh_ring* r);
 // 3N-cyclotomic transform (ntt3n.hip)
 int rh_ring3n_setup(rh_ring* r, std::vector<LimbConsts>& hc);
 void rh_ring3n_teardown(rh_ring* r);

@@ -150,6 +150,119 @@ ntt3n_perm_inv(const u64* in, u64* out, int N, int nb, int log_n2, const int* __
   }
 }
 
+// ---- b = 1 fast path: split + the single radix-3 layer fused, 6 coefficients {i + k*N/6} per thread (one pass) -------
+__global__ void __launch_bounds__(256)
+ntt3n_pre_b1_fwd(const u64* in, u64* out, int N, const tw2* __restrict__ r3, int r3_stride,
+                 const Limb3N* __restrict__ l3, const LimbConsts* __restrict__ consts, int L) {
+  const u32 row = blockIdx.x, limb = row % (u32)L;
+  const LimbConsts c = consts[limb]; const Limb3N k = l3[limb];
+  const tw2* t = r3 + (size_t)limb * r3_stride;           // layer 1: blocks 0,1 -> (z1,z2) pairs
+  const u64 q4 = 4 * c.q;
+  const size_t base = (size_t)row * N;
+  const int s = N / 6;
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < s; i += gridDim.y * blockDim.x) {
+    u64 x[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) x[j] = csub(in[base + i + (size_t)j * s], q4);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {                          // split: pairs (j, j+3) are N/2 apart
+      const u64 tt = shoup_mul(x[j + 3], k.zeta.w, k.zeta.wp, c.nq);
+      const u64 lo = add4(x[j], tt, q4), hi = sub4(add4(x[j], x[j + 3], q4), tt, q4);
+      x[j] = lo; x[j + 3] = hi;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                          // radix-3 on each half
+      const tw2 z1 = t[2 * h], z2 = t[2 * h + 1];
+      const u64 b0 = x[3 * h], b1 = x[3 * h + 1], b2 = x[3 * h + 2];
+      const u64 t1 = shoup_mul(b1, z1.w, z1.wp, c.nq), t2 = shoup_mul(b2, z2.w, z2.wp, c.nq);
+      const u64 t3 = shoup_mul(t1 + q4 - t2, k.w3.w, k.w3.wp, c.nq);
+      x[3 * h] = add4(add4(b0, t1, q4), t2, q4);
+      x[3 * h + 1] = add4(sub4(b0, t2, q4), t3, q4);
+      x[3 * h + 2] = sub4(sub4(b0, t1, q4), t3, q4);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) out[base + i + (size_t)j * s] = x[j];
+  }
+}
+__global__ void __launch_bounds__(256)
+ntt3n_post_b1_inv(const u64* in, u64* out, int N, const tw2* __restrict__ r3, int r3_stride,
+                  const Limb3N* __restrict__ l3, const LimbConsts* __restrict__ consts, int L) {
+  const u32 row = blockIdx.x, limb = row % (u32)L;
+  const LimbConsts c = consts[limb]; const Limb3N k = l3[limb];
+  const tw2* t = r3 + (size_t)limb * r3_stride;
+  const u64 q4 = 4 * c.q;
+  const size_t base = (size_t)row * N;
+  const int s = N / 6;
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < s; i += gridDim.y * blockDim.x) {
+    u64 x[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) x[j] = in[base + i + (size_t)j * s];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const tw2 z1 = t[2 * h], z2 = t[2 * h + 1];
+      const u64 B0 = x[3 * h], B1 = x[3 * h + 1], B2 = x[3 * h + 2];
+      const u64 tt = shoup_mul(B1 + q4 - B2, k.w3.w, k.w3.wp, c.nq);
+      const u64 s1 = sub4(sub4(B0, B1, q4), tt, q4), s2 = add4(sub4(B0, B2, q4), tt, q4);
+      x[3 * h] = add4(add4(B0, B1, q4), B2, q4);
+      x[3 * h + 1] = shoup_mul(s1, z1.w, z1.wp, c.nq);
+      x[3 * h + 2] = shoup_mul(s2, z2.w, z2.wp, c.nq);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const u64 lo = x[j], hi = x[j + 3];
+      const u64 d = hi + q4 - lo;
+      const u64 b1 = shoup_mul(d, k.inv_b1.w, k.inv_b1.wp, c.nq);
+      const u64 zb1 = shoup_mul(d, k.inv_b0z.w, k.inv_b0z.wp, c.nq);
+      const u64 los = shoup_mul(lo, k.inv_s.w, k.inv_s.wp, c.nq);
+      x[j] = canon8(los + q4 - zb1, c.q); x[j + 3] = canon4(b1, c.q);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) out[base + i + (size_t)j * s] = x[j];
+  }
+}
+
+// ---- tiled permutation (log_n2 >= 10): a tile is {j_low: 32} x {j_high: 32} x {nb blocks} for one j_mid.
+// Reads are 256 B runs (32 consecutive j), writes are nb*256 B runs (32 consecutive bitrev(j) x nb ranks).
+#define PT 5
+template <bool FWD>
+__global__ void __launch_bounds__(256)
+ntt3n_perm_tiled(const u64* in, u64* out, int N, int nb, int log_n2, const int* __restrict__ rank_of_block) {
+  extern __shared__ u64 tile[];                           // [32 j_low][32*nb + 1]
+  const int m = log_n2, midbits = m - 2 * PT;
+  const u32 jmid = blockIdx.y;                            // 0 .. 2^midbits - 1
+  const size_t base = (size_t)blockIdx.x * N;
+  const int rowlen = 32 * nb + 1;
+  const u32 jbmid = midbits ? (__brev(jmid) >> (32 - midbits)) : 0u;
+  // global "block order" side: element (c, jhigh, jlow) at c*n2 + (jhigh << (m-PT)) | (jmid << PT) | jlow
+  // global "rank order" side:  element at nb * ((brev5(jlow) << (m-PT)) | (jbmid << PT) | brev5(jhigh)) + rank[c]
+  const int nseg = nb * 32;                               // (c, jhigh) pairs
+  if (FWD) {
+    for (int e = threadIdx.x; e < nseg * 32; e += 256) {
+      const int seg = e >> 5, jl = e & 31, c = seg >> 5, jh = seg & 31;
+      const u64 v = in[base + ((size_t)c << m) + ((size_t)jh << (m - PT)) + ((size_t)jmid << PT) + jl];
+      tile[jl * rowlen + (int)(__brev((u32)jh) >> 27) * nb + rank_of_block[c]] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * nseg; e += 256) {
+      const int jl = e / nseg, w = e - jl * nseg;
+      const size_t jbhi = (size_t)(__brev((u32)jl) >> 27);
+      out[base + (size_t)nb * ((jbhi << (m - PT)) + ((size_t)jbmid << PT)) + w] = tile[jl * rowlen + w];
+    }
+  } else {
+    for (int e = threadIdx.x; e < 32 * nseg; e += 256) {
+      const int jl = e / nseg, w = e - jl * nseg;
+      const size_t jbhi = (size_t)(__brev((u32)jl) >> 27);
+      tile[jl * rowlen + w] = in[base + (size_t)nb * ((jbhi << (m - PT)) + ((size_t)jbmid << PT)) + w];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nseg * 32; e += 256) {
+      const int seg = e >> 5, jl = e & 31, c = seg >> 5, jh = seg & 31;
+      out[base + ((size_t)c << m) + ((size_t)jh << (m - PT)) + ((size_t)jmid << PT) + jl] =
+          tile[jl * rowlen + (int)(__brev((u32)jh) >> 27) * nb + rank_of_block[c]];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host: twiddle tree and tables
 // ---------------------------------------------------------------------------------------------------------------
@@ -295,25 +408,38 @@ int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
   auto chunks = [](int work) { int g = (work + 255) / 256; return g < 1 ? 1 : (g > 64 ? 64 : g); };
   u64* tmp = s->d_tmp;
   if (s->sub) s->sub->stream = st;
+  const bool tiled = s->log_n2 >= 2 * PT && nb <= 6;     // LDS: 32*(32*nb+1)*8 bytes = 48 KiB at nb = 6
+  const size_t perm_lds = (size_t)32 * (32 * nb + 1) * 8;
+  const dim3 pgrid(rows, 1u << (s->log_n2 >= 2 * PT ? s->log_n2 - 2 * PT : 0));
   if (!inverse) {
-    ntt3n_split_fwd<<<dim3(rows, chunks(N / 2)), 256, 0, st>>>(in, tmp, N, l3, c, Lrows);
-    int step = N / 6, cnt = 2;
-    for (int l = 1; l <= s->b; ++l, cnt *= 3, step /= 3)
-      ntt3n_radix3_fwd<<<dim3(rows, chunks(cnt * step)), 256, 0, st>>>(tmp, N, step, cnt, r3f + s->r3_off[l], s->r3_stride, l3, c, Lrows);
+    if (s->b == 1) {
+      ntt3n_pre_b1_fwd<<<dim3(rows, chunks(N / 6)), 256, 0, st>>>(in, tmp, N, r3f + s->r3_off[1], s->r3_stride, l3, c, Lrows);
+    } else {
+      ntt3n_split_fwd<<<dim3(rows, chunks(N / 2)), 256, 0, st>>>(in, tmp, N, l3, c, Lrows);
+      int step = N / 6, cnt = 2;
+      for (int l = 1; l <= s->b; ++l, cnt *= 3, step /= 3)
+        ntt3n_radix3_fwd<<<dim3(rows, chunks(cnt * step)), 256, 0, st>>>(tmp, N, step, cnt, r3f + s->r3_off[l], s->r3_stride, l3, c, Lrows);
+    }
     if (s->sub) {
       // (poly, limb, block) rows of length n2: limb-major virtual limb index = limb*nb + c
       if (int rc = rh_std_ntt_launch(s->sub, tmp, tmp, npoly, Lrows * nb, limb0 * nb, false, false, 0)) return rc;
     }
-    ntt3n_perm_fwd<<<dim3(rows, chunks(N)), 256, 0, st>>>(tmp, out, N, nb, s->log_n2, s->d_block_of_rank, c, Lrows, s->sub ? 0 : 1);
+    if (tiled) ntt3n_perm_tiled<true><<<pgrid, 256, perm_lds, st>>>(tmp, out, N, nb, s->log_n2, s->d_rank);
+    else ntt3n_perm_fwd<<<dim3(rows, chunks(N)), 256, 0, st>>>(tmp, out, N, nb, s->log_n2, s->d_block_of_rank, c, Lrows, s->sub ? 0 : 1);
   } else {
-    ntt3n_perm_inv<<<dim3(rows, chunks(N)), 256, 0, st>>>(in, tmp, N, nb, s->log_n2, s->d_block_of_rank);
+    if (tiled) ntt3n_perm_tiled<false><<<pgrid, 256, perm_lds, st>>>(in, tmp, N, nb, s->log_n2, s->d_rank);
+    else ntt3n_perm_inv<<<dim3(rows, chunks(N)), 256, 0, st>>>(in, tmp, N, nb, s->log_n2, s->d_block_of_rank);
     if (s->sub) {
       if (int rc = rh_std_ntt_launch(s->sub, tmp, tmp, npoly, Lrows * nb, limb0 * nb, true, false, 0)) return rc;
     }
-    int cnt = nb / 3, step = s->n2;
-    for (int l = s->b; l >= 1; --l, cnt /= 3, step *= 3)
-      ntt3n_radix3_inv<<<dim3(rows, chunks(cnt * step)), 256, 0, st>>>(tmp, N, step, cnt, r3i + s->r3_off[l], s->r3_stride, l3, c, Lrows);
-    ntt3n_split_inv<<<dim3(rows, chunks(N / 2)), 256, 0, st>>>(tmp, out, N, l3, c, Lrows);
+    if (s->b == 1) {
+      ntt3n_post_b1_inv<<<dim3(rows, chunks(N / 6)), 256, 0, st>>>(tmp, out, N, r3i + s->r3_off[1], s->r3_stride, l3, c, Lrows);
+    } else {
+      int cnt = nb / 3, step = s->n2;
+      for (int l = s->b; l >= 1; --l, cnt /= 3, step *= 3)
+        ntt3n_radix3_inv<<<dim3(rows, chunks(cnt * step)), 256, 0, st>>>(tmp, N, step, cnt, r3i + s->r3_off[l], s->r3_stride, l3, c, Lrows);
+      ntt3n_split_inv<<<dim3(rows, chunks(N / 2)), 256, 0, st>>>(tmp, out, N, l3, c, Lrows);
+    }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "3N transform launch failed: %s", hipGetErrorString(e));

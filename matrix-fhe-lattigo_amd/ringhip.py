@@ -62,6 +62,8 @@ def lib():
         "rh_ring_ntt_phase": (i, [vp, vp, vp, i, i, i, i]),
         "rh_ring_set_tuning": (i, [vp, C.c_char_p, C.c_long]),
         "rh_ring_vec_op": (i, [vp, i, vp, vp, vp, i, i, U64P, U64P]),
+        "rh_ring_div_by_last_modulus_many": (i, [vp, i, i, i, vp, vp, i, i]),
+        "rh_ring_div_by_last_modulus_many_ntt": (i, [vp, i, i, i, vp, vp, i, i]),
         "rh_bext_create": (i, [C.POINTER(vp), vp, vp]), "rh_bext_destroy": (None, [vp]),
         "rh_bext_modup_q_to_p": (i, [vp, i, i, vp, vp, i]), "rh_bext_modup_p_to_q": (i, [vp, i, i, vp, vp, i]),
         "rh_bext_moddown_qp_to_q": (i, [vp, i, i, vp, vp, vp, i]),
@@ -257,6 +259,25 @@ class Ring:
 
     def INTTLazy(self, p1, p2):
         self._chk(p1, p2); _check(lib().rh_ring_intt(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 1))
+
+    # ---- rescale (ring/scaling.go).  Output poly may have level+1 or fewer limbs, like the reference -----------
+    def DivFloorByLastModulusMany(self, nbRescales, p0, p1):
+        _check(lib().rh_ring_div_by_last_modulus_many(self._h, 0, self.level, nbRescales, p0.ptr, p1.ptr, p1.limbs, p0.npoly))
+
+    def DivRoundByLastModulusMany(self, nbRescales, p0, p1):
+        _check(lib().rh_ring_div_by_last_modulus_many(self._h, 1, self.level, nbRescales, p0.ptr, p1.ptr, p1.limbs, p0.npoly))
+
+    def DivFloorByLastModulus(self, p0, p1): self.DivFloorByLastModulusMany(1, p0, p1)
+    def DivRoundByLastModulus(self, p0, p1): self.DivRoundByLastModulusMany(1, p0, p1)
+
+    def DivFloorByLastModulusManyNTT(self, nbRescales, p0, p1):
+        _check(lib().rh_ring_div_by_last_modulus_many_ntt(self._h, 0, self.level, nbRescales, p0.ptr, p1.ptr, p1.limbs, p0.npoly))
+
+    def DivRoundByLastModulusManyNTT(self, nbRescales, p0, p1):
+        _check(lib().rh_ring_div_by_last_modulus_many_ntt(self._h, 1, self.level, nbRescales, p0.ptr, p1.ptr, p1.limbs, p0.npoly))
+
+    def DivFloorByLastModulusNTT(self, p0, p1): self.DivFloorByLastModulusManyNTT(1, p0, p1)
+    def DivRoundByLastModulusNTT(self, p0, p1): self.DivRoundByLastModulusManyNTT(1, p0, p1)
 
     # ---- element-wise (ring/operations.go -> ring/vec_ops.go) --------------------------------------------------
     def vec_op(self, op, p1, p2, p3, s0=None, s1=None):

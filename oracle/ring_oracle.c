@@ -552,6 +552,30 @@ void orc_decompose_and_split(int levelQ, int levelP, int nbPi, int digit, const 
   free(tgt); orc_free_modup_constants(c);
 }
 
+/* ------------------------------------------------------------------ RNS rescale (ring/scaling.go) */
+
+/* DivFloorByLastModulus :21-28 (round = 0) / DivRoundByLastModulus :112-126 (round = 1), coefficient domain, one step at
+ * `level`.  p0: level+1 limb pointers (modified in place in round mode exactly like the reference), p1: level limbs. */
+void orc_div_by_last_modulus(int round, uint64_t* const* p0, uint64_t* const* p1, size_t n, const uint64_t* Q, int level) {
+  u64 qL = Q[level];
+  u64 pHalf = (qL - 1) >> 1;
+  if (round) for (size_t k = 0; k < n; k++) p0[level][k] = orc_cred(p0[level][k] + pHalf, qL);          /* :120 */
+  for (int i = 0; i < level; i++) {
+    u64 qi = Q[i], qinv = orc_gen_mred_constant(qi);
+    u64 brc[2]; orc_gen_bred_constant(qi, brc);
+    u64 c = orc_mform(qi - orc_modexp(qL, qi - 2, qi), qi, brc);                                        /* ring/ring.go:363-380 */
+    if (round) {
+      u64 s = qi - orc_bred_add(pHalf, qi, brc);
+      for (size_t k = 0; k < n; k++) {
+        p0[i][k] = s + 2 * qi - p0[i][k];                                                                /* :123 */
+        p1[i][k] = orc_mred(p0[level][k] + p0[i][k], c, qi, qinv);                                       /* :124 */
+      }
+    } else {
+      for (size_t k = 0; k < n; k++) p1[i][k] = orc_mred(2 * qi - p0[i][k] + p0[level][k], c, qi, qinv); /* :26 */
+    }
+  }
+}
+
 /* ------------------------------------------------------------------ 3N-cyclotomic transform (ring/ntt_3n.go) */
 
 static int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a < 0 ? -a : a; }

@@ -96,6 +96,9 @@ void orc_decompose_and_split(int levelQ, int levelP, int nbPi, int digit, const 
                              uint64_t* const* p1q, uint64_t* const* p1p, size_t n,
                              const uint64_t* Qall, int nQall, const uint64_t* Pall, int nPall);
 
+/* ---- RNS rescale: ring/scaling.go:21-28 (floor) / :112-126 (round); one step at `level`, coefficient domain ---- */
+void orc_div_by_last_modulus(int round, uint64_t* const* p0, uint64_t* const* p1, size_t n, const uint64_t* Q, int level);
+
 /* ---- 3N-cyclotomic transform: ring/ntt_3n.go ---- */
 /* ascending totatives of 3N :235-243; returns count written (= N) */
 int  orc_ntt3n_exponents(int threeN, int* out);

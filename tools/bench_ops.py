@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the headline metric): inverse NTT, element-wise kernels, basis extension and the 3N
+transform at the BASELINE config sizes, each against its algorithmic bytes.  Prints one JSON object."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import matrix_fhe_lattigo_amd as rh
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import QI60, PI60
+
+dev = torch.device("cuda", 0)
+stream = torch.cuda.current_stream()
+PEAK = 8000.0
+
+
+def timed(fn, reps=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def rand_block(B, mods, N):
+    qs = torch.tensor(mods, dtype=torch.int64, device=dev).view(1, len(mods), 1)
+    return torch.randint(0, 1 << 62, (B, len(mods), N), dtype=torch.int64, device=dev) % qs
+
+
+def entry(name, ms, alg_bytes, units, unit_name):
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    return {"op": name, "ms": round(ms, 4), unit_name + "_per_s": units / (ms * 1e-3), "algorithmic_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / PEAK, 3)}
+
+
+res = []
+# ---- N = 2^16, 16 limbs, batch 512 (4 GiB) ----
+N, L, B = 1 << 16, 16, 512
+ring = rh.Ring(N, QI60[:L]); ring.set_stream(stream.cuda_stream)
+a, b, c = rand_block(B, QI60[:L], N), rand_block(B, QI60[:L], N), rand_block(B, QI60[:L], N)
+pa, pb, pc = (rh.DevicePoly.from_torch(ring, t) for t in (a, b, c))
+res.append(entry("Ring.NTT N=2^16 L=16", timed(lambda: ring.NTT(pa, pa)), 16.0 * N * L * B, B, "poly"))
+res.append(entry("Ring.INTT N=2^16 L=16", timed(lambda: ring.INTT(pa, pa)), 16.0 * N * L * B, B, "poly"))
+res.append(entry("Ring.NTTLazy (exact reference representatives) N=2^16 L=16", timed(lambda: ring.NTTLazy(pa, pc)), 16.0 * N * L * B, B, "poly"))
+for op, nops in (("ADD", 3), ("MUL_MONT", 3), ("MUL_MONT_THEN_ADD", 4), ("MFORM", 2), ("MUL_BARRETT", 3), ("REDUCE", 2), ("MUL_MONT_LAZY_THEN_ADD_LAZY", 4)):
+    res.append(entry("vec " + op + " N=2^16 L=16", timed(lambda: ring.vec_op(op, pa, pb, pc)), 8.0 * nops * N * L * B, B, "poly"))
+del pa, pb, pc, a, b, c
+ring.close(); torch.cuda.empty_cache()
+
+# ---- config 3: N = 2^15, 16 limbs: c = INTT(NTT(a) * NTT(b)) as schemes/ckks/evaluator.go:821-834 sequences it ----
+N, L, B = 1 << 15, 16, 512
+ring = rh.Ring(N, QI60[:L]); ring.set_stream(stream.cuda_stream)
+a, b = rand_block(B, QI60[:L], N), rand_block(B, QI60[:L], N)
+pa, pb = rh.DevicePoly.from_torch(ring, a), rh.DevicePoly.from_torch(ring, b)
+def polymul():
+    ring.NTT(pa, pa); ring.NTT(pb, pb); ring.MForm(pa, pa); ring.MulCoeffsMontgomery(pa, pb, pa); ring.INTT(pa, pa)
+ms = timed(polymul, reps=5)
+e = entry("config3 poly-mul N=2^15 L=16 (NTT,NTT,MForm,MulCoeffsMontgomery,INTT)", ms, 88.0 * N * L * B, B, "polymul")
+e["frac_vs_fused_lower_bound_24NL"] = round(24.0 * N * L * B / (ms * 1e-3) / 1e9 / PEAK, 3)
+res.append(e)
+del pa, pb, a, b
+ring.close(); torch.cuda.empty_cache()
+
+# ---- config 5 shapes: N = 2^16, Q = Qi60[0:24], P = Pi60[0:6]: DecomposeAndSplit digit, ModDownQPtoQNTT ----
+N, B = 1 << 16, 64
+rq, rp = rh.Ring(N, QI60[:24]), rh.Ring(N, PI60[:6]); rq.set_stream(stream.cuda_stream); rp.set_stream(stream.cuda_stream)
+be = rh.BasisExtender(rq, rp)
+xq, xp = rand_block(B, QI60[:24], N), rand_block(B, PI60[:6], N)
+oq, op_ = torch.zeros_like(xq), torch.zeros_like(xp)
+pq, pp, poq, pop = rh.DevicePoly.from_torch(rq, xq), rh.DevicePoly.from_torch(rp, xp), rh.DevicePoly.from_torch(rq, oq), rh.DevicePoly.from_torch(rp, op_)
+res.append(entry("DecomposeAndSplit N=2^16 alpha=6 -> 18 Q + 6 P limbs", timed(lambda: be.DecomposeAndSplit(23, 5, 6, 1, pq, poq, pop), reps=5), 8.0 * N * (6 + 24) * B, B, "poly"))
+res.append(entry("ModUpPtoQ N=2^16 6 -> 24 limbs", timed(lambda: be.ModUpPtoQ(5, 23, pp, poq), reps=5), 8.0 * N * (6 + 24) * B, B, "poly"))
+res.append(entry("ModDownQPtoQ N=2^16 (24+6) -> 24 limbs", timed(lambda: be.ModDownQPtoQ(23, 5, pq, pp, poq), reps=5), 8.0 * N * (6 + 24 + 24) * B, B, "poly"))
+res.append(entry("ModDownQPtoQNTT N=2^16 (24+6) -> 24 limbs", timed(lambda: be.ModDownQPtoQNTT(23, 5, pq, pp, poq), reps=5), 8.0 * N * (6 + 24 + 24) * B + 16.0 * N * 30 * B, B, "poly"))
+del pq, pp, poq, pop, xq, xp, oq, op_
+be.close(); rq.close(); rp.close(); torch.cuda.empty_cache()
+
+# ---- config 2 / 4 rings: 3N transform ----
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_oracle_ntt3n import find_prime_3n
+for N, L, B in ((3 << 13, 1, 1024), (3 << 16, 24, 16)):
+    mods = []
+    import oracle
+    q = find_prime_3n(N, 60)
+    while len(mods) < L:
+        if oracle.lib().orc_is_prime(q):
+            mods.append(q)
+        q += 3 * N
+    ring = rh.Ring(N, mods, kind=rh.Matrix3N); ring.set_stream(stream.cuda_stream)
+    x = rand_block(B, mods, N)
+    px = rh.DevicePoly.from_torch(ring, x)
+    res.append(entry("3N NTT N=%d L=%d" % (N, L), timed(lambda: ring.NTT(px, px), reps=5), 16.0 * N * L * B, B, "poly"))
+    res.append(entry("3N INTT N=%d L=%d" % (N, L), timed(lambda: ring.INTT(px, px), reps=5), 16.0 * N * L * B, B, "poly"))
+    del px, x
+    ring.close(); torch.cuda.empty_cache()
+print(json.dumps({"device": torch.cuda.get_device_name(0), "results": res}, indent=1))
