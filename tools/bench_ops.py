@@ -49,7 +49,11 @@ res.append(entry("Ring.INTT N=2^16 L=16", timed(lambda: ring.INTT(pa, pa)), 16.0
 res.append(entry("Ring.NTTLazy (exact reference representatives) N=2^16 L=16", timed(lambda: ring.NTTLazy(pa, pc)), 16.0 * N * L * B, B, "poly"))
 for op, nops in (("ADD", 3), ("MUL_MONT", 3), ("MUL_MONT_THEN_ADD", 4), ("MFORM", 2), ("MUL_BARRETT", 3), ("REDUCE", 2), ("MUL_MONT_LAZY_THEN_ADD_LAZY", 4)):
     res.append(entry("vec " + op + " N=2^16 L=16", timed(lambda: ring.vec_op(op, pa, pb, pc)), 8.0 * nops * N * L * B, B, "poly"))
-del pa, pb, pc, a, b, c
+# rescale (ring/scaling.go): NTT-domain rounded division by the last modulus, 16 -> 15 limbs
+po = rh.DevicePoly.from_torch(ring, torch.empty((B, L - 1, N), dtype=torch.int64, device=dev))
+res.append(entry("DivRoundByLastModulusNTT N=2^16 L=16->15 (1 INTT + 15 NTT + 2 elementwise passes)",
+                 timed(lambda: ring.DivRoundByLastModulusNTT(pa, po), reps=5), 8.0 * N * (2 * (L - 1) + 1) * B + 16.0 * N * L * B, B, "poly"))
+del pa, pb, pc, a, b, c, po
 ring.close(); torch.cuda.empty_cache()
 
 # ---- config 3: N = 2^15, 16 limbs: c = INTT(NTT(a) * NTT(b)) as schemes/ckks/evaluator.go:821-834 sequences it ----
