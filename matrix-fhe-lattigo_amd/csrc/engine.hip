@@ -308,7 +308,10 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
       else      ntt_fwd_tile<ShoupPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, 1, npoly);
     }
   } else {
-    if (phase != 1) ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, (S1 == 0 && r->inv_scale) ? 1 : 0, npoly);
+    if (phase != 1) {
+      if (r->asm_tile && S1 > 0) ntt_inv_tile_asm<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly);
+      else ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, (S1 == 0 && r->inv_scale) ? 1 : 0, npoly);
+    }
     if (S1 > 0 && phase != 2) launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, logN, r->inv_scale ? 1 : 0);
   }
   return check_launch("ntt");
@@ -377,6 +380,36 @@ static int launch_persistent(rh_ring* r, const u64* in, u64* out, int npoly, int
   return check_launch("ntt_fwd_persistent");
 }
 
+template <int S1>
+static void launch_inv_fused(rh_ring* r, const u64* in1, u64* out1, unsigned n1, int npoly1, u64* data2, unsigned n2,
+                             size_t toff, int limb0, const LimbConsts* c, int Lrows) {
+  const unsigned grid = n1 > n2 ? n1 : n2;
+  ntt_inv_fused_asm<S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff,
+                                                     r->d_lastw + limb0, c, Lrows, r->logN);
+}
+// Inverse transform of a large batch: launch j = tile stages of span j fused with column stages (+ N^-1) of span j-1.
+static int std_ntt_inv_pipelined(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, int chunk) {
+  (void)hipGetLastError();
+  const int N = r->N, S1 = r->logN - LT;
+  const size_t toff = (size_t)limb0 * N, stride = (size_t)Lrows * N;
+  const LimbConsts* c = r->d_consts + limb0;
+  const int nspans = (npoly + chunk - 1) / chunk;
+  for (int j = 0; j <= nspans; ++j) {
+    const int p1 = j * chunk, n1p = j < nspans ? ((npoly - p1 < chunk) ? npoly - p1 : chunk) : 0;
+    const int p2 = (j - 1) * chunk, n2p = j >= 1 ? ((npoly - p2 < chunk) ? npoly - p2 : chunk) : 0;
+    const unsigned n1 = ((unsigned)n1p * Lrows) << S1, n2 = (unsigned)n2p * Lrows * 16;
+    const u64* i1 = in + (size_t)p1 * stride; u64* o1 = out + (size_t)p1 * stride; u64* d2 = out + (size_t)p2 * stride;
+    switch (S1) {
+      case 1: launch_inv_fused<1>(r, i1, o1, n1, n1p, d2, n2, toff, limb0, c, Lrows); break;
+      case 2: launch_inv_fused<2>(r, i1, o1, n1, n1p, d2, n2, toff, limb0, c, Lrows); break;
+      case 3: launch_inv_fused<3>(r, i1, o1, n1, n1p, d2, n2, toff, limb0, c, Lrows); break;
+      case 4: launch_inv_fused<4>(r, i1, o1, n1, n1p, d2, n2, toff, limb0, c, Lrows); break;
+      case 5: launch_inv_fused<5>(r, i1, o1, n1, n1p, d2, n2, toff, limb0, c, Lrows); break;
+    }
+  }
+  return check_launch("ntt_inv_fused_asm");
+}
+
 int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase) {
   if (r->persistent && r->logN > LT && phase == 0 && !inverse && !lazy && npoly >= 1) {
     (void)hipGetLastError();
@@ -395,6 +428,8 @@ int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows,
   const bool two_pass = r->logN > LT;
   if (chunk > 0 && two_pass && phase == 0 && !inverse && !lazy && npoly > chunk)
     return std_ntt_fwd_pipelined(r, in, out, npoly, Lrows, limb0, chunk);
+  if (chunk > 0 && two_pass && phase == 0 && inverse && r->asm_tile && r->inv_scale && npoly > chunk)
+    return std_ntt_inv_pipelined(r, in, out, npoly, Lrows, limb0, chunk);
   return std_ntt_launch_span(r, in, out, npoly, Lrows, limb0, inverse, lazy, phase);
 }
 

@@ -274,11 +274,9 @@ ntt_fwd_fused(const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n2, i
 // reduction.  The last stage (h = 1) folds N^-1 into both outputs: X = (U+V)*ninv, Y = (U-V)*(psi*ninv);
 // lastw = Shoup pair of psi_bwd[1]*N^-1.
 template <int S1>
-__global__ void __launch_bounds__(256)
-ntt_inv_cols(u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
-             const LimbConsts* __restrict__ consts, int L, int logN, int scale) {
+RH_DEV void inv_cols_body(const u32 b, u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
+                          const LimbConsts* __restrict__ consts, int L, int logN, int scale) {
   constexpr int R = 1 << S1;
-  const u32 b = blockIdx.x;
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
   const u32 cb = r & 15;
@@ -318,6 +316,12 @@ ntt_inv_cols(u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ las
   }
 #pragma unroll
   for (int k = 0; k < R; ++k) data[base + ((size_t)k << LT)] = x[k];
+}
+template <int S1>
+__global__ void __launch_bounds__(256)
+ntt_inv_cols(u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
+             const LimbConsts* __restrict__ consts, int L, int logN, int scale) {
+  inv_cols_body<S1>(blockIdx.x, data, twn, lastw, consts, L, logN, scale);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

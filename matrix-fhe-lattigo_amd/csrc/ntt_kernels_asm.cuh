@@ -52,6 +52,46 @@ ntt_fwd_fused_asm(const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n
   if (blockIdx.x < n2) fwd_tile_asm_body(lds, blockIdx.x, data2, data2, twk, consts, L, logN, npoly2);
 }
 
+// ---- inverse: first 12 stages (t = 1..2048) on a 4096-tile, values leave < 4q (N^-1 is applied by ntt_inv_cols).
+// Same contract as ntt_inv_tile(last = 0).  twk = kernel-order table built from RootsBackward.
+RH_DEV void inv_tile_asm_body(u64* lds, const u32 b, const u64* in, u64* out, const tw2* __restrict__ twk,
+                              const LimbConsts* __restrict__ consts, int L, int logN, int npoly) {
+  const u32 limb = b % (u32)L;
+  const u32 r = b / (u32)L;
+  const u32 poly = r % (u32)npoly;
+  const u32 tile = r / (u32)npoly;
+  const size_t base = (((size_t)poly * L + limb) << logN) + ((size_t)tile << LT);
+  const u64 pin = uni64((u64)(size_t)(in + base));
+  const u64 pout = uni64((u64)(size_t)(out + base));
+  const u64 tw = uni64((u64)(size_t)(twk + ((size_t)limb << logN) + ((size_t)tile << LT)));
+  const u64 q = uni64(consts[limb].q);
+  const u64 nq = (u64)0 - q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
+  const u32 lds_off = uni32((u32)(size_t)lds);
+  const u32 tid = threadIdx.x;
+  asm volatile(NTT_TILE_INV_ASM_BODY
+               :
+               : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw),
+                 [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)),
+                 [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4)
+               : NTT_TILE_ASM_CLOBBERS);
+}
+__global__ void __launch_bounds__(256)
+ntt_inv_tile_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts,
+                 int L, int logN, int npoly) {
+  __shared__ u64 lds[LDS_WORDS];
+  inv_tile_asm_body(lds, blockIdx.x, in, out, twk, consts, L, logN, npoly);
+}
+// software-pipelined inverse: tile stages of span j (in -> out), then column stages + N^-1 of span j-1 (in place)
+template <int S1>
+__global__ void __launch_bounds__(256)
+ntt_inv_fused_asm(const u64* in1, u64* out1, unsigned n1, int npoly1, u64* data2, unsigned n2,
+                  const tw2* __restrict__ twk, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
+                  const LimbConsts* __restrict__ consts, int L, int logN) {
+  __shared__ u64 lds[LDS_WORDS];
+  if (blockIdx.x < n2) inv_cols_body<S1>(blockIdx.x, data2, twn, lastw, consts, L, logN, 1);
+  if (blockIdx.x < n1) inv_tile_asm_body(lds, blockIdx.x, in1, out1, twk, consts, L, logN, npoly1);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Persistent single-launch forward transform (N >= 8192): gridDim.x resident workgroups walk a static schedule that
 // alternates a column unit of poly-group g with a tile of poly-group g-1.  A tile of row (poly, limb) may start once

@@ -203,3 +203,27 @@ def test_persistent_pipeline_identical(rh, oracle, logN, L, B, group):
     sr = oracle.SubRingConsts(N, mods[-1])
     assert np.array_equal(p.numpy()[B - 1, L - 1], oracle.ntt(a[B - 1, L - 1], sr))
     ring.close()
+
+
+@pytest.mark.parametrize("logN,B", [(13, 3), (16, 5), (14, 300)])
+def test_inverse_asm_and_pipeline_equal_cxx(rh, oracle, logN, B):
+    # hand-scheduled inverse tile body (and, for B >= 256, the fused inverse pipeline) vs the C++ kernels, incl. lazy inputs < 2q
+    N, mods = 1 << logN, [QI60[0], QI60[9]]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(logN + B)
+    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    a[0] = np.array(mods, dtype=np.uint64)[:, None] - np.uint64(1)
+    a[1, :, ::2] += np.array(mods, dtype=np.uint64)[:, None]            # < 2q: accepted like the reference's invbutterfly
+    p = rh.DevicePoly.from_numpy(ring, a)
+    o1, o2 = ring.NewPoly(B), ring.NewPoly(B)
+    ring.set_tuning("asm_tile", 1); ring.INTT(p, o1)
+    ring.set_tuning("asm_tile", 0); ring.INTT(p, o2)
+    x1 = o1.numpy()
+    assert np.array_equal(x1, o2.numpy())
+    srs = [oracle.SubRingConsts(N, q) for q in mods]
+    for k in (0, 1, B - 1):
+        for i in range(2):
+            assert np.array_equal(x1[k, i], oracle.intt(a[k, i] % np.uint64(mods[i]), srs[i]))
+    ring.set_tuning("asm_tile", 1); ring.INTT(p, p)                    # in place
+    assert np.array_equal(p.numpy(), x1)
+    ring.close()

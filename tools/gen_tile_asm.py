@@ -96,6 +96,42 @@ def butterfly_steps(u, v, w, t, sgpr_tw=None):
     ]
 
 
+def inv_butterfly_steps(u, v, w, t, sgpr_tw=None):
+    """inverse (Gentleman-Sande) butterfly, U,V < 4q:  X = csub(U+V, 4q) -> U ;  Y = (U + 4q - V)*w in [0,4q) -> V.
+    Same math as ShoupPolicy::inv (ntt_kernels.cuh).  17 slow + 2 fast."""
+    if sgpr_tw is None:
+        w0, w1, p0, p1 = "v%d" % w, "v%d" % (w + 1), "v%d" % (w + 2), "v%d" % (w + 3)
+    else:
+        w0, w1, p0, p1 = sgpr_tw
+    U, V = pair(u), pair(v)
+    ul, uh, vl, vh = "v%d" % u, "v%d" % (u + 1), "v%d" % v, "v%d" % (v + 1)
+    T, Q, H, G, R, S = pair(t.T), pair(t.Q), pair(t.H), pair(t.G), pair(t.R), pair(t.S)
+    tl, th, m = "v%d" % t.T, "v%d" % (t.T + 1), "v%d" % t.M
+    ql, qh = "v%d" % t.Q, "v%d" % (t.Q + 1)
+    return [
+        "v_lshl_add_u64 %s, %s, 0, %s" % (T, U, V),                 # T = U + V
+        "v_lshl_add_u64 %s, %s, 0, %%[q4]" % (U, U),                # U = U + 4q
+        "v_sub_co_u32 %s, %s, %s, %s" % (vl, t.cc, ul, vl),         # V = d = U + 4q - V
+        "@CARRY",
+        "v_subb_co_u32 %s, %s, %s, %s, %s" % (vh, t.cc, uh, vh, t.cc),
+        "v_lshl_add_u64 %s, %s, 0, %%[nq4]" % (U, T),               # U = T - 4q
+        "v_mul_hi_u32 v%d, %s, %s" % (t.H, vh, p0),
+        "v_mul_hi_u32 v%d, %s, %s" % (t.G, vl, p1),
+        "v_ashrrev_i32 %s, 31, %s" % (m, uh),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (Q, DUMMY, vh, p1, H),
+        "v_mad_u64_u32 %s, %s, %s, %s, 0" % (R, DUMMY, vl, w1),
+        "v_bfi_b32 %s, %s, %s, %s" % (ul, m, tl, ul),               # X = (T - 4q < 0) ? T : T - 4q
+        "v_bfi_b32 %s, %s, %s, %s" % (uh, m, th, uh),
+        "v_lshl_add_u64 %s, %s, 0, %s" % (Q, Q, G),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (S, DUMMY, vh, w0, R),
+        "v_mad_u64_u32 %s, %s, %s, %%[nq1], %s" % (R, DUMMY, ql, S),
+        "v_mad_u64_u32 %s, %s, %s, %%[nq0], %s" % (S, DUMMY, qh, R),
+        "v_mad_u64_u32 %s, %s, %s, %s, 0" % (R, DUMMY, vl, w0),
+        "v_add_u32 v%d, v%d, v%d" % (t.R + 1, t.S, t.R + 1),        # + (h << 32)
+        "v_mad_u64_u32 %s, %s, %s, %%[nq0], %s" % (V, DUMMY, ql, R),
+    ]
+
+
 def interleave(a, b):
     """instruction-wise interleave of two independent butterflies; resolves @CARRY markers (the partner's
     instructions provide the wait states between v_sub_co and v_subb_co; pad with s_nop when they do not)"""
@@ -130,6 +166,102 @@ def single(a):
         else:
             final.append(ins)
     return final
+
+
+def round16_inv(tw_of_slot, stage_hook=None):
+    for u in (3, 2, 1, 0):
+        h = 8 >> u
+        if stage_hook:
+            stage_hook(u)
+        bfs = []
+        for g in range(1 << u):
+            slot = (1 << u) - 1 + g
+            w, sg = tw_of_slot(slot)
+            for e in range(h):
+                k = g * 2 * h + e
+                bfs.append((X(k), X(k + h), w, sg))
+        for i in range(0, len(bfs), 2):
+            a = inv_butterfly_steps(bfs[i][0], bfs[i][1], bfs[i][2], T0, bfs[i][3])
+            b = inv_butterfly_steps(bfs[i + 1][0], bfs[i + 1][1], bfs[i + 1][2], T1, bfs[i + 1][3])
+            for ins in interleave(a, b):
+                emit(ins)
+
+
+INV_SLOT_ORDER = list(range(7, 15)) + list(range(3, 7)) + [1, 2] + [0]      # consumption order of an inverse round
+INV_NEED = {3: 8, 2: 12, 1: 14, 0: 15}                                      # twiddle quads needed before stage u
+
+
+def gen_inverse():
+    """first 12 stages (t = 1..2048) of the inverse transform on a 4096-tile; values leave < 4q (no scaling):
+    mirror image of gen(); same LDS layout and kernel-order twiddle table (built from RootsBackward)."""
+    A0, A1, A2, A3 = ADDR, ADDR + 1, ADDR + 2, ADDR + 3
+    for t in (T0, T1):
+        emit("v_mov_b32 v%d, 0" % (t.H + 1))
+        emit("v_mov_b32 v%d, 0" % (t.G + 1))
+    for slot in range(15):
+        emit("s_load_dwordx4 s[%d:%d], %%[tw], %d" % (36 + 4 * slot, 39 + 4 * slot, 16 * slot))
+    emit("v_lshlrev_b32 v%d, 3, %%[tid]" % A0)
+    for j in range(4):
+        emit("v_add_u32 v%d, %d, v%d" % (SCR + j, 8192 * j + 4096, A0))
+    for k in range(16):
+        j, rem = divmod(k, 4)
+        emit("global_load_dwordx2 %s, v%d, %%[pin] offset:%d" % (pair(X(k)), SCR + j, rem * 2048 - 4096))
+    # round C' twiddles: tw[256 + slot*256 + tid]
+    emit("v_lshlrev_b32 v%d, 4, %%[tid]" % A2)
+    for slot in INV_SLOT_ORDER:
+        emit("s_add_u32 vcc_lo, %%[twlo], %d" % ((256 + 256 * slot) * 16))
+        emit("s_addc_u32 vcc_hi, %[twhi], 0")
+        emit("global_load_dwordx4 v[%d:%d], v%d, vcc" % (TW0 + 4 * slot, TW0 + 4 * slot + 3, A2))
+    emit("v_lshrrev_b32 v%d, 4, %%[tid]" % A1)                # hi4
+    emit("v_add_u32 v%d, %%[tid], v%d" % (A3, A1))
+    emit("v_lshlrev_b32 v%d, 3, v%d" % (A3, A3))
+    emit("v_add_u32 v%d, %%[lds], v%d" % (A3, A3))            # addrA
+    emit("v_mul_u32_u24 v%d, 136, %%[tid]" % A0)
+    emit("v_add_u32 v%d, %%[lds], v%d" % (A0, A0))            # addrC
+    emit("s_waitcnt vmcnt(15)")                               # the 16 data loads
+    for k in range(16):
+        emit("ds_write_b64 v%d, %s offset:%d" % (A3, pair(X(k)), 2176 * k))
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("s_barrier")
+    for k in range(16):
+        emit("ds_read_b64 %s, v%d offset:%d" % (pair(X(k)), A0, 8 * k))
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("; ---- round C' (t = 1, 2, 4, 8)")
+    round16_inv(lambda slot: (TW0 + 4 * slot, None), stage_hook=lambda u: emit("s_waitcnt vmcnt(%d)" % (15 - INV_NEED[u])))
+    # round B' twiddles: tw[16 + slot*16 + hi4]
+    emit("v_lshlrev_b32 v%d, 4, v%d" % (A2, A1))              # hi4*16 bytes
+    for slot in INV_SLOT_ORDER:
+        emit("global_load_dwordx4 v[%d:%d], v%d, %%[tw] offset:%d" % (TW0 + 4 * slot, TW0 + 4 * slot + 3, A2, 256 + 256 * slot))
+    for k in range(16):
+        emit("ds_write_b64 v%d, %s offset:%d" % (A0, pair(X(k)), 8 * k))
+    emit("v_and_b32 v%d, 15, %%[tid]" % A0)                   # lo4
+    emit("v_mul_u32_u24 v%d, 272, v%d" % (A1, A1))
+    emit("v_add_u32 v%d, v%d, v%d" % (A0, A0, A1))
+    emit("v_lshlrev_b32 v%d, 3, v%d" % (A0, A0))
+    emit("v_add_u32 v%d, %%[lds], v%d" % (A0, A0))            # addrB
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("s_barrier")
+    for k in range(16):
+        emit("ds_read_b64 %s, v%d offset:%d" % (pair(X(k)), A0, 136 * k))
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("; ---- round B' (t = 16 .. 128)")
+    round16_inv(lambda slot: (TW0 + 4 * slot, None), stage_hook=lambda u: emit("s_waitcnt vmcnt(%d)" % (15 - INV_NEED[u])))
+    for k in range(16):
+        emit("ds_write_b64 v%d, %s offset:%d" % (A0, pair(X(k)), 136 * k))
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("s_barrier")
+    for k in range(16):
+        emit("ds_read_b64 %s, v%d offset:%d" % (pair(X(k)), A3, 2176 * k))
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("; ---- round A' (t = 256 .. 2048), twiddles in SGPRs")
+    round16_inv(lambda slot: (None, ("s%d" % (36 + 4 * slot), "s%d" % (37 + 4 * slot), "s%d" % (38 + 4 * slot), "s%d" % (39 + 4 * slot))))
+    emit("v_lshlrev_b32 v%d, 3, %%[tid]" % A0)
+    for j in range(4):
+        emit("v_add_u32 v%d, %d, v%d" % (SCR + j, 8192 * j + 4096, A0))
+    for k in range(16):
+        j, rem = divmod(k, 4)
+        emit("global_store_dwordx2 v%d, %s, %%[pout] offset:%d" % (SCR + j, pair(X(k)), rem * 2048 - 4096))
+    emit("s_waitcnt vmcnt(0)")
 
 
 def round16(tw_of_slot, stage_hook=None, pair_hook=None):
@@ -258,16 +390,22 @@ def gen():
     emit("s_waitcnt vmcnt(0)")
 
 
+
+def render(name, lines):
+    body = "\n".join('  "%s\\n\\t"' % l for l in lines)
+    return "#define %s \\\n%s\n" % (name, body.replace("\n", " \\\n"))
+
+
 gen()
-body = "\n".join('  "%s\\n\\t"' % l for l in out)
+fwd = list(out)
+del out[:]
+gen_inverse()
+inv = list(out)
 clob_v = ", ".join('"v%d"' % i for i in range(NVGPR_USED))
 clob_s = ", ".join('"s%d"' % i for i in range(36, 102))
-text = '''// GENERATED by tools/gen_tile_asm.py -- do not edit.  %d instructions.
-#define NTT_TILE_ASM_BODY \\
-%s
-#define NTT_TILE_ASM_CLOBBERS %s, %s, "vcc", "memory"
-''' % (len(out), body.replace("\n", " \\\n"), clob_v, clob_s)
+text = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  forward: %d instructions, inverse: %d.\n" % (len(fwd), len(inv))
+text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_INV_ASM_BODY", inv)
+text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"memory\"\n" % (clob_v, clob_s)
 path = sys.argv[1] if len(sys.argv) > 1 else "ntt_tile_asm.inc"
 open(path, "w").write(text)
-valu = sum(1 for l in out if l.startswith("v_"))
-print("wrote", path, "instructions:", len(out), "VALU:", valu)
+print("wrote", path, "forward:", len(fwd), "VALU", sum(1 for l in fwd if l.startswith("v_")), "| inverse:", len(inv), "VALU", sum(1 for l in inv if l.startswith("v_")))
