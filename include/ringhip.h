@@ -125,6 +125,15 @@ int rh_bext_moddown_qp_to_p(rh_bext* be, int levelQ, int levelP, const uint64_t*
 int rh_bext_decompose_and_split(rh_bext* be, int levelQ, int levelP, int nbPi, int digit, const uint64_t* p0Q,
                                 uint64_t* p1Q, uint64_t* p1P, int npoly);
 
+
+/* ---- hybrid key-switch gadget product, NTT-domain input, levelP >= 1: rlwe.Evaluator.GadgetProduct
+ * (core/rlwe/evaluator_gadget_product.go:16-30) = gadgetProductMultiplePLazy (:122-188) + ModDown NTT->NTT (:33-46).
+ * cx: npoly polys of levelQ+1 limbs (NTT domain).  evkQ / evkP: GadgetCiphertext.Value[i][0][c].Q / .P
+ * (core/rlwe/gadgetciphertext.go:17-45) laid out [digit i < beta_key][component c < 2][all limbs of the ring][N], NTT
+ * domain, Montgomery form, shared by every poly of the batch.  ct0/ct1: npoly polys of levelQ+1 limbs (NTT domain). */
+int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const uint64_t* cx_dev, const uint64_t* evkQ_dev,
+                           const uint64_t* evkP_dev, int beta_key, uint64_t* ct0_dev, uint64_t* ct1_dev, int npoly);
+
 #ifdef __cplusplus
 }
 #endif

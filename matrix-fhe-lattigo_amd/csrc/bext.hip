@@ -116,7 +116,7 @@ struct BextPlan {
 struct rh_bext {
   rh_ring* Q = nullptr; rh_ring* P = nullptr;
   std::map<std::array<int, 5>, BextPlan> plans;
-  u64* buf[2] = {nullptr, nullptr}; size_t buf_words[2] = {0, 0};
+  u64* buf[7] = {}; size_t buf_words[7] = {};      // 0,1: ModDownNTT buffers; 2..6: gadget product (keyswitch.hip)
 };
 
 template <class T>
@@ -183,7 +183,7 @@ extern "C" void rh_bext_destroy(rh_bext* be) {
     void* ptrs[] = {p.d_S, p.d_T, p.d_coef, p.d_vt, p.d_sign};
     for (void* q : ptrs) if (q) (void)hipFree(q);
   }
-  for (int i = 0; i < 2; ++i) if (be->buf[i]) (void)hipFree(be->buf[i]);
+  for (int i = 0; i < 7; ++i) if (be->buf[i]) (void)hipFree(be->buf[i]);
   delete be;
 }
 
@@ -193,6 +193,14 @@ static int ensure_buf(rh_bext* be, int which, size_t words) {
   be->buf[which] = nullptr; be->buf_words[which] = 0;
   if (hipMalloc((void**)&be->buf[which], words * 8) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc(basis-extension scratch) failed");
   be->buf_words[which] = words;
+  return 0;
+}
+
+rh_ring* rh_bext_ringQ(rh_bext* be) { return be->Q; }
+rh_ring* rh_bext_ringP(rh_bext* be) { return be->P; }
+int rh_bext_scratch(rh_bext* be, int which, size_t words, u64** out) {
+  if (int rc = ensure_buf(be, which, words)) return rc;
+  *out = be->buf[which];
   return 0;
 }
 

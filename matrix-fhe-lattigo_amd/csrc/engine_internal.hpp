@@ -52,3 +52,9 @@ void rh_rescale_teardown(rh_ring* r);
 int rh_ring3n_setup(rh_ring* r, std::vector<LimbConsts>& hc);
 void rh_ring3n_teardown(rh_ring* r);
 int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse);
+
+// basis extender internals shared with keyswitch.hip
+struct rh_bext;
+rh_ring* rh_bext_ringQ(rh_bext* be);
+rh_ring* rh_bext_ringP(rh_bext* be);
+int rh_bext_scratch(rh_bext* be, int which, size_t words, u64** out);

@@ -1,0 +1,111 @@
+// keyswitch.hip -- device-side orchestration of the hybrid key-switch gadget product.
+//
+// Replaces, for NTT-domain inputs and levelP >= 1, rlwe.Evaluator.GadgetProduct (core/rlwe/evaluator_gadget_product.go:16-30)
+// = gadgetProductMultiplePLazy (:122-188) + ModDown NTT->NTT (:33-46), including DecomposeSingleNTT (:455-478).
+// Everything it sequences already exists on the device (INTT, DecomposeAndSplit, NTT, ModDownQPtoQNTT); the one new
+// kernel is the multiply-accumulate that streams the evaluation key once per digit for BOTH output components
+// (MulCoeffsMontgomeryLazy / ...LazyThenAddLazy of ringqp, ring/ringqp/operations.go:115-155).
+// Outputs are canonical (the reference ends with ring.Reduce and a full MRed in ModDown), so they are bit-identical.
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "engine_internal.hpp"
+
+// acc_c[row] (=|+=) MRedLazy(evk_c[limb], c2[row]) for c = 0,1.  rows = npoly * L; evk is shared by every poly.
+__global__ void __launch_bounds__(256)
+gadget_mac_kernel(const u64* c2, const u64* __restrict__ evk0, const u64* __restrict__ evk1, u64* acc0, u64* acc1,
+                  unsigned n, const LimbConsts* __restrict__ consts, int L, int first) {
+  const u32 row = blockIdx.x, limb = row % (u32)L;
+  const u64 q = consts[limb].q, qi = consts[limb].qinv;
+  const size_t ro = (size_t)row * n, eo = (size_t)limb * n;
+  const unsigned npairs = n >> 1;
+  for (unsigned i = blockIdx.y * blockDim.x + threadIdx.x; i < npairs; i += gridDim.y * blockDim.x) {
+    const ulonglong2 x = *reinterpret_cast<const ulonglong2*>(c2 + ro + 2 * (size_t)i);
+    const ulonglong2 k0 = *reinterpret_cast<const ulonglong2*>(evk0 + eo + 2 * (size_t)i);
+    const ulonglong2 k1 = *reinterpret_cast<const ulonglong2*>(evk1 + eo + 2 * (size_t)i);
+    ulonglong2 a, b;
+    a.x = mred_lazy(k0.x, x.x, q, qi); a.y = mred_lazy(k0.y, x.y, q, qi);
+    b.x = mred_lazy(k1.x, x.x, q, qi); b.y = mred_lazy(k1.y, x.y, q, qi);
+    if (!first) {
+      const ulonglong2 pa = *reinterpret_cast<const ulonglong2*>(acc0 + ro + 2 * (size_t)i);
+      const ulonglong2 pb = *reinterpret_cast<const ulonglong2*>(acc1 + ro + 2 * (size_t)i);
+      a.x += pa.x; a.y += pa.y; b.x += pb.x; b.y += pb.y;
+    }
+    *reinterpret_cast<ulonglong2*>(acc0 + ro + 2 * (size_t)i) = a;
+    *reinterpret_cast<ulonglong2*>(acc1 + ro + 2 * (size_t)i) = b;
+  }
+}
+
+static int mac(rh_ring* r, const u64* c2, const u64* e0, const u64* e1, u64* a0, u64* a1, int npoly, int L, int first) {
+  const unsigned rows = (unsigned)npoly * L, n = (unsigned)r->N;
+  unsigned chunks = (n / 2 + 1023) / 1024; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
+  gadget_mac_kernel<<<dim3(rows, chunks), 256, 0, r->stream>>>(c2, e0, e1, a0, a1, n, r->d_consts, L, first);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_mac_kernel launch failed: %s", hipGetErrorString(e));
+  return RH_OK;
+}
+
+static int overflow_margin(const std::vector<u64>& m, int level) {     // QiOverflowMargin / PiOverflowMargin, core/rlwe/params.go
+  u64 mx = 0; for (int i = 0; i <= level; ++i) if (m[i] > mx) mx = m[i];
+  return (int)(18446744073709551616.0 / (double)mx);
+}
+
+extern "C" int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, const uint64_t* evkQ,
+                                      const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly) {
+  if (!be || !cx || !evkQ || !evkP || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "gadget_product: null argument");
+  rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
+  if (!RP) return rh_fail(RH_ERR_ARG, "gadget_product: basis extender has no P ring");
+  if (RQ->kind != RH_RING_STANDARD) return rh_fail(RH_ERR_UNSUPPORTED, "gadget_product: standard rings only");
+  if (levelQ < 0 || levelQ >= RQ->L || levelP < 1 || levelP >= RP->L) return rh_fail(RH_ERR_ARG, "gadget_product: need 0 <= levelQ < %d and 1 <= levelP < %d", RQ->L, RP->L);
+  const int LQ = levelQ + 1, LP = levelP + 1, N = RQ->N;
+  const int beta = (levelQ + levelP + 1) / (levelP + 1);           // BaseRNSDecompositionVectorSize, params.go:635-642
+  if (beta > beta_key) return rh_fail(RH_ERR_ARG, "gadget_product: key has %d digits, level needs %d", beta_key, beta);
+  if (npoly <= 0) return RH_OK;
+  (void)hipSetDevice(RQ->device);
+  RP->stream = RQ->stream;
+  const size_t wq = (size_t)npoly * LQ * N, wp = (size_t)npoly * LP * N;
+  u64 *cxInv, *c2Q, *c2P, *aP0, *aP1;
+  if (int rc = rh_bext_scratch(be, 2, wq, &cxInv)) return rc;
+  if (int rc = rh_bext_scratch(be, 3, wq, &c2Q)) return rc;
+  if (int rc = rh_bext_scratch(be, 4, wp, &c2P)) return rc;
+  if (int rc = rh_bext_scratch(be, 5, wp, &aP0)) return rc;
+  if (int rc = rh_bext_scratch(be, 6, wp, &aP1)) return rc;
+  // ringQ.INTT(cxNTT, cxInvNTT)  (:138)
+  if (int rc = rh_std_ntt_launch(RQ, cx, cxInv, npoly, LQ, 0, true, false, 0)) return rc;
+  const int QiOverF = overflow_margin(RQ->moduli, levelQ) >> 1, PiOverF = overflow_margin(RP->moduli, levelP) >> 1;
+  const size_t evq_stride = (size_t)RQ->L * N, evp_stride = (size_t)RP->L * N;     // one (digit, component) block
+  int reduce = 0;
+  for (int i = 0; i < beta; ++i) {
+    // DecomposeSingleNTT (:455-478)
+    if (int rc = rh_bext_decompose_and_split(be, levelQ, levelP, levelP + 1, i, cxInv, c2Q, c2P, npoly)) return rc;
+    if (int rc = rh_std_ntt_launch(RQ, c2Q, c2Q, npoly, LQ, 0, false, false, 0)) return rc;
+    const int st = i * LP; int ed = st + LP; if (ed > LQ) ed = LQ;
+    // digit limbs are taken from the NTT-domain input as they are (:467-468)
+    if (hipMemcpy2DAsync(c2Q + (size_t)st * N, (size_t)LQ * N * 8, cx + (size_t)st * N, (size_t)LQ * N * 8, (size_t)(ed - st) * N * 8, npoly,
+                         hipMemcpyDeviceToDevice, RQ->stream) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_product: digit copy failed");
+    if (int rc = rh_std_ntt_launch(RP, c2P, c2P, npoly, LP, 0, false, false, 0)) return rc;
+    const u64* eq0 = evkQ + ((size_t)i * 2 + 0) * evq_stride; const u64* eq1 = evkQ + ((size_t)i * 2 + 1) * evq_stride;
+    const u64* ep0 = evkP + ((size_t)i * 2 + 0) * evp_stride; const u64* ep1 = evkP + ((size_t)i * 2 + 1) * evp_stride;
+    if (int rc = mac(RQ, c2Q, eq0, eq1, ct0, ct1, npoly, LQ, i == 0)) return rc;
+    if (int rc = mac(RP, c2P, ep0, ep1, aP0, aP1, npoly, LP, i == 0)) return rc;
+    if (reduce % QiOverF == QiOverF - 1) {
+      if (int rc = rh_vec_launch(RQ, RH_OP_REDUCE, ct0, nullptr, ct0, npoly, LQ, 0, nullptr, nullptr)) return rc;
+      if (int rc = rh_vec_launch(RQ, RH_OP_REDUCE, ct1, nullptr, ct1, npoly, LQ, 0, nullptr, nullptr)) return rc;
+    }
+    if (reduce % PiOverF == PiOverF - 1) {
+      if (int rc = rh_vec_launch(RP, RH_OP_REDUCE, aP0, nullptr, aP0, npoly, LP, 0, nullptr, nullptr)) return rc;
+      if (int rc = rh_vec_launch(RP, RH_OP_REDUCE, aP1, nullptr, aP1, npoly, LP, 0, nullptr, nullptr)) return rc;
+    }
+    ++reduce;
+  }
+  if (reduce % QiOverF != 0) {
+    if (int rc = rh_vec_launch(RQ, RH_OP_REDUCE, ct0, nullptr, ct0, npoly, LQ, 0, nullptr, nullptr)) return rc;
+    if (int rc = rh_vec_launch(RQ, RH_OP_REDUCE, ct1, nullptr, ct1, npoly, LQ, 0, nullptr, nullptr)) return rc;
+  }
+  if (reduce % PiOverF != 0) {
+    if (int rc = rh_vec_launch(RP, RH_OP_REDUCE, aP0, nullptr, aP0, npoly, LP, 0, nullptr, nullptr)) return rc;
+    if (int rc = rh_vec_launch(RP, RH_OP_REDUCE, aP1, nullptr, aP1, npoly, LP, 0, nullptr, nullptr)) return rc;
+  }
+  // eval.ModDown, NTT -> NTT (:41-44)
+  if (int rc = rh_bext_moddown_qp_to_q_ntt(be, levelQ, levelP, ct0, aP0, ct0, npoly)) return rc;
+  return rh_bext_moddown_qp_to_q_ntt(be, levelQ, levelP, ct1, aP1, ct1, npoly);
+}

@@ -70,6 +70,7 @@ def lib():
         "rh_bext_moddown_qp_to_q_ntt": (i, [vp, i, i, vp, vp, vp, i]),
         "rh_bext_moddown_qp_to_p": (i, [vp, i, i, vp, vp, vp, i]),
         "rh_bext_decompose_and_split": (i, [vp, i, i, i, i, vp, vp, vp, i]),
+        "rh_bext_gadget_product": (i, [vp, i, i, vp, vp, vp, i, vp, vp, i]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -342,6 +343,10 @@ class BasisExtender:
 
     def DecomposeAndSplit(self, levelQ, levelP, nbPi, digit, p0Q, p1Q, p1P):
         _check(lib().rh_bext_decompose_and_split(self._h, levelQ, levelP, nbPi, digit, p0Q.ptr, p1Q.ptr, p1P.ptr, p0Q.npoly))
+
+    def GadgetProduct(self, levelQ, levelP, cx, evkQ_ptr, evkP_ptr, beta_key, ct0, ct1):
+        """rlwe.Evaluator.GadgetProduct for NTT-domain cx; evk*_ptr: device pointers of the key blocks (see ringhip.h)"""
+        _check(lib().rh_bext_gadget_product(self._h, levelQ, levelP, cx.ptr, evkQ_ptr, evkP_ptr, beta_key, ct0.ptr, ct1.ptr, cx.npoly))
 
     def close(self):
         if getattr(self, "_h", None):

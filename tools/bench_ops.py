@@ -81,7 +81,18 @@ res.append(entry("DecomposeAndSplit N=2^16 alpha=6 -> 18 Q + 6 P limbs", timed(l
 res.append(entry("ModUpPtoQ N=2^16 6 -> 24 limbs", timed(lambda: be.ModUpPtoQ(5, 23, pp, poq), reps=5), 8.0 * N * (6 + 24) * B, B, "poly"))
 res.append(entry("ModDownQPtoQ N=2^16 (24+6) -> 24 limbs", timed(lambda: be.ModDownQPtoQ(23, 5, pq, pp, poq), reps=5), 8.0 * N * (6 + 24 + 24) * B, B, "poly"))
 res.append(entry("ModDownQPtoQNTT N=2^16 (24+6) -> 24 limbs", timed(lambda: be.ModDownQPtoQNTT(23, 5, pq, pp, poq), reps=5), 8.0 * N * (6 + 24 + 24) * B + 16.0 * N * 30 * B, B, "poly"))
-del pq, pp, poq, pop, xq, xp, oq, op_
+# config 5: GadgetProduct (key-switch of one ciphertext component), beta = 4 digits, key shared by the batch
+beta = 4
+evq, evp = rand_block(beta * 2, QI60[:24], N), rand_block(beta * 2, PI60[:6], N)
+c0, c1 = torch.zeros_like(xq), torch.zeros_like(xq)
+p0, p1 = rh.DevicePoly.from_torch(rq, c0), rh.DevicePoly.from_torch(rq, c1)
+ms = timed(lambda: be.GadgetProduct(23, 5, pq, evq.data_ptr(), evp.data_ptr(), beta, p0, p1), reps=3, warm=1)
+limb_ntts = 24 + beta * 24 + 2 * 30                      # INTT(cx) + per digit (18 Q + 6 P) + 2 x ModDownNTT (6 INTT + 24 NTT)
+e = entry("config5 GadgetProduct N=2^16 Q=24 P=6 beta=4 (per ciphertext component, key shared by batch of %d)" % B, ms,
+          16.0 * N * limb_ntts * B + 2.0 * beta * 30 * 8 * N, B, "keyswitch")
+e["limb_ntt_equivalents_per_keyswitch"] = limb_ntts
+res.append(e)
+del pq, pp, poq, pop, xq, xp, oq, op_, p0, p1, c0, c1, evq, evp
 be.close(); rq.close(); rp.close(); torch.cuda.empty_cache()
 
 # ---- config 2 / 4 rings: 3N transform ----
