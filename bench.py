@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=-1, help="polys per (column,tile) kernel pair; -1 = engine default")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path on one GPU)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--persistent", type=int, default=-1)
     ap.add_argument("--unsafe", type=int, default=0)
     ap.add_argument("--group", type=int, default=-1, help="polys per group of the persistent pipeline")
@@ -49,10 +51,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    if args.single_device:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -105,7 +112,7 @@ def main():
     wall = t1 - t0
     dev_ms = e0.elapsed_time(e1)
     if dist is not None:
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(t[0]), float(t[1])
 
@@ -137,8 +144,10 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
     if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
+        try:                                            # PMC-measured bytes (profiles/), valid for the profiled shape only
+            tj = json.load(open(tpath))
+            if tj.get("config", {}).get("logn") == args.logn and tj.get("config", {}).get("limbs") == L:
+                traffic = tj["hbm_bytes_per_poly"] * B
         except Exception:
             traffic = None
     out = {

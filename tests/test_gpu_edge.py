@@ -1,0 +1,87 @@
+"""GPU: edge cases of the C ABI -- extreme ring sizes, odd limb counts, empty batches, aliasing, levels."""
+import numpy as np
+import pytest
+
+from conftest import QI60, uniform_mod
+
+pytestmark = pytest.mark.gpu
+
+
+def test_largest_ring_2_17(rh, oracle):
+    # N = 2^17 (Qi60 are valid up to 2^17: ring/test_params.go:14): five column stages per thread
+    N, mods = 1 << 17, QI60[:2]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(17)
+    a = np.stack([uniform_mod(rng, q, N) for q in mods])[None]
+    p = rh.DevicePoly.from_numpy(ring, a)
+    o = ring.NewPoly(1)
+    ring.NTT(p, o)
+    srs = [oracle.SubRingConsts(N, q) for q in mods]
+    assert np.array_equal(o.numpy()[0], np.stack([oracle.ntt(a[0, i], srs[i]) for i in range(2)]))
+    ring.NTTLazy(p, o)
+    assert np.array_equal(o.numpy()[0, 1], oracle.ntt(a[0, 1], srs[1], lazy=True))
+    ring.NTT(p, p); ring.INTT(p, p)
+    assert np.array_equal(p.numpy(), a)
+    ring.close()
+
+
+@pytest.mark.parametrize("L", [1, 3, 7, 13])
+def test_limb_counts_not_multiple_of_eight(rh, oracle, L):
+    N, mods = 8192, QI60[:L]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(L)
+    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(3)])
+    p = rh.DevicePoly.from_numpy(ring, a)
+    ring.NTT(p, p)
+    got = p.numpy()
+    for i in (0, L - 1):
+        assert np.array_equal(got[2, i], oracle.ntt(a[2, i], oracle.SubRingConsts(N, mods[i])))
+    ring.INTT(p, p)
+    assert np.array_equal(p.numpy(), a)
+    ring.close()
+
+
+def test_empty_batch_and_bad_arguments(rh):
+    ring = rh.Ring(4096, QI60[:2])
+    p = ring.NewPoly(1)
+    lib = rh.lib()
+    assert lib.rh_ring_ntt(ring._h, p.ptr, p.ptr, 0, 1, 0) == 0            # npoly = 0 is a no-op
+    assert lib.rh_ring_vec_op(ring._h, 0, p.ptr, p.ptr, p.ptr, 0, 1, None, None) == 0
+    assert lib.rh_ring_ntt(ring._h, p.ptr, p.ptr, 1, 2, 0) == -1           # level out of range
+    assert lib.rh_ring_ntt(ring._h, p.ptr, p.ptr, -1, 1, 0) == -1
+    assert lib.rh_ring_vec_op(ring._h, 99, p.ptr, p.ptr, p.ptr, 1, 1, None, None) == -1
+    assert lib.rh_ring_vec_op(ring._h, rh.OPS["ADD"], p.ptr, None, p.ptr, 1, 1, None, None) == -1     # missing operand
+    assert lib.rh_ring_set_tuning(ring._h, b"no_such_knob", 1) == -1
+    ring.close()
+
+
+def test_modulus_range_is_enforced(rh):
+    with pytest.raises(rh.RingHipError):                       # q must be < 2^61 (lazy ranges reach 8q: ring/ntt.go:169)
+        rh.Ring(64, [(1 << 62) + 1], constants=dict(mred=[1], bred=[[0, 0]], ninv=[1],
+                                                     roots_fwd=np.zeros((1, 64), dtype=np.uint64), roots_bwd=np.zeros((1, 64), dtype=np.uint64)))
+
+
+def test_small_moduli_and_mixed_sizes(rh, oracle):
+    # 31-bit and 45-bit primes next to a 61-bit one: every kernel must be generic in q
+    N = 4096
+    mods = []
+    for bits in (31, 45, 58):
+        q = (1 << bits) + 1
+        while not (oracle.lib().orc_is_prime(q) and q % (2 * N) == 1):
+            q += 2 * N if q % (2 * N) == 1 else 1
+        mods.append(q)
+    mods.append(QI60[3])
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(3)
+    a = np.stack([uniform_mod(rng, q, N) for q in mods])[None]
+    p = rh.DevicePoly.from_numpy(ring, a)
+    o = ring.NewPoly(1)
+    ring.NTT(p, o)
+    srs = [oracle.SubRingConsts(N, q) for q in mods]
+    assert np.array_equal(o.numpy()[0], np.stack([oracle.ntt(a[0, i], srs[i]) for i in range(4)]))
+    ring.NTTLazy(p, o)
+    assert np.array_equal(o.numpy()[0], np.stack([oracle.ntt(a[0, i], srs[i], lazy=True) for i in range(4)]))
+    ring.INTT(o, o)            # lazy representatives (< 6q) are accepted by INTT only up to 4q: reduce first
+    ring.NTT(p, o); ring.INTT(o, o)
+    assert np.array_equal(o.numpy(), a)
+    ring.close()
