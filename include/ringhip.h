@@ -108,6 +108,13 @@ int rh_ring_vec_op(rh_ring* r, int opcode, const uint64_t* p1_dev, const uint64_
 int rh_ring_div_by_last_modulus_many(rh_ring* r, int round, int level, int nb, uint64_t* p0_dev, uint64_t* p1_dev, int p1_rows, int npoly);
 int rh_ring_div_by_last_modulus_many_ntt(rh_ring* r, int round, int level, int nb, const uint64_t* p0_dev, uint64_t* p1_dev, int p1_rows, int npoly);
 
+/* ---- Galois automorphisms X -> X^gen (ring/automorphism.go), power-of-two rings, never in place.
+ *   rh_ring_automorphism_ntt: AutomorphismNTT (:39-47) / AutomorphismNTTWithIndex (:52-81); add_lazy != 0:
+ *                             AutomorphismNTTWithIndexThenAddLazy (:86-117) (out += permuted in, wrapping)
+ *   rh_ring_automorphism:     Automorphism (:121-176, standard ring branch), coefficient domain with sign flips   */
+int rh_ring_automorphism_ntt(rh_ring* r, int level, const uint64_t* in_dev, uint64_t gen, uint64_t* out_dev, int npoly, int add_lazy);
+int rh_ring_automorphism(rh_ring* r, int level, const uint64_t* in_dev, uint64_t gen, uint64_t* out_dev, int npoly);
+
 /* ---- RNS basis extension (ring/basis_extension.go).  A basis extender pairs a Q ring and a P ring
  * (NewBasisExtender :52-79).  All polys device-resident, limbs 0..levelQ / 0..levelP, npoly polys.  Asynchronous. */
 typedef struct rh_bext rh_bext;

@@ -64,6 +64,8 @@ def lib():
         "rh_ring_vec_op": (i, [vp, i, vp, vp, vp, i, i, U64P, U64P]),
         "rh_ring_div_by_last_modulus_many": (i, [vp, i, i, i, vp, vp, i, i]),
         "rh_ring_div_by_last_modulus_many_ntt": (i, [vp, i, i, i, vp, vp, i, i]),
+        "rh_ring_automorphism_ntt": (i, [vp, i, vp, C.c_uint64, vp, i, i]),
+        "rh_ring_automorphism": (i, [vp, i, vp, C.c_uint64, vp, i]),
         "rh_bext_create": (i, [C.POINTER(vp), vp, vp]), "rh_bext_destroy": (None, [vp]),
         "rh_bext_modup_q_to_p": (i, [vp, i, i, vp, vp, i]), "rh_bext_modup_p_to_q": (i, [vp, i, i, vp, vp, i]),
         "rh_bext_moddown_qp_to_q": (i, [vp, i, i, vp, vp, vp, i]),
@@ -260,6 +262,16 @@ class Ring:
 
     def INTTLazy(self, p1, p2):
         self._chk(p1, p2); _check(lib().rh_ring_intt(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 1))
+
+    # ---- automorphisms (ring/automorphism.go) ---------------------------------------------------------------
+    def AutomorphismNTT(self, polIn, gen, polOut):
+        _check(lib().rh_ring_automorphism_ntt(self._h, self.level, polIn.ptr, int(gen), polOut.ptr, polIn.npoly, 0))
+
+    def AutomorphismNTTThenAddLazy(self, polIn, gen, polOut):
+        _check(lib().rh_ring_automorphism_ntt(self._h, self.level, polIn.ptr, int(gen), polOut.ptr, polIn.npoly, 1))
+
+    def Automorphism(self, polIn, gen, polOut):
+        _check(lib().rh_ring_automorphism(self._h, self.level, polIn.ptr, int(gen), polOut.ptr, polIn.npoly))
 
     # ---- rescale (ring/scaling.go).  Output poly may have level+1 or fewer limbs, like the reference -----------
     def DivFloorByLastModulusMany(self, nbRescales, p0, p1):

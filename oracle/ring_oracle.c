@@ -552,6 +552,31 @@ void orc_decompose_and_split(int levelQ, int levelP, int nbPi, int digit, const 
   free(tgt); orc_free_modup_constants(c);
 }
 
+/* ------------------------------------------------------------------ automorphisms (ring/automorphism.go) */
+
+void orc_automorphism_ntt_index(int N, uint64_t nthroot, uint64_t gal, uint64_t* index) { /* :12-35 */
+  int lg = 0; while (((u64)1 << (lg + 1)) < nthroot) lg++;        /* bits.Len64(NthRoot-1) - 1 */
+  u64 mask = nthroot - 1;
+  for (int i = 0; i < N; i++) {
+    u64 t1 = 2 * bitrev64((u64)i, lg) + 1;
+    u64 t2 = ((gal * t1 & mask) - 1) >> 1;
+    index[i] = bitrev64(t2, lg);
+  }
+}
+void orc_automorphism_ntt(const uint64_t* in, uint64_t* out, int N, uint64_t gal, int add_lazy) { /* :52-117 */
+  u64* idx = (u64*)malloc((size_t)N * 8);
+  orc_automorphism_ntt_index(N, (u64)2 * N, gal, idx);
+  for (int j = 0; j < N; j++) out[j] = add_lazy ? out[j] + in[idx[j]] : in[idx[j]];
+  free(idx);
+}
+void orc_automorphism(const uint64_t* in, uint64_t* out, int N, uint64_t gal, uint64_t q) { /* :162-175 */
+  u64 mask = (u64)N - 1; int logN = 0; while (((u64)1 << logN) < (u64)N) logN++;
+  for (u64 i = 0; i < (u64)N; i++) {
+    u64 raw = i * gal, index = raw & mask, tmp = (raw >> logN) & 1;
+    out[index] = in[i] * (tmp ^ 1) | (q - in[i]) * tmp;
+  }
+}
+
 /* ------------------------------------------------------------------ RNS rescale (ring/scaling.go) */
 
 /* DivFloorByLastModulus :21-28 (round = 0) / DivRoundByLastModulus :112-126 (round = 1), coefficient domain, one step at

@@ -96,6 +96,11 @@ void orc_decompose_and_split(int levelQ, int levelP, int nbPi, int digit, const 
                              uint64_t* const* p1q, uint64_t* const* p1p, size_t n,
                              const uint64_t* Qall, int nQall, const uint64_t* Pall, int nPall);
 
+/* ---- automorphisms: ring/automorphism.go:12-35 (index), :52-117 (NTT domain, optional += lazy), :162-175 (coefficients) ---- */
+void orc_automorphism_ntt_index(int N, uint64_t nthroot, uint64_t gal, uint64_t* index);
+void orc_automorphism_ntt(const uint64_t* in, uint64_t* out, int N, uint64_t gal, int add_lazy);
+void orc_automorphism(const uint64_t* in, uint64_t* out, int N, uint64_t gal, uint64_t q);
+
 /* ---- RNS rescale: ring/scaling.go:21-28 (floor) / :112-126 (round); one step at `level`, coefficient domain ---- */
 void orc_div_by_last_modulus(int round, uint64_t* const* p0, uint64_t* const* p1, size_t n, const uint64_t* Q, int level);
 
