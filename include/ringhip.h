@@ -31,6 +31,9 @@ typedef enum rh_status {
 
 typedef enum rh_ring_kind {
   RH_RING_STANDARD = 0,   /* Z_q[X]/(X^N+1), NumberTheoreticTransformerStandard (ring/ntt.go:31-78)                    */
+  RH_RING_CI = 1,         /* Z_q[X+X^-1]/(X^2N+1), NumberTheoreticTransformerConjugateInvariant (ring/ntt.go:80-124,
+                             716-1311); NthRoot = 4N: root tables have 2N entries per limb; ForwardLazy returns the
+                             canonical residues (inside the documented range, congruent)                             */
   RH_RING_3N = 2          /* Z_q[X]/(X^N-X^(N/2)+1), NumberTheoreticTransformer3N (ring/ntt_3n.go:21-156)             */
 } rh_ring_kind;
 

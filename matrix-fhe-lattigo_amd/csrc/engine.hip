@@ -83,7 +83,7 @@ int rh_upload_consts(rh_ring* r, const std::vector<LimbConsts>& hc) { return upl
 
 // ------------------------------------------------------------------------------------------------ ring construction
 static int validate_degree(int kind, int N) {
-  if (kind == RH_RING_STANDARD) {
+  if (kind == RH_RING_STANDARD || kind == RH_RING_CI) {
     if (N < 16 || (N & (N - 1)) != 0 || N > (1 << 17)) return rh_fail(RH_ERR_ARG, "invalid ring degree: N=%d must be a power of two in [16, 2^17]", N);
     return 0;
   }
@@ -118,14 +118,18 @@ extern "C" int rh_ring_create(rh_ring** out, int device, int kind, int N, int L,
     c.q = moduli[i]; c.qinv = mred[i]; c.bred0 = bred[2 * i]; c.bred1 = bred[2 * i + 1]; c.nq = (u64)0 - moduli[i];
     c.ninv_mont = 0; c.ninv_w = 0; c.ninv_wp = 0;
   }
-  if (kind == RH_RING_STANDARD) {
-    if (!ninv || !roots_fwd || !roots_bwd) { delete r; return rh_fail(RH_ERR_ARG, "rh_ring_create: standard ring needs ninv and root tables"); }
+  if (kind == RH_RING_STANDARD || kind == RH_RING_CI) {
+    if (!ninv || !roots_fwd || !roots_bwd) { delete r; return rh_fail(RH_ERR_ARG, "rh_ring_create: ring needs ninv and root tables"); }
     int logN = 0; while ((1 << logN) < N) ++logN;
     r->logN = logN;
+    // table length handed over: NthRoot/2 = N (standard, 2N-th root) or 2N (conjugate invariant, 4N-th root)
+    const size_t TN = kind == RH_RING_CI ? (size_t)2 * N : (size_t)N;
     r->ninv.assign(ninv, ninv + L);
-    r->roots_fwd.assign(roots_fwd, roots_fwd + (size_t)L * N);
-    r->roots_bwd.assign(roots_bwd, roots_bwd + (size_t)L * N);
+    r->roots_fwd.assign(roots_fwd, roots_fwd + (size_t)L * TN);
+    r->roots_bwd.assign(roots_bwd, roots_bwd + (size_t)L * TN);
     std::vector<tw2> fs((size_t)L * N), is((size_t)L * N), lastw(L);
+    std::vector<u64> mont((size_t)L * N);
+    std::vector<CiFold> fold(L);
     for (int i = 0; i < L; ++i) {
       const u64 q = moduli[i];
       LimbConsts& c = hc[i];
@@ -133,15 +137,26 @@ extern "C" int rh_ring_create(rh_ring** out, int device, int kind, int N, int L,
       c.ninv_w = rh::imform(ninv[i], q); c.ninv_wp = rh::shoup_quotient(c.ninv_w, q);
       // one modular inverse of 2^64 per limb, then a multiply per root
       const u64 rinv = rh::imform(1, q);
+      const u64* rf = roots_fwd + (size_t)i * TN; const u64* rb = roots_bwd + (size_t)i * TN;
       for (int j = 0; j < N; ++j) {
-        u64 wf = rh::mulmod(roots_fwd[(size_t)i * N + j] % q, rinv, q), wb = rh::mulmod(roots_bwd[(size_t)i * N + j] % q, rinv, q);
+        // standard: stage with m blocks uses roots[m+i] (ring/ntt.go:240-255).  Conjugate invariant: the same stage
+        // uses roots[2m+i] of the 4N-th-root table (:768-781, :1119-1147), i.e. entry j = m+i reads 2m+i = j + 2^floor(log2 j)
+        size_t src = (size_t)j;
+        if (kind == RH_RING_CI && j > 0) { int hb = 31 - __builtin_clz((unsigned)j); src = (size_t)j + ((size_t)1 << hb); }
+        u64 wf = rh::mulmod(rf[src] % q, rinv, q), wb = rh::mulmod(rb[src] % q, rinv, q);
         fs[(size_t)i * N + j] = tw2{wf, rh::shoup_quotient(wf, q)};
         is[(size_t)i * N + j] = tw2{wb, rh::shoup_quotient(wb, q)};
+        mont[(size_t)i * N + j] = rf[src];
       }
       u64 lw = rh::mulmod(is[(size_t)i * N + 1].w, c.ninv_w, q);
       lastw[i] = tw2{lw, rh::shoup_quotient(lw, q)};
+      if (kind == RH_RING_CI) {
+        const u64 ff = rh::mulmod(rf[1] % q, rinv, q), fb = rh::mulmod(rb[1] % q, rinv, q);
+        fold[i] = CiFold{tw2{ff, rh::shoup_quotient(ff, q)}, tw2{fb, rh::shoup_quotient(fb, q)}};
+      }
     }
-    if (!rc) rc = rh_std_upload_tables(r, fs, is, &r->roots_fwd, lastw);
+    if (!rc) rc = rh_std_upload_tables(r, fs, is, &mont, lastw);
+    if (!rc && kind == RH_RING_CI) rc = upload(&r->d_cifold, fold);
   } else {
     if (!omega3n) { delete r; return rh_fail(RH_ERR_ARG, "rh_ring_create: 3N ring needs omega3n"); }
     r->omega3n.assign(omega3n, omega3n + L);
@@ -159,8 +174,10 @@ extern "C" int rh_ring_create_auto(rh_ring** out, int device, int kind, int N, i
   if (!out || !moduli || L < 1 || L > RH_MAX_LIMBS) return rh_fail(RH_ERR_ARG, "rh_ring_create_auto: bad arguments");
   if (int e = validate_degree(kind, N)) return e;
   std::vector<u64> mred(L), bred(2 * L), ninv(L), rf, rb, om;
-  const u64 nthroot = (kind == RH_RING_STANDARD) ? (u64)2 * N : (u64)3 * N;
-  if (kind == RH_RING_STANDARD) { rf.resize((size_t)L * N); rb.resize((size_t)L * N); }
+  const bool pow2 = kind == RH_RING_STANDARD || kind == RH_RING_CI;
+  const u64 nthroot = kind == RH_RING_STANDARD ? (u64)2 * N : (kind == RH_RING_CI ? (u64)4 * N : (u64)3 * N);
+  const size_t TN = (size_t)(nthroot >> 1);
+  if (pow2) { rf.resize((size_t)L * TN); rb.resize((size_t)L * TN); }
   else om.resize(L);
   for (int i = 0; i < L; ++i) {
     const u64 q = moduli[i];
@@ -168,22 +185,21 @@ extern "C" int rh_ring_create_auto(rh_ring** out, int device, int kind, int N, i
     if (q % nthroot != 1) return rh_fail(RH_ERR_MODULUS, "invalid modulus: %llu != 1 mod NthRoot)", (unsigned long long)q);
     mred[i] = rh::gen_mred_constant(q);
     rh::gen_bred_constant(q, &bred[2 * i]);
-    if (kind == RH_RING_STANDARD) {
-      if (rh::gen_ntt_tables(q, nthroot, &rf[(size_t)i * N], &rb[(size_t)i * N], &ninv[i])) return rh_fail(RH_ERR_MODULUS, "table generation failed for modulus %llu", (unsigned long long)q);
+    if (pow2) {
+      if (rh::gen_ntt_tables(q, nthroot, &rf[(size_t)i * TN], &rb[(size_t)i * TN], &ninv[i])) return rh_fail(RH_ERR_MODULUS, "table generation failed for modulus %llu", (unsigned long long)q);
     } else {
       ninv[i] = rh::mform(rh::invmod_prime((u64)N % q, q), q);
       om[i] = omega3n ? omega3n[i] : rh::powmod(rh::primitive_root(q), (q - 1) / nthroot, q);
     }
   }
   return rh_ring_create(out, device, kind, N, L, moduli, mred.data(), bred.data(), ninv.data(),
-                        kind == RH_RING_STANDARD ? rf.data() : nullptr, kind == RH_RING_STANDARD ? rb.data() : nullptr,
-                        kind == RH_RING_3N ? om.data() : nullptr);
+                        pow2 ? rf.data() : nullptr, pow2 ? rb.data() : nullptr, kind == RH_RING_3N ? om.data() : nullptr);
 }
 
 extern "C" void rh_ring_destroy(rh_ring* r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
-  void* ptrs[] = {r->d_consts, r->d_tw_fwd, r->d_tw_inv, r->d_tw_fwd_mont, r->d_twk_fwd, r->d_twk_inv, r->d_twk_fwd_mont, r->d_lastw, r->d_scratch, r->d_rowcnt};
+  void* ptrs[] = {r->d_cifold, r->d_consts, r->d_tw_fwd, r->d_tw_inv, r->d_tw_fwd_mont, r->d_twk_fwd, r->d_twk_inv, r->d_twk_fwd_mont, r->d_lastw, r->d_scratch, r->d_rowcnt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   rh_rescale_teardown(r);
   for (int i = 0; i < 2; ++i) if (r->d_rs[i]) (void)hipFree(r->d_rs[i]);
@@ -433,12 +449,54 @@ int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows,
   return std_ntt_launch_span(r, in, out, npoly, Lrows, limb0, inverse, lazy, phase);
 }
 
+// ---- conjugate-invariant ring Z[X+X^-1]/(X^2N+1) (ring/ntt.go:716-1311): the negacyclic kernels on the re-indexed
+// 4N-th-root table, plus the fold with F = roots[1] before (forward :761-768) / after (inverse :1149-1156) them.
+__global__ void __launch_bounds__(256)
+ci_fold_kernel(const u64* in, u64* out, int logN, const CiFold* __restrict__ fold, const LimbConsts* __restrict__ consts, int L, int inverse) {
+  const u32 N = 1u << logN;
+  const u32 limb = blockIdx.x % (u32)L;
+  const LimbConsts c = consts[limb];
+  const tw2 F = inverse ? fold[limb].b : fold[limb].f;
+  const u64 q4 = 4 * c.q;
+  const size_t base = (size_t)blockIdx.x << logN;
+  for (u32 jx = blockIdx.y * blockDim.x + threadIdx.x; jx <= (N >> 1); jx += gridDim.y * blockDim.x) {
+    if (jx == 0) {
+      const u64 x = in[base];
+      out[base] = inverse ? cred(2 * csub(csub(x, 2 * c.q), c.q), c.q) : x;          // p2[0] = CRed(p2[0] << 1) (:1157) / p1[0] (:770)
+    } else if (jx == (N >> 1)) {
+      const u64 x = csub(in[base + jx], q4);
+      const u64 v = x + q4 - shoup_mul(x, F.w, F.wp, c.nq);
+      out[base + jx] = inverse ? canon8(v, c.q) : v;
+    } else {
+      const u32 jy = N - jx;
+      const u64 a = csub(in[base + jx], q4), b = csub(in[base + jy], q4);
+      const u64 va = a + q4 - shoup_mul(b, F.w, F.wp, c.nq), vb = b + q4 - shoup_mul(a, F.w, F.wp, c.nq);
+      out[base + jx] = inverse ? canon8(va, c.q) : va;
+      out[base + jy] = inverse ? canon8(vb, c.q) : vb;
+    }
+  }
+}
+static int ci_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse) {
+  const unsigned rows = (unsigned)npoly * Lrows;
+  if (!rows) return RH_OK;
+  unsigned chunks = ((unsigned)r->N / 2 + 256) / 256; if (chunks > 64) chunks = 64;
+  (void)hipGetLastError();
+  if (!inverse) {
+    ci_fold_kernel<<<dim3(rows, chunks), 256, 0, r->stream>>>(in, out, r->logN, r->d_cifold + limb0, r->d_consts + limb0, Lrows, 0);
+    return rh_std_ntt_launch(r, out, out, npoly, Lrows, limb0, false, false, 0);
+  }
+  if (int rc = rh_std_ntt_launch(r, in, out, npoly, Lrows, limb0, true, false, 0)) return rc;
+  ci_fold_kernel<<<dim3(rows, chunks), 256, 0, r->stream>>>(out, out, r->logN, r->d_cifold + limb0, r->d_consts + limb0, Lrows, 1);
+  return check_launch("ci_fold_kernel");
+}
+
 static int ntt_batch(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, bool inverse, bool lazy, int phase = 0) {
   if (!r || !in || !out) return rh_fail(RH_ERR_ARG, "ntt: null argument");
   if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "ntt: level %d out of range [0,%d)", level, r->L);
   if (npoly < 0) return rh_fail(RH_ERR_ARG, "ntt: npoly < 0");
   (void)hipSetDevice(r->device);
   if (r->kind == RH_RING_3N) return rh_ring3n_ntt_launch(r, in, out, npoly, level + 1, 0, inverse);
+  if (r->kind == RH_RING_CI) return ci_ntt_launch(r, in, out, npoly, level + 1, 0, inverse);
   return rh_std_ntt_launch(r, in, out, npoly, level + 1, 0, inverse, lazy, phase);
 }
 extern "C" int rh_ring_ntt(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, int lazy) { return ntt_batch(r, in, out, npoly, level, false, lazy != 0); }
@@ -468,6 +526,7 @@ static int ntt_host_limb(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2,
   hipError_t e = hipMemcpyAsync(r->d_scratch, p1, bytes, hipMemcpyHostToDevice, r->stream);
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "H2D: %s", hipGetErrorString(e));
   int rc = (r->kind == RH_RING_3N) ? rh_ring3n_ntt_launch(r, r->d_scratch, r->d_scratch, 1, 1, limb, inverse)
+         : (r->kind == RH_RING_CI) ? ci_ntt_launch(r, r->d_scratch, r->d_scratch, 1, 1, limb, inverse)
                                    : rh_std_ntt_launch(r, r->d_scratch, r->d_scratch, 1, 1, limb, inverse, lazy, 0);
   if (rc) return rc;
   e = hipMemcpyAsync(p2, r->d_scratch, bytes, hipMemcpyDeviceToHost, r->stream);

@@ -11,6 +11,7 @@
 int rh_fail(int code, const char* fmt, ...);
 
 struct rh_ring3n_state;   // ntt3n.hip
+struct CiFold { tw2 f, b; };   // conjugate-invariant fold twiddles roots_fwd[1], roots_bwd[1] (Shoup pairs)
 
 struct rh_ring {
   int device = 0, kind = 0, N = 0, logN = 0, L = 0;
@@ -26,6 +27,7 @@ struct rh_ring {
   tw2* d_twk_fwd = nullptr;       // kernel order (logN >= 12)
   tw2* d_twk_inv = nullptr;
   u64* d_twk_fwd_mont = nullptr;
+  CiFold* d_cifold = nullptr;     // conjugate-invariant rings only
   tw2* d_lastw = nullptr;         // psi_bwd[1] * N^-1 per limb
   u64* d_scratch = nullptr;       // 2N words for the host-pointer single-limb path
   rh_ring3n_state* s3n = nullptr;

@@ -13,6 +13,7 @@ _ROOT = os.path.dirname(_HERE)
 U64P = C.POINTER(C.c_uint64)
 
 Standard = 0   # ring.Standard (ring/ring.go Type)
+ConjugateInvariant = 1   # ring.ConjugateInvariant, Z[X+X^-1]/(X^2N+1)
 Matrix3N = 2   # 3N-cyclotomic ring (ring.Matrix, ring/ring.go:299-304)
 
 
@@ -199,8 +200,9 @@ class Ring:
         mred = np.zeros(self.L, dtype=np.uint64); bred = np.zeros(2 * self.L, dtype=np.uint64)
         ninv = np.zeros(self.L, dtype=np.uint64)
         out = {"mred": mred, "bred": bred.reshape(self.L, 2), "ninv": ninv}
-        if self.kind == Standard:
-            rf = np.zeros((self.L, self.N), dtype=np.uint64); rb = np.zeros((self.L, self.N), dtype=np.uint64)
+        if self.kind in (Standard, ConjugateInvariant):
+            TN = self.N if self.kind == Standard else 2 * self.N
+            rf = np.zeros((self.L, TN), dtype=np.uint64); rb = np.zeros((self.L, TN), dtype=np.uint64)
             _check(lib().rh_ring_get_constants(self._h, None, _p(mred), _p(bred), _p(ninv), _p(rf), _p(rb), None))
             out.update(roots_fwd=rf, roots_bwd=rb)
         else:

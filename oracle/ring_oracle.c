@@ -248,6 +248,57 @@ void orc_intt_standard_lazy(const u64* p1, u64* p2, int N, u64 ninv, u64 q, u64 
   else        { for (int i = 0; i < N; i++) p2[i] = orc_mred(p2[i], ninv, q, qinv); }        /* :203-205 */
 }
 
+/* Conjugate-invariant NTT in Z[X+X^-1]/(X^2N+1): ring/ntt.go:716-1311.  roots: the 4N-th-root tables (2N entries).
+ * Restates the non-unrolled forms nttConjugateInvariantLazy (:751-783) / inttConjugateInvariantLazy (:1113-1157) and
+ * the canonical wrappers NTTConjugateInvariant (:717-720) / INTTConjugateInvariant (:728-731).  The unrolled forms
+ * differ only in which stages apply the lazy 4q subtraction, which does not change the canonical result. */
+void orc_ntt_ci(const u64* p1, u64* p2, int N, u64 q, u64 qinv, const u64 bred[2], const u64* roots) {
+  u64 twoQ = 2 * q;
+  u64 F = roots[1];
+  u64* in = (u64*)malloc((size_t)N * 8); memcpy(in, p1, (size_t)N * 8);
+  for (int jx = 1, jy = N - 1; jx < (N >> 1); jx++, jy--) {
+    p2[jx] = in[jx] + twoQ - orc_mred_lazy(in[jy], F, q, qinv);
+    p2[jy] = in[jy] + twoQ - orc_mred_lazy(in[jx], F, q, qinv);
+  }
+  p2[N >> 1] = in[N >> 1] + twoQ - orc_mred_lazy(in[N >> 1], F, q, qinv);
+  p2[0] = in[0];
+  free(in);
+  int t = N;
+  for (int m = 2; m < 2 * N; m <<= 1) {
+    t >>= 1;
+    int h = m >> 1;
+    for (int i = 0; i < h; i++) {
+      u64 W = roots[m + i];
+      int j1 = 2 * i * t;
+      for (int j = j1; j < j1 + t; j++) fwd_bfly(&p2[j], &p2[j + t], p2[j], p2[j + t], W, q, qinv, 1);
+    }
+  }
+  for (int i = 0; i < N; i++) p2[i] = orc_bred_add(p2[i], q, bred);
+}
+void orc_intt_ci(const u64* p1, u64* p2, int N, u64 ninv, u64 q, u64 qinv, const u64* roots) {
+  u64 twoQ = 2 * q;
+  int t = 1;
+  const u64* src = p1;
+  for (int m = N; m > 1; m >>= 1, t <<= 1) {           /* first stage uses roots[N+i] (h = N/2), then roots[m+i], h = m/2 */
+    int h = m >> 1;
+    for (int i = 0; i < h; i++) {
+      u64 W = roots[m + i];
+      int j1 = 2 * i * t;
+      for (int j = j1; j < j1 + t; j++) inv_bfly(&p2[j], &p2[j + t], src[j], src[j + t], W, q, qinv);
+    }
+    src = p2;
+  }
+  u64 F = roots[1];
+  for (int jx = 1, jy = N - 1; jx < (N >> 1); jx++, jy--) {
+    u64 a = p2[jx], b = p2[jy];
+    p2[jx] = a + twoQ - orc_mred_lazy(b, F, q, qinv);
+    p2[jy] = b + twoQ - orc_mred_lazy(a, F, q, qinv);
+  }
+  p2[N >> 1] = p2[N >> 1] + twoQ - orc_mred_lazy(p2[N >> 1], F, q, qinv);
+  p2[0] = orc_cred(p2[0] << 1, q);
+  for (int i = 0; i < N; i++) p2[i] = orc_mred(p2[i], ninv, q, qinv);
+}
+
 /* ------------------------------------------------------------------ element-wise kernels (ring/vec_ops.go) */
 
 int orc_vec_op(int op, const u64* p1, const u64* p2, u64* p3, size_t n, u64 s0, u64 s1, u64 q, u64 qinv,

@@ -60,6 +60,10 @@ void orc_intt_standard(const uint64_t* p1, uint64_t* p2, int N, uint64_t ninv, u
 void orc_intt_standard_lazy(const uint64_t* p1, uint64_t* p2, int N, uint64_t ninv, uint64_t q, uint64_t qinv,
                             const uint64_t* roots);                                             /* :197-206 */
 
+/* conjugate-invariant NTT (ring/ntt.go:716-1311), canonical outputs; roots = tables of the 4N-th root (2N entries) */
+void orc_ntt_ci(const uint64_t* p1, uint64_t* p2, int N, uint64_t q, uint64_t qinv, const uint64_t bred[2], const uint64_t* roots);
+void orc_intt_ci(const uint64_t* p1, uint64_t* p2, int N, uint64_t ninv, uint64_t q, uint64_t qinv, const uint64_t* roots);
+
 /* ---- element-wise kernels: ring/vec_ops.go.  Opcodes are shared with include/ringhip.h (RH_OP_*). ----
  * p1,p2: inputs (p2 may be NULL for unary/scalar ops); p3: output (read-modify-write for the *then* ops);
  * s0,s1: scalars.  n must be a multiple of 8 (reference contract). */
