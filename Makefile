@@ -7,7 +7,7 @@ LIB   := $(PKG)/lib/libringhip.so
 SRCS  := $(CSRC)/engine.hip $(CSRC)/ntt3n.hip $(CSRC)/bext.hip $(CSRC)/rescale.hip $(CSRC)/keyswitch.hip $(CSRC)/automorphism.hip
 HDRS  := $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.inc) $(wildcard $(CSRC)/*.hpp) $(wildcard include/*.h)
 
-all: $(LIB) oracle
+all: $(LIB) oracle tests/cpp/test_ring_cpp
 
 $(CSRC)/ntt_tile_asm.inc: tools/gen_tile_asm.py
 	python3 tools/gen_tile_asm.py $@
@@ -15,6 +15,9 @@ $(CSRC)/ntt_tile_asm.inc: tools/gen_tile_asm.py
 $(LIB): $(SRCS) $(HDRS) $(CSRC)/ntt_tile_asm.inc
 	@mkdir -p $(PKG)/lib
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Iinclude $(SRCS) -o $@
+
+tests/cpp/test_ring_cpp: tests/cpp/test_ring_cpp.cpp include/ringhip.hpp include/ringhip.h $(LIB)
+	g++ -O2 -std=c++17 -Iinclude $< -L$(PKG)/lib -lringhip -Wl,-rpath,'$$ORIGIN/../../$(PKG)/lib' -o $@
 
 oracle: oracle/libring_oracle.so
 oracle/libring_oracle.so: oracle/ring_oracle.c oracle/ring_oracle.h include/ringhip_ops.h

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--persistent", type=int, default=-1)
     ap.add_argument("--unsafe", type=int, default=0)
+    ap.add_argument("--order-mix", type=int, default=-1)
     ap.add_argument("--group", type=int, default=-1, help="polys per group of the persistent pipeline")
     ap.add_argument("--asm", type=int, default=-1, help="1/0: hand-scheduled vs C++ forward tile kernel; -1 = engine default")
     args = ap.parse_args()
@@ -74,6 +75,8 @@ def main():
         ring.set_tuning("asm_tile", args.asm)
     if args.persistent >= 0:
         ring.set_tuning("persistent", args.persistent)
+    if args.order_mix >= 0:
+        ring.set_tuning("order_mix", args.order_mix)
     if args.unsafe:
         ring.set_tuning("persist_unsafe_timing", 1)
     if args.group >= 1:

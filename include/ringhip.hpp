@@ -1,0 +1,162 @@
+// ringhip.hpp -- C++ host-side mirror of the reference's `ring` interface over the C ABI (ringhip.h).
+//
+// The reference is compiled Go; this image has no Go toolchain, so the compiled-language host side is C++ (the Go/cgo
+// binding is go/ringhip/).  Names, argument order and error behaviour follow the reference: methods that panic in Go
+// throw ringhip::Panic here (ring/ntt.go:212-214), constructors that return `error` throw ringhip::Error
+// (ring/ring.go:321-331).  Header-only; link with -lringhip.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+#include "ringhip.h"
+
+namespace ringhip {
+
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };   // Go `error`
+struct Panic : std::logic_error { using std::logic_error::logic_error; };         // Go `panic`
+
+inline void check(int rc) {
+  if (rc == RH_OK) return;
+  const std::string msg = rh_last_error();
+  if (rc == RH_ERR_ARG) throw Panic(msg);
+  throw Error(msg);
+}
+
+enum class Type { Standard = RH_RING_STANDARD, ConjugateInvariant = RH_RING_CI, Matrix = RH_RING_3N };   // ring.Type
+
+class Ring;
+
+// Device-resident block of `npoly` polynomials with `limbs` limbs: the device form of ring.Poly (ring/poly.go:13-24)
+class Poly {
+ public:
+  Poly(const Ring& r, int npoly, int limbs);
+  ~Poly();
+  Poly(const Poly&) = delete;
+  Poly& operator=(const Poly&) = delete;
+  Poly(Poly&& o) noexcept : ring_(o.ring_), ptr_(o.ptr_), npoly_(o.npoly_), limbs_(o.limbs_) { o.ptr_ = nullptr; }
+  uint64_t* data() const { return ptr_; }
+  int npoly() const { return npoly_; }
+  int limbs() const { return limbs_; }
+  size_t words() const;
+  void upload(const std::vector<uint64_t>& host);          // host layout: [poly][limb][coeff]
+  std::vector<uint64_t> download() const;
+ private:
+  const Ring* ring_; uint64_t* ptr_ = nullptr; int npoly_, limbs_;
+};
+
+// one modulus of a Ring: the NumberTheoreticTransformer seam (ring/ntt.go:17-22), host slices, one limb per call
+class SubRing {
+ public:
+  SubRing(rh_ring* h, int idx, int n, uint64_t q) : N(n), Modulus(q), h_(h), idx_(idx) {}
+  const int N; const uint64_t Modulus;
+  void NTT(const std::vector<uint64_t>& p1, std::vector<uint64_t>& p2) const { call(rh_ntt_forward, p1, p2); }
+  void NTTLazy(const std::vector<uint64_t>& p1, std::vector<uint64_t>& p2) const { call(rh_ntt_forward_lazy, p1, p2); }
+  void INTT(const std::vector<uint64_t>& p1, std::vector<uint64_t>& p2) const { call(rh_ntt_backward, p1, p2); }
+  void INTTLazy(const std::vector<uint64_t>& p1, std::vector<uint64_t>& p2) const { call(rh_ntt_backward_lazy, p1, p2); }
+ private:
+  template <class F> void call(F f, const std::vector<uint64_t>& p1, std::vector<uint64_t>& p2) const {
+    if ((int)p1.size() < N || (int)p2.size() < N)
+      throw Panic("cannot NTT: ensure that len(p1)=" + std::to_string(p1.size()) + ", len(p2)=" + std::to_string(p2.size()) + " >= N=" + std::to_string(N));
+    check(f(h_, idx_, p1.data(), p2.data()));
+  }
+  rh_ring* h_; int idx_;
+};
+
+class Ring {
+ public:
+  // NewRing / NewRingFromType (ring/ring.go:264-308): constants generated with the reference's rules
+  Ring(int N, const std::vector<uint64_t>& moduli, Type type = Type::Standard, int device = 0, const std::vector<uint64_t>* omega3n = nullptr)
+      : N_(N), moduli_(moduli), level_((int)moduli.size() - 1) {
+    rh_ring* h = nullptr;
+    check(rh_ring_create_auto(&h, device, (int)type, N, (int)moduli.size(), moduli.data(), omega3n ? omega3n->data() : nullptr));
+    h_.reset(h, rh_ring_destroy);
+    for (int i = 0; i < (int)moduli.size(); ++i) SubRings.emplace_back(h, i, N, moduli[i]);
+  }
+  int N() const { return N_; }
+  int Level() const { return level_; }
+  int ModuliChainLength() const { return (int)moduli_.size(); }
+  const std::vector<uint64_t>& ModuliChain() const { return moduli_; }
+  rh_ring* handle() const { return h_.get(); }
+  // view restricted to limbs 0..level (ring/ring.go:194-213); shares the engine handle
+  Ring AtLevel(int level) const {
+    if (level < 0 || level >= (int)moduli_.size()) throw Panic("level out of range");
+    Ring v(*this); v.level_ = level; return v;
+  }
+  Poly NewPoly(int npoly = 1) const { return Poly(*this, npoly, level_ + 1); }
+  void Sync() const { check(rh_ring_sync(h_.get())); }
+
+  void NTT(const Poly& p1, Poly& p2) const { check(rh_ring_ntt(h_.get(), p1.data(), p2.data(), p1.npoly(), level_, 0)); }
+  void NTTLazy(const Poly& p1, Poly& p2) const { check(rh_ring_ntt(h_.get(), p1.data(), p2.data(), p1.npoly(), level_, 1)); }
+  void INTT(const Poly& p1, Poly& p2) const { check(rh_ring_intt(h_.get(), p1.data(), p2.data(), p1.npoly(), level_, 0)); }
+  void INTTLazy(const Poly& p1, Poly& p2) const { check(rh_ring_intt(h_.get(), p1.data(), p2.data(), p1.npoly(), level_, 1)); }
+
+  // ring/operations.go -> ring/vec_ops.go
+  void VecOp(int op, const Poly* p1, const Poly* p2, Poly& p3, const uint64_t* s0 = nullptr, const uint64_t* s1 = nullptr) const {
+    check(rh_ring_vec_op(h_.get(), op, p1 ? p1->data() : nullptr, p2 ? p2->data() : nullptr, p3.data(), p3.npoly(), level_, s0, s1));
+  }
+  void Add(const Poly& a, const Poly& b, Poly& c) const { VecOp(RH_OP_ADD, &a, &b, c); }
+  void Sub(const Poly& a, const Poly& b, Poly& c) const { VecOp(RH_OP_SUB, &a, &b, c); }
+  void Neg(const Poly& a, Poly& c) const { VecOp(RH_OP_NEG, &a, nullptr, c); }
+  void Reduce(const Poly& a, Poly& c) const { VecOp(RH_OP_REDUCE, &a, nullptr, c); }
+  void MForm(const Poly& a, Poly& c) const { VecOp(RH_OP_MFORM, &a, nullptr, c); }
+  void IMForm(const Poly& a, Poly& c) const { VecOp(RH_OP_IMFORM, &a, nullptr, c); }
+  void MulCoeffsBarrett(const Poly& a, const Poly& b, Poly& c) const { VecOp(RH_OP_MUL_BARRETT, &a, &b, c); }
+  void MulCoeffsMontgomery(const Poly& a, const Poly& b, Poly& c) const { VecOp(RH_OP_MUL_MONT, &a, &b, c); }
+  void MulCoeffsMontgomeryThenAdd(const Poly& a, const Poly& b, Poly& c) const { VecOp(RH_OP_MUL_MONT_THEN_ADD, &a, &b, c); }
+  void MulCoeffsMontgomeryLazy(const Poly& a, const Poly& b, Poly& c) const { VecOp(RH_OP_MUL_MONT_LAZY, &a, &b, c); }
+  void MulCoeffsMontgomeryLazyThenAddLazy(const Poly& a, const Poly& b, Poly& c) const { VecOp(RH_OP_MUL_MONT_LAZY_THEN_ADD_LAZY, &a, &b, c); }
+  // ring/scaling.go
+  void DivRoundByLastModulusManyNTT(int nb, const Poly& p0, Poly& p1) const {
+    check(rh_ring_div_by_last_modulus_many_ntt(h_.get(), 1, level_, nb, p0.data(), p1.data(), p1.limbs(), p0.npoly()));
+  }
+  void DivFloorByLastModulusManyNTT(int nb, const Poly& p0, Poly& p1) const {
+    check(rh_ring_div_by_last_modulus_many_ntt(h_.get(), 0, level_, nb, p0.data(), p1.data(), p1.limbs(), p0.npoly()));
+  }
+  // ring/automorphism.go
+  void AutomorphismNTT(const Poly& in, uint64_t gen, Poly& out) const { check(rh_ring_automorphism_ntt(h_.get(), level_, in.data(), gen, out.data(), in.npoly(), 0)); }
+  void Automorphism(const Poly& in, uint64_t gen, Poly& out) const { check(rh_ring_automorphism(h_.get(), level_, in.data(), gen, out.data(), in.npoly())); }
+
+  std::vector<SubRing> SubRings;
+ private:
+  int N_; std::vector<uint64_t> moduli_; int level_;
+  std::shared_ptr<rh_ring> h_;
+};
+
+inline Poly::Poly(const Ring& r, int npoly, int limbs) : ring_(&r), npoly_(npoly), limbs_(limbs) {
+  check(rh_dev_alloc(r.handle(), words() ? words() : 1, &ptr_));
+}
+inline Poly::~Poly() { if (ptr_) rh_dev_free(nullptr, ptr_); }
+inline size_t Poly::words() const { return (size_t)npoly_ * limbs_ * ring_->N(); }
+inline void Poly::upload(const std::vector<uint64_t>& host) {
+  if (host.size() < words()) throw Panic("upload: host vector too short");
+  check(rh_dev_upload(ring_->handle(), ptr_, host.data(), words()));
+}
+inline std::vector<uint64_t> Poly::download() const {
+  std::vector<uint64_t> out(words());
+  check(rh_dev_download(ring_->handle(), out.data(), ptr_, words()));
+  return out;
+}
+
+// ring.BasisExtender (ring/basis_extension.go:13-79) + the key-switch gadget product built on it
+class BasisExtender {
+ public:
+  BasisExtender(const Ring& q, const Ring& p) { rh_bext* h = nullptr; check(rh_bext_create(&h, q.handle(), p.handle())); h_.reset(h, rh_bext_destroy); }
+  void ModUpQtoP(int lq, int lp, const Poly& polQ, Poly& polP) const { check(rh_bext_modup_q_to_p(h_.get(), lq, lp, polQ.data(), polP.data(), polQ.npoly())); }
+  void ModUpPtoQ(int lp, int lq, const Poly& polP, Poly& polQ) const { check(rh_bext_modup_p_to_q(h_.get(), lp, lq, polP.data(), polQ.data(), polP.npoly())); }
+  void ModDownQPtoQ(int lq, int lp, const Poly& q1, const Poly& p1, Poly& q2) const { check(rh_bext_moddown_qp_to_q(h_.get(), lq, lp, q1.data(), p1.data(), q2.data(), q1.npoly())); }
+  void ModDownQPtoQNTT(int lq, int lp, const Poly& q1, const Poly& p1, Poly& q2) const { check(rh_bext_moddown_qp_to_q_ntt(h_.get(), lq, lp, q1.data(), p1.data(), q2.data(), q1.npoly())); }
+  void ModDownQPtoP(int lq, int lp, const Poly& q1, const Poly& p1, Poly& p2) const { check(rh_bext_moddown_qp_to_p(h_.get(), lq, lp, q1.data(), p1.data(), p2.data(), q1.npoly())); }
+  void DecomposeAndSplit(int lq, int lp, int nbPi, int digit, const Poly& p0Q, Poly& p1Q, Poly& p1P) const {
+    check(rh_bext_decompose_and_split(h_.get(), lq, lp, nbPi, digit, p0Q.data(), p1Q.data(), p1P.data(), p0Q.npoly()));
+  }
+  void GadgetProduct(int lq, int lp, const Poly& cx, const Poly& evkQ, const Poly& evkP, int beta, Poly& ct0, Poly& ct1) const {
+    check(rh_bext_gadget_product(h_.get(), lq, lp, cx.data(), evkQ.data(), evkP.data(), beta, ct0.data(), ct1.data(), cx.npoly()));
+  }
+ private:
+  std::shared_ptr<rh_bext> h_;
+};
+
+}  // namespace ringhip

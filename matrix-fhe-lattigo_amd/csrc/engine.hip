@@ -338,7 +338,7 @@ static void launch_fused(rh_ring* r, const u64* in1, u64* out1, unsigned n1, u64
                          size_t toff, const LimbConsts* c, int Lrows) {
   const unsigned grid = n1 > n2 ? n1 : n2;
   if (r->asm_tile)
-    ntt_fwd_fused_asm<S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN);
+    ntt_fwd_fused_asm<S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN, r->order_mix);
   else
     ntt_fwd_fused<ShoupPolicy, S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff,
                                                              c, Lrows, r->logN, 1);
@@ -509,6 +509,7 @@ extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
   if (!r || !key) return rh_fail(RH_ERR_ARG, "set_tuning: null argument");
   if (!strcmp(key, "chunk_polys")) { r->chunk_polys = (int)value; return RH_OK; }
   if (!strcmp(key, "asm_tile")) { r->asm_tile = value != 0; return RH_OK; }
+  if (!strcmp(key, "order_mix")) { r->order_mix = (int)value; return RH_OK; }
   if (!strcmp(key, "persistent")) { r->persistent = value != 0; return RH_OK; }
   if (!strcmp(key, "group_polys")) { if (value < 1) return rh_fail(RH_ERR_ARG, "group_polys must be >= 1"); r->group_polys = (int)value; return RH_OK; }
   if (!strcmp(key, "persist_grid")) { r->persist_grid = (int)value; return RH_OK; }

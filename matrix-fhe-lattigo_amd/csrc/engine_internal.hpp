@@ -38,6 +38,7 @@ struct rh_ring {
   int persist_unsafe = 0;         // timing experiments only: plain stores and no acquire in the hand-off
   int persist_grid = 0;           // resident workgroups (0 = query)
   unsigned* d_rowcnt = nullptr; size_t rowcnt_words = 0, err_index = 0;
+  int order_mix = 0;              // fused forward launch: alternate (cols, tile) / (tile, cols) order between CU slots
   bool asm_tile = true;           // forward tile kernel: hand-scheduled body (ntt_kernels_asm.cuh) vs the C++ one
   bool inv_scale = true;          // false: inverse leaves values < 4q without the N^-1 factor (3N sub-transform)
   int chunk_polys = -1;           // -1 = auto (128-poly spans for batches >= 256), 0 = whole batch in two launches, >0 = polys per span

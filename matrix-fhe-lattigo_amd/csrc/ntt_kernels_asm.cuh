@@ -46,10 +46,19 @@ ntt_fwd_tile_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const Lim
 template <int S1>
 __global__ void __launch_bounds__(256)
 ntt_fwd_fused_asm(const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n2, int npoly2,
-                  const tw2* __restrict__ twn, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts, int L, int logN) {
+                  const tw2* __restrict__ twn, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts, int L, int logN,
+                  int order_mix) {
   __shared__ u64 lds[LDS_WORDS];
-  if (blockIdx.x < n1) fwd_cols_body<ShoupPolicy, S1>(blockIdx.x, in1, out1, twn, consts, L, logN);
-  if (blockIdx.x < n2) fwd_tile_asm_body(lds, blockIdx.x, data2, data2, twk, consts, L, logN, npoly2);
+  // the two items of a launch are independent: alternate their order between the workgroup slots of a CU
+  // (blocks b, b+256, ... share a CU slot under round-robin placement; speed only) so that memory-phase and
+  // compute-phase workgroups are co-resident from the first instant of the launch
+  if (order_mix && ((blockIdx.x >> 8) & 1u)) {
+    if (blockIdx.x < n2) fwd_tile_asm_body(lds, blockIdx.x, data2, data2, twk, consts, L, logN, npoly2);
+    if (blockIdx.x < n1) fwd_cols_body<ShoupPolicy, S1>(blockIdx.x, in1, out1, twn, consts, L, logN);
+  } else {
+    if (blockIdx.x < n1) fwd_cols_body<ShoupPolicy, S1>(blockIdx.x, in1, out1, twn, consts, L, logN);
+    if (blockIdx.x < n2) fwd_tile_asm_body(lds, blockIdx.x, data2, data2, twk, consts, L, logN, npoly2);
+  }
 }
 
 // ---- inverse: first 12 stages (t = 1..2048) on a 4096-tile, values leave < 4q (N^-1 is applied by ntt_inv_cols).

@@ -45,3 +45,14 @@ def test_argument_errors_without_device(rh):
     assert lib.rh_ring_create_auto(C.byref(h), 0, rh.Standard, 4096, 1, notfriendly.ctypes.data_as(rh.ringhip.U64P), None) == -2
     assert b"!= 1 mod NthRoot" in lib.rh_last_error()
     assert lib.rh_ring_ntt(None, None, None, 1, 0, 0) == -1
+
+
+@pytest.mark.gpu
+def test_cpp_host_mirror_binary():
+    # include/ringhip.hpp: the compiled-language host side (the reference is compiled Go); built by `make`
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "test_ring_cpp")
+    assert os.path.exists(exe), "run `make` first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all checks passed" in out.stdout
