@@ -38,8 +38,12 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--persistent", type=int, default=-1)
+    ap.add_argument("--cluster", type=int, default=-1)
+    ap.add_argument("--cluster-wgs", type=int, default=-1)
     ap.add_argument("--unsafe", type=int, default=0)
     ap.add_argument("--order-mix", type=int, default=-1)
+    ap.add_argument("--prefetch", type=int, default=-1, help="fused launch with tile loads ahead of the column stages (default off: measured no gain)")
+    ap.add_argument("--cols2", type=int, default=-1)
     ap.add_argument("--group", type=int, default=-1, help="polys per group of the persistent pipeline")
     ap.add_argument("--asm", type=int, default=-1, help="1/0: hand-scheduled vs C++ forward tile kernel; -1 = engine default")
     args = ap.parse_args()
@@ -73,8 +77,16 @@ def main():
         ring.set_tuning("chunk_polys", args.chunk)
     if args.asm >= 0:
         ring.set_tuning("asm_tile", args.asm)
+    if args.cluster >= 0:
+        ring.set_tuning("cluster", args.cluster)
+    if args.cluster_wgs >= 1:
+        ring.set_tuning("cluster_wgs_per_cu", args.cluster_wgs)
     if args.persistent >= 0:
         ring.set_tuning("persistent", args.persistent)
+    if args.cols2 >= 0:
+        ring.set_tuning("cols2", args.cols2)
+    if args.prefetch >= 0:
+        ring.set_tuning("prefetch", args.prefetch)
     if args.order_mix >= 0:
         ring.set_tuning("order_mix", args.order_mix)
     if args.unsafe:

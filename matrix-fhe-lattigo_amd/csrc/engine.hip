@@ -199,7 +199,7 @@ extern "C" int rh_ring_create_auto(rh_ring** out, int device, int kind, int N, i
 extern "C" void rh_ring_destroy(rh_ring* r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
-  void* ptrs[] = {r->d_cifold, r->d_consts, r->d_tw_fwd, r->d_tw_inv, r->d_tw_fwd_mont, r->d_twk_fwd, r->d_twk_inv, r->d_twk_fwd_mont, r->d_lastw, r->d_scratch, r->d_rowcnt};
+  void* ptrs[] = {r->d_cifold, r->d_consts, r->d_tw_fwd, r->d_tw_inv, r->d_tw_fwd_mont, r->d_twk_fwd, r->d_twk_inv, r->d_twk_fwd_mont, r->d_lastw, r->d_scratch, r->d_rowcnt, r->d_cl};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   rh_rescale_teardown(r);
   for (int i = 0; i < 2; ++i) if (r->d_rs[i]) (void)hipFree(r->d_rs[i]);
@@ -225,6 +225,13 @@ extern "C" int rh_ring_sync(rh_ring* r) {
   if (!r) return rh_fail(RH_ERR_ARG, "null ring");
   hipError_t e = hipStreamSynchronize(r->stream);
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "hipStreamSynchronize: %s", hipGetErrorString(e));
+  if (r->d_cl) {                          // single-pass transform: bounded hand-off waits report here
+    unsigned flag = 0;
+    if (hipMemcpy(&flag, r->d_cl + 8, sizeof(flag), hipMemcpyDeviceToHost) == hipSuccess && flag) {
+      (void)hipMemset(r->d_cl + 8, 0, sizeof(flag));
+      return rh_fail(RH_ERR_DEVICE, "single-pass NTT: a hand-off wait timed out (results of the last batch are invalid)");
+    }
+  }
   if (r->d_rowcnt) {                      // the persistent pipeline's bounded waits report here
     unsigned flag = 0;
     if (hipMemcpy(&flag, r->d_rowcnt + r->err_index, sizeof(flag), hipMemcpyDeviceToHost) == hipSuccess && flag) {
@@ -265,6 +272,17 @@ static int check_launch(const char* what) {
   return RH_OK;
 }
 
+template <class P>
+static void launch_fwd_cols2(int S1, dim3 grid, hipStream_t st, const u64* in, u64* out, const typename P::tw_t* tw,
+                             const LimbConsts* c, int L, int logN) {
+  switch (S1) {
+    case 1: ntt_fwd_cols2<P, 1><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
+    case 2: ntt_fwd_cols2<P, 2><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
+    case 3: ntt_fwd_cols2<P, 3><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
+    case 4: ntt_fwd_cols2<P, 4><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
+    case 5: ntt_fwd_cols<P, 5><<<dim3(grid.x * 2), 256, 0, st>>>(in, out, tw, c, L, logN); break;   // 64 coefficients/thread: keep one column
+  }
+}
 template <class P>
 static void launch_fwd_cols(int S1, dim3 grid, hipStream_t st, const u64* in, u64* out, const typename P::tw_t* tw,
                             const LimbConsts* c, int L, int logN) {
@@ -314,7 +332,8 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
       dim3 g1(rows * 16);
       if (phase != 2) {
         if (lazy) launch_fwd_cols<MontPolicy>(S1, g1, st, in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN);
-        else      launch_fwd_cols<ShoupPolicy>(S1, g1, st, in, out, r->d_tw_fwd + toff, c, Lrows, logN);
+        else if (r->cols2) launch_fwd_cols2<ShoupPolicy>(S1, dim3(rows * 8), st, in, out, r->d_tw_fwd + toff, c, Lrows, logN);
+      else      launch_fwd_cols<ShoupPolicy>(S1, g1, st, in, out, r->d_tw_fwd + toff, c, Lrows, logN);
       }
       src = out;
     }
@@ -337,7 +356,9 @@ template <int S1>
 static void launch_fused(rh_ring* r, const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n2, int npoly2,
                          size_t toff, const LimbConsts* c, int Lrows) {
   const unsigned grid = n1 > n2 ? n1 : n2;
-  if (r->asm_tile)
+  if (r->asm_tile && r->prefetch)
+    ntt_fwd_fused_pre<S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN);
+  else if (r->asm_tile)
     ntt_fwd_fused_asm<S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN, r->order_mix);
   else
     ntt_fwd_fused<ShoupPolicy, S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff,
@@ -426,7 +447,39 @@ static int std_ntt_inv_pipelined(rh_ring* r, const u64* in, u64* out, int npoly,
   return check_launch("ntt_inv_fused_asm");
 }
 
+// Single-pass forward transform (ntt_fwd_cluster).  Counters: [0,8) per-XCD ticket heads, [8] error word, [16, 16+rows) row counters.
+template <int S1>
+static int launch_cluster(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, size_t toff, const LimbConsts* c) {
+  const size_t rows = (size_t)npoly * Lrows;
+  if (r->cl_words < rows + 16) {
+    if (r->d_cl) (void)hipFree(r->d_cl);
+    r->d_cl = nullptr; r->cl_words = 0;
+    if (hipMalloc((void**)&r->d_cl, (rows + 16) * sizeof(unsigned)) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc(cluster counters) failed");
+    r->cl_words = rows + 16;
+  }
+  (void)hipMemsetAsync(r->d_cl, 0, (rows + 16) * sizeof(unsigned), r->stream);
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r->device) != hipSuccess || cus < 1) cus = 256;
+  unsigned grid = (unsigned)(cus * (r->cluster_wgs_per_cu > 0 ? r->cluster_wgs_per_cu : 4));
+  if (grid < 128) grid = 128;                      // >= 16 workgroups per XCD (progress condition)
+  ntt_fwd_cluster<S1><<<grid, 256, 0, r->stream>>>(in, out, (unsigned)rows, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN,
+                                                   r->d_cl, r->d_cl + 16, r->d_cl + 8, r->cluster_dbg);
+  return check_launch("ntt_fwd_cluster");
+}
+
 int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase) {
+  if (r->cluster && r->logN > LT && phase == 0 && !inverse && !lazy && npoly >= 1) {
+    (void)hipGetLastError();
+    const size_t toff = (size_t)limb0 * r->N;
+    const LimbConsts* c = r->d_consts + limb0;
+    switch (r->logN - LT) {
+      case 1: return launch_cluster<1>(r, in, out, npoly, Lrows, toff, c);
+      case 2: return launch_cluster<2>(r, in, out, npoly, Lrows, toff, c);
+      case 3: return launch_cluster<3>(r, in, out, npoly, Lrows, toff, c);
+      case 4: return launch_cluster<4>(r, in, out, npoly, Lrows, toff, c);
+      case 5: return launch_cluster<5>(r, in, out, npoly, Lrows, toff, c);
+    }
+  }
   if (r->persistent && r->logN > LT && phase == 0 && !inverse && !lazy && npoly >= 1) {
     (void)hipGetLastError();
     const size_t toff = (size_t)limb0 * r->N;
@@ -505,12 +558,33 @@ extern "C" int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in, uint64_t* out, 
   if (phase < 0 || phase > 2) return rh_fail(RH_ERR_ARG, "phase must be 0, 1 or 2");
   return ntt_batch(r, in, out, npoly, level, inverse != 0, false, phase);
 }
+// debugging aid (not part of the documented ABI surface): dry run of the single-pass ticket schedule
+extern "C" int rh_debug_cluster_dryrun(rh_ring* r, int npoly, int Lrows, unsigned* out_host, unsigned cap) {
+  if (!r || !out_host) return rh_fail(RH_ERR_ARG, "null");
+  (void)hipSetDevice(r->device);
+  unsigned *d_head = nullptr, *d_dbg = nullptr;
+  const size_t words = 8 + 8 * (size_t)cap;
+  if (hipMalloc((void**)&d_head, 64) != hipSuccess || hipMalloc((void**)&d_dbg, words * 4) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc");
+  (void)hipMemset(d_head, 0, 64); (void)hipMemset(d_dbg, 0, words * 4);
+  ntt_cluster_dryrun<<<1024, 256, 0, r->stream>>>((unsigned)npoly * Lrows, Lrows, d_head, d_dbg, cap);
+  hipError_t e = hipStreamSynchronize(r->stream);
+  if (e == hipSuccess) e = hipMemcpy(out_host, d_dbg, words * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d_head); (void)hipFree(d_dbg);
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "dryrun: %s", hipGetErrorString(e));
+  return RH_OK;
+}
+
 extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
   if (!r || !key) return rh_fail(RH_ERR_ARG, "set_tuning: null argument");
   if (!strcmp(key, "chunk_polys")) { r->chunk_polys = (int)value; return RH_OK; }
   if (!strcmp(key, "asm_tile")) { r->asm_tile = value != 0; return RH_OK; }
+  if (!strcmp(key, "prefetch")) { r->prefetch = (int)value; return RH_OK; }
   if (!strcmp(key, "order_mix")) { r->order_mix = (int)value; return RH_OK; }
+  if (!strcmp(key, "cols2")) { r->cols2 = (int)value; return RH_OK; }
   if (!strcmp(key, "persistent")) { r->persistent = value != 0; return RH_OK; }
+  if (!strcmp(key, "cluster")) { r->cluster = value != 0; return RH_OK; }
+  if (!strcmp(key, "cluster_dbg")) { r->cluster_dbg = (int)value; return RH_OK; }
+  if (!strcmp(key, "cluster_wgs_per_cu")) { r->cluster_wgs_per_cu = (int)value; return RH_OK; }
   if (!strcmp(key, "group_polys")) { if (value < 1) return rh_fail(RH_ERR_ARG, "group_polys must be >= 1"); r->group_polys = (int)value; return RH_OK; }
   if (!strcmp(key, "persist_grid")) { r->persist_grid = (int)value; return RH_OK; }
   if (!strcmp(key, "persist_unsafe_timing")) { r->persist_unsafe = (int)value; return RH_OK; }   // timing experiments only

@@ -33,11 +33,17 @@ struct rh_ring {
   rh_ring3n_state* s3n = nullptr;
   std::vector<void*> rescale_tables;      // per level, rescale.hip
   u64* d_rs[2] = {nullptr, nullptr}; size_t rs_words[2] = {0, 0};
+  bool cluster = false;           // single-pass forward transform through the XCD L2 (ntt_fwd_cluster)
+  int cluster_wgs_per_cu = 4;
+  int cluster_dbg = 0;            // debugging: bit 0 skips the column stages, bit 1 the tile stages
+  unsigned* d_cl = nullptr; size_t cl_words = 0;
   bool persistent = false;        // single-launch pipelined forward transform (ntt_fwd_persistent)
   int group_polys = 8;            // polys per pipeline group of the persistent kernel
   int persist_unsafe = 0;         // timing experiments only: plain stores and no acquire in the hand-off
   int persist_grid = 0;           // resident workgroups (0 = query)
   unsigned* d_rowcnt = nullptr; size_t rowcnt_words = 0, err_index = 0;
+  int cols2 = 0;                  // column kernel: two adjacent columns per thread (16 B per lane)
+  int prefetch = 0;               // fused forward launch: issue the tile loads ahead of the column stages (ntt_fwd_fused_pre); measured: no gain
   int order_mix = 0;              // fused forward launch: alternate (cols, tile) / (tile, cols) order between CU slots
   bool asm_tile = true;           // forward tile kernel: hand-scheduled body (ntt_kernels_asm.cuh) vs the C++ one
   bool inv_scale = true;          // false: inverse leaves values < 4q without the N^-1 factor (3N sub-transform)

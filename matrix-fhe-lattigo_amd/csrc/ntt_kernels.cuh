@@ -257,6 +257,50 @@ ntt_fwd_cols(const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
              const LimbConsts* __restrict__ consts, int L, int logN) {
   fwd_cols_body<P, S1>(blockIdx.x, in, out, twn, consts, L, logN);
 }
+// two adjacent columns per thread: every global access is 16 B per lane (1 KiB per wave instruction)
+template <class P, int S1>
+RH_DEV void fwd_cols2_body(const u32 b, const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
+                           const LimbConsts* __restrict__ consts, int L, int logN) {
+  constexpr int R = 1 << S1;
+  const u32 limb = b % (u32)L;
+  const u32 r = b / (u32)L;
+  const u32 cb = r & 7;             // 8 blocks of 512 columns per limb
+  const u32 poly = r >> 3;
+  const size_t base = (((size_t)poly * L + limb) << logN) + cb * 512 + 2 * threadIdx.x;
+  const typename P::tw_t* tw = twn + ((size_t)limb << logN);
+  P p; p.init(consts[limb]);
+  u64 x[R], y[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(in + base + ((size_t)k << LT));
+    x[k] = v.x; y[k] = v.y;
+  }
+#pragma unroll
+  for (int s = 0; s < S1; ++s) {
+    const int h = R >> (s + 1);
+    const bool red = ref_reduce(s, logN);
+#pragma unroll
+    for (int g = 0; g < (1 << s); ++g) {
+      typename P::tw_t w = tw[(1 << s) + g];
+#pragma unroll
+      for (int e = 0; e < h; ++e) {
+        p.fwd(x[g * 2 * h + e], x[g * 2 * h + e + h], w, red);
+        p.fwd(y[g * 2 * h + e], y[g * 2 * h + e + h], w, red);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    ulonglong2 v; v.x = x[k]; v.y = y[k];
+    *reinterpret_cast<ulonglong2*>(out + base + ((size_t)k << LT)) = v;
+  }
+}
+template <class P, int S1>
+__global__ void __launch_bounds__(256)
+ntt_fwd_cols2(const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
+              const LimbConsts* __restrict__ consts, int L, int logN) {
+  fwd_cols2_body<P, S1>(blockIdx.x, in, out, twn, consts, L, logN);
+}
 // Fused launch of a software pipeline over spans of polys: the workgroup first runs the (HBM-bound) column stages of
 // one unit of span j, then the (VALU-bound) tile stages of one tile of span j-1, so that on every CU memory-phase and
 // compute-phase workgroups are co-resident.  n1/n2 = number of column units / tiles in this launch.

@@ -299,7 +299,7 @@ def csub_all(const_name):
             emit("v_bfi_b32 v%d, v%d, v%d, v%d" % (X(kk) + 1, t.M, X(kk) + 1, t.T + 1))
 
 
-def gen():
+def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True):
     A0, A1, A2, A3 = ADDR, ADDR + 1, ADDR + 2, ADDR + 3
     emit("; ---- prologue: zero halves of the zero-extended pairs, addresses")
     for t in (T0, T1):
@@ -313,9 +313,11 @@ def gen():
     for j in range(4):
         emit("v_add_u32 v%d, %d, v%d" % (SCR + j, 8192 * j + 4096, A0))
     for kk in range(16):
+        if preloaded:
+            break                                             # x[k] already sits in v[2k:2k+1] (loaded by the caller)
         k = (kk >> 1) + 8 * (kk & 1)
         j, rem = divmod(k, 4)
-        emit("global_load_dwordx2 %s, v%d, %%[pin] offset:%d" % (pair(X(k)), SCR + j, rem * 2048 - 4096))
+        emit("global_load_dwordx2 %s, v%d, %%[pin] offset:%d%s" % (pair(X(k)), SCR + j, rem * 2048 - 4096, load_flags))
     # round B twiddles: tw[16 + slot*16 + hi4] -> byte (16+16*slot)*16 + hi4*16
     emit("v_lshrrev_b32 v%d, 4, %%[tid]" % A1)                # hi4
     emit("v_lshlrev_b32 v%d, 4, v%d" % (A2, A1))              # hi4*16 bytes
@@ -333,7 +335,7 @@ def gen():
 
     def a_pair_hook(u, i):
         # stage 0, butterflies i and i+1 consume data loads 0 .. 2*i+3 of the 31 issued (16 data then 15 twiddle quads)
-        if u == 0:
+        if u == 0 and not preloaded:
             emit("s_waitcnt vmcnt(%d)" % (31 - (2 * i + 4)))
     round16(lambda slot: (None, ("s%d" % (36 + 4 * slot), "s%d" % (37 + 4 * slot), "s%d" % (38 + 4 * slot), "s%d" % (39 + 4 * slot))),
             pair_hook=a_pair_hook)
@@ -386,8 +388,9 @@ def gen():
     for k in range(16):
         j, rem = divmod(k, 4)
         emit("s_waitcnt lgkmcnt(%d)" % (15 - k))
-        emit("global_store_dwordx2 v%d, %s, %%[pout] offset:%d" % (SCR + j, pair(X(k)), rem * 2048 - 4096))
-    emit("s_waitcnt vmcnt(0)")
+        emit("global_store_dwordx2 v%d, %s, %%[pout] offset:%d%s" % (SCR + j, pair(X(k)), rem * 2048 - 4096, store_flags))
+    if tail_wait:
+        emit("s_waitcnt vmcnt(0)")
 
 
 
@@ -399,13 +402,21 @@ def render(name, lines):
 gen()
 fwd = list(out)
 del out[:]
+gen(load_flags=" sc1")          # data loads bypass L1 (served by the XCD's L2): in-launch hand-off of ntt_fwd_cluster
+fwd_sc1 = list(out)
+del out[:]
+gen(preloaded=True, tail_wait=False)   # fused launch: the caller issued the data loads ahead of its column stages
+fwd_pre = list(out)
+del out[:]
 gen_inverse()
 inv = list(out)
 clob_v = ", ".join('"v%d"' % i for i in range(NVGPR_USED))
 clob_s = ", ".join('"s%d"' % i for i in range(36, 102))
 text = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  forward: %d instructions, inverse: %d.\n" % (len(fwd), len(inv))
-text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_INV_ASM_BODY", inv)
-text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"memory\"\n" % (clob_v, clob_s)
+text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_SC1_ASM_BODY", fwd_sc1) + render("NTT_TILE_PRE_ASM_BODY", fwd_pre) + render("NTT_TILE_INV_ASM_BODY", inv)
+text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v, clob_s)
+clob_v_pre = ", ".join('"v%d"' % i for i in range(32, NVGPR_USED))     # v0..v31 are read-write operands there
+text += "#define NTT_TILE_PRE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v_pre, clob_s)
 path = sys.argv[1] if len(sys.argv) > 1 else "ntt_tile_asm.inc"
 open(path, "w").write(text)
 print("wrote", path, "forward:", len(fwd), "VALU", sum(1 for l in fwd if l.startswith("v_")), "| inverse:", len(inv), "VALU", sum(1 for l in inv if l.startswith("v_")))
