@@ -1,0 +1,87 @@
+"""Scheme-level callers of the ring hot path for BASELINE configs 3 and 4: the *sequences* of ring calls the reference's
+evaluators issue, on device-resident batches.  Nothing here computes: every step is a Ring method (HIP kernels behind
+the C ABI).  No key material, encoders or encryptors -- those stay with the reference.
+
+* ``MatrixCKKSEvaluator.Mul``  schemes/matrix_ckks/evaluator.go:114-192   (config 4, 3N ring)
+* ``ckks_tensor_degree1``      schemes/ckks/evaluator.go:821-834          (config 3 / first half of MulRelin)
+"""
+from .ringhip import RingHipError
+
+
+class Ciphertext:
+    """rlwe.Ciphertext as far as the evaluator reads it: Value[0..degree] (DevicePoly batches of equal shape),
+    IsNTT and the level (= limbs - 1).  A batch of B ciphertexts is one Ciphertext whose polys have npoly = B."""
+
+    def __init__(self, value, is_ntt=False):
+        self.Value = list(value)
+        self.IsNTT = bool(is_ntt)
+
+    def Degree(self):
+        return len(self.Value) - 1
+
+    def Level(self):
+        return self.Value[0].limbs - 1
+
+
+class MatrixCKKSEvaluator:
+    """schemes/matrix_ckks/evaluator.go: Evaluator over the 3N ring Z_Q[X]/(X^N - X^{N/2} + 1)."""
+
+    def __init__(self, ringQ):
+        self.ringQ = ringQ
+
+    def Mul(self, ct0, ct1, ctOut):
+        """evaluator.go:114-192.  Reproduced as written, including its two side effects: inputs not yet in the NTT
+        domain are transformed IN PLACE and their IsNTT flips (:136-149), and the products are MulCoeffsMontgomery
+        on operands that were never put in Montgomery form (no MForm), so every output coefficient carries a factor
+        2^-64 mod q_i.  The output is returned in the coefficient domain (:182-189)."""
+        if ct0.Level() != ct1.Level():
+            raise RingHipError("ciphertexts must be at the same level for multiplication")
+        d0, d1 = ct0.Degree(), ct1.Degree()
+        if d0 > 1 or d1 > 1:
+            raise RingHipError("unsupported ciphertext degrees for multiplication: %d, %d" % (d0, d1))
+        if ctOut.Degree() != d0 + d1:
+            raise RingHipError("ctOut must have degree %d" % (d0 + d1))
+        rq = self.ringQ.AtLevel(ct0.Level())
+        for ct in (ct0, ct1):
+            if not ct.IsNTT:
+                for v in ct.Value:
+                    rq.NTT(v, v)
+                ct.IsNTT = True
+        a, b, o = ct0.Value, ct1.Value, ctOut.Value
+        if d0 == 0 and d1 == 0:
+            rq.MulCoeffsMontgomery(a[0], b[0], o[0])
+        elif d0 == 0 and d1 == 1:
+            rq.MulCoeffsMontgomery(a[0], b[0], o[0])
+            rq.MulCoeffsMontgomery(a[0], b[1], o[1])
+        elif d0 == 1 and d1 == 0:
+            rq.MulCoeffsMontgomery(a[0], b[0], o[0])
+            rq.MulCoeffsMontgomery(a[1], b[0], o[1])
+        else:
+            rq.MulCoeffsMontgomery(a[0], b[0], o[0])
+            rq.MulCoeffsMontgomery(a[0], b[1], o[1])
+            rq.MulCoeffsMontgomeryThenAdd(a[1], b[0], o[1])
+            rq.MulCoeffsMontgomery(a[1], b[1], o[2])
+        for v in o:
+            rq.INTT(v, v)
+        ctOut.IsNTT = False
+
+
+def ckks_tensor_degree1(ringQ, ct0, ct1, c0, c1, c2, c00, c01):
+    """schemes/ckks/evaluator.go:821-834 (degree-1 x degree-1 tensoring of mulRelin; all operands in the NTT domain):
+    c00 = MForm(ct0[0]); c01 = MForm(ct0[1]); c0 = c00*ct1[0]; c1 = c00*ct1[1] + c01*ct1[0]; c2 = c01*ct1[1]."""
+    ringQ.MForm(ct0.Value[0], c00)
+    ringQ.MForm(ct0.Value[1], c01)
+    ringQ.MulCoeffsMontgomery(c00, ct1.Value[0], c0)
+    ringQ.MulCoeffsMontgomery(c00, ct1.Value[1], c1)
+    ringQ.MulCoeffsMontgomeryThenAdd(c01, ct1.Value[0], c1)
+    ringQ.MulCoeffsMontgomery(c01, ct1.Value[1], c2)
+
+
+def ckks_polymul(ringQ, a, b, c, tmp):
+    """BASELINE config 3: c = INTT(NTT(a) . NTT(b)) with MForm + MulCoeffsMontgomery as mulRelin sequences it
+    (schemes/ckks/evaluator.go:821-834).  a and b are transformed in place (they end in the NTT domain)."""
+    ringQ.NTT(a, a)
+    ringQ.NTT(b, b)
+    ringQ.MForm(a, tmp)
+    ringQ.MulCoeffsMontgomery(tmp, b, c)
+    ringQ.INTT(c, c)

@@ -1,0 +1,162 @@
+"""Scheme-level callers (BASELINE configs 3 and 4) through the C ABI: the evaluators' call sequences on device batches.
+matrix_ckks.Evaluator.Mul has no reference test: end-to-end parity is UNPINNED by the reference; it is
+checked here against (a) the same sequence on the CPU oracle, whose pieces are pinned, and (b) the ring's product rule
+X^N = X^(N/2) - 1 with the 2^-64 factor the reference's missing MForm leaves in (ring/ntt_3n_test.go:312-364)."""
+import numpy as np
+import pytest
+
+from conftest import QI60, uniform_mod
+from test_oracle_ntt3n import find_prime_3n, omega_for, naive_mul_3n
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rh():
+    import matrix_fhe_lattigo_amd as m
+    return m
+
+
+def primes_3n(oracle, N, n, bits=60):
+    q = find_prime_3n(N, bits)
+    out = []
+    while len(out) < n:
+        out.append(q)
+        q += 3 * N
+        while not oracle.lib().orc_is_prime(q):
+            q += 3 * N
+    return out
+
+
+def oracle_mul_3n(oracle, a0, a1, b0, b1, mods, N):
+    """evaluator.go:114-192 on the oracle: per limb 3N NTT, MulCoeffsMontgomery x3 + ThenAdd, inverse 3N NTT"""
+    OPS = __import__("matrix_fhe_lattigo_amd").OPS
+    out = [np.zeros_like(a0) for _ in range(3)]
+    for i, q in enumerate(mods):
+        om = omega_for(q, N)
+        f = lambda x: oracle.ntt3n_forward(x, q, om)
+        A0, A1, B0, B1 = f(a0[i]), f(a1[i]), f(b0[i]), f(b1[i])
+        z = np.zeros(N, dtype=np.uint64)
+        c0 = oracle.vec_op(OPS["MUL_MONT"], A0, B0, z, 0, 0, q)
+        c1 = oracle.vec_op(OPS["MUL_MONT"], A0, B1, z, 0, 0, q)
+        c1 = oracle.vec_op(OPS["MUL_MONT_THEN_ADD"], A1, B0, c1, 0, 0, q)
+        c2 = oracle.vec_op(OPS["MUL_MONT"], A1, B1, z, 0, 0, q)
+        for o, c in zip(out, (c0, c1, c2)):
+            o[i] = oracle.ntt3n_backward(c, q, om)
+    return out
+
+
+@pytest.mark.parametrize("N,B", [(48, 3), (3 * 1024, 2)])
+def test_matrix_ckks_mul_degree1(rh, oracle, N, B):
+    mods = primes_3n(oracle, N, 2)
+    ring = rh.Ring(N, mods, kind=rh.Matrix3N, omega3n=[omega_for(q, N) for q in mods])
+    rng = np.random.default_rng(N + B)
+    mk = lambda: np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    a0, a1, b0, b1 = mk(), mk(), mk(), mk()
+    ct0 = rh.Ciphertext([rh.DevicePoly.from_numpy(ring, a0), rh.DevicePoly.from_numpy(ring, a1)])
+    ct1 = rh.Ciphertext([rh.DevicePoly.from_numpy(ring, b0), rh.DevicePoly.from_numpy(ring, b1)])
+    out = rh.Ciphertext([ring.NewPoly(B) for _ in range(3)])
+    ev = rh.MatrixCKKSEvaluator(ring)
+    ev.Mul(ct0, ct1, out)
+    assert ct0.IsNTT and ct1.IsNTT and not out.IsNTT            # the reference's side effects (:136-149, :189)
+    got = [v.numpy() for v in out.Value]
+    for k in range(B):
+        exp = oracle_mul_3n(oracle, a0[k], a1[k], b0[k], b1[k], mods, N)
+        for c in range(3):
+            assert np.array_equal(got[c][k], exp[c]), (k, c)
+    # inputs were transformed in place
+    assert np.array_equal(ct0.Value[1].numpy()[0, 1], oracle.ntt3n_forward(a1[0, 1], mods[1], omega_for(mods[1], N)))
+    if N <= 96:                                                  # product rule with the 2^-64 factor
+        for i, q in enumerate(mods):
+            rinv = pow(1 << 64, -1, q)
+            A0, A1, B0, B1 = ([int(v) for v in x[0, i]] for x in (a0, a1, b0, b1))
+            e0 = naive_mul_3n(A0, B0, q, N)
+            e1 = [(x + y) % q for x, y in zip(naive_mul_3n(A0, B1, q, N), naive_mul_3n(A1, B0, q, N))]
+            e2 = naive_mul_3n(A1, B1, q, N)
+            for c, e in enumerate((e0, e1, e2)):
+                assert [int(v) for v in got[c][0, i]] == [(v * rinv) % q for v in e]
+    # second call with inputs already in the NTT domain: same result, inputs untouched
+    keep = ct0.Value[0].numpy().copy()
+    out2 = rh.Ciphertext([ring.NewPoly(B) for _ in range(3)])
+    ev.Mul(ct0, ct1, out2)
+    assert np.array_equal(ct0.Value[0].numpy(), keep)
+    for c in range(3):
+        assert np.array_equal(out2.Value[c].numpy(), got[c])
+    ring.close()
+
+
+def test_matrix_ckks_mul_mixed_degrees_and_errors(rh, oracle):
+    N, B = 96, 2
+    mods = primes_3n(oracle, N, 2)
+    ring = rh.Ring(N, mods, kind=rh.Matrix3N, omega3n=[omega_for(q, N) for q in mods])
+    rng = np.random.default_rng(9)
+    mk = lambda: np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    a0, b0, b1 = mk(), mk(), mk()
+    ev = rh.MatrixCKKSEvaluator(ring)
+    ct0 = rh.Ciphertext([rh.DevicePoly.from_numpy(ring, a0)])
+    ct1 = rh.Ciphertext([rh.DevicePoly.from_numpy(ring, b0), rh.DevicePoly.from_numpy(ring, b1)])
+    out = rh.Ciphertext([ring.NewPoly(B), ring.NewPoly(B)])
+    ev.Mul(ct0, ct1, out)                                       # degree 0 x degree 1 (:155-158)
+    for i, q in enumerate(mods):
+        rinv = pow(1 << 64, -1, q)
+        A0, B0, B1 = ([int(v) for v in x[1, i]] for x in (a0, b0, b1))
+        assert [int(v) for v in out.Value[0].numpy()[1, i]] == [(v * rinv) % q for v in naive_mul_3n(A0, B0, q, N)]
+        assert [int(v) for v in out.Value[1].numpy()[1, i]] == [(v * rinv) % q for v in naive_mul_3n(A0, B1, q, N)]
+    with pytest.raises(rh.RingHipError):                        # level mismatch (:116-118)
+        ev.Mul(ct0, rh.Ciphertext([ring.AtLevel(0).NewPoly(B)]), out)
+    with pytest.raises(rh.RingHipError):                        # degree 2 input (:174-176)
+        ev.Mul(rh.Ciphertext([ring.NewPoly(B) for _ in range(3)]), ct1, rh.Ciphertext([ring.NewPoly(B) for _ in range(4)]))
+    ring.close()
+
+
+def test_config4_size_mul_bilinear(rh, oracle):
+    # config 4 ring N = 3*2^16 (2 of the 24 limbs, batch 2): Mul is bilinear -- Mul(x + x', y) = Mul(x, y) + Mul(x', y)
+    N, B = 3 << 16, 2
+    mods = primes_3n(oracle, N, 2)
+    ring = rh.Ring(N, mods, kind=rh.Matrix3N)
+    rng = np.random.default_rng(44)
+    mk = lambda: np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    x0, x1, xp0, xp1, y0, y1 = mk(), mk(), mk(), mk(), mk(), mk()
+    dp = lambda a: rh.DevicePoly.from_numpy(ring, a)
+    ev = rh.MatrixCKKSEvaluator(ring)
+
+    def mul(u0, u1):
+        o = rh.Ciphertext([ring.NewPoly(B) for _ in range(3)])
+        ev.Mul(rh.Ciphertext([dp(u0), dp(u1)]), rh.Ciphertext([dp(y0), dp(y1)]), o)
+        return o
+    r1, r2 = mul(x0, x1), mul(xp0, xp1)
+    s0, s1 = dp(x0), dp(x1)
+    ring.Add(s0, dp(xp0), s0); ring.Add(s1, dp(xp1), s1)
+    rs = rh.Ciphertext([ring.NewPoly(B) for _ in range(3)])
+    ev.Mul(rh.Ciphertext([s0, s1]), rh.Ciphertext([dp(y0), dp(y1)]), rs)
+    for c in range(3):
+        ring.Add(r1.Value[c], r2.Value[c], r1.Value[c])
+        assert np.array_equal(rs.Value[c].numpy(), r1.Value[c].numpy())
+    ring.close()
+
+
+def test_config3_polymul(rh, oracle):
+    # config 3: N = 2^15, 16 limbs, c = INTT(NTT(a) . NTT(b)) as mulRelin sequences it; X^i * X^j = -X^(i+j-N) wraps
+    N, L, B = 1 << 15, 16, 3
+    mods = QI60[:L]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(3)
+    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    b = np.zeros_like(a)
+    b[:, :, 1] = 1                                               # multiply by X: negacyclic shift
+    b[1, :, 1] = 0; b[1, :, N - 1] = 5                           # poly 1: multiply by 5 X^(N-1)
+    pa, pb, pc, tmp = (rh.DevicePoly.from_numpy(ring, a), rh.DevicePoly.from_numpy(ring, b), ring.NewPoly(B), ring.NewPoly(B))
+    rh.ckks_polymul(ring, pa, pb, pc, tmp)
+    got = pc.numpy()
+    for i, q in enumerate(mods):
+        q = int(q)
+        e0 = np.roll(a[0, i], 1); e0[0] = (q - int(e0[0])) % q
+        assert np.array_equal(got[0, i], e0)
+        e1 = np.roll(a[1, i], -1).astype(object) * 5 % q        # X^(N-1) * X^j = -X^(j-1) for j >= 1, X^(N-1) for j = 0
+        e1 = np.array([(q - int(v)) % q for v in e1], dtype=np.uint64)
+        e1[N - 1] = (5 * int(a[1, i, 0])) % q
+        assert np.array_equal(got[1, i], e1)
+    # one limb of the dense product against the oracle sequence
+    sr = oracle.SubRingConsts(N, mods[2])
+    assert np.array_equal(pa.numpy()[2, 2], oracle.ntt(a[2, 2], sr))
+    ring.close()
