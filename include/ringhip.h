@@ -144,6 +144,30 @@ int rh_bext_decompose_and_split(rh_bext* be, int levelQ, int levelP, int nbPi, i
 int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const uint64_t* cx_dev, const uint64_t* evkQ_dev,
                            const uint64_t* evkP_dev, int beta_key, uint64_t* ct0_dev, uint64_t* ct1_dev, int npoly);
 
+/* ---- limb-sharded hybrid key switch (BASELINE config 5): one process per GPU owns a subset of the limbs
+ * of Q and P and the matching slice of the evaluation key.  Same arithmetic as rh_bext_gadget_product, cut where
+ * reconstructRNS (ring/basis_extension.go:550-594) needs limbs of other owners; the exchange (an all-gather of the
+ * digit's source limbs, and of the P part before ModDown) is the caller's -- RCCL through torch.distributed in
+ * matrix-fhe-lattigo_amd/sharding.py -- and this library never communicates.
+ * ringQ_loc / ringP_loc: rings over the OWNED moduli only, ascending global order (ringP_loc NULL iff nownP == 0);
+ * allQ / allP: moduli 0..levelQ / 0..levelP of the full chain; ownQ / ownP: global indices of the owned limbs.
+ * Local blocks are (poly, owned limb, N); gathered source blocks are (poly, source limb in global order, N). */
+typedef struct rh_kshard rh_kshard;
+int rh_kshard_create(rh_kshard** out, rh_ring* ringQ_loc, rh_ring* ringP_loc, const uint64_t* allQ, int levelQ,
+                     const uint64_t* allP, int levelP, const int* ownQ, int nownQ, const int* ownP, int nownP);
+void rh_kshard_destroy(rh_kshard* ks);
+int rh_kshard_num_digits(const rh_kshard* ks);                             /* core/rlwe/params.go:635-642 */
+int rh_kshard_digit_range(const rh_kshard* ks, int digit, int* st, int* ed); /* global limbs [st, ed) of the digit */
+/* one digit of gadgetProductMultiplePLazy (core/rlwe/evaluator_gadget_product.go:154-187, DecomposeSingleNTT :455-478)
+ * for the owned limbs.  src_dev: limbs [st, ed) of INTT(cx) gathered from their owners; cx_loc: owned limbs of the
+ * NTT-domain input; evkQ_loc / evkP_loc: [digit][component < 2][owned limb][N].  Feed digits 0 .. beta-1 in order. */
+int rh_kshard_digit(rh_kshard* ks, int digit, const uint64_t* src_dev, const uint64_t* cx_loc, const uint64_t* evkQ_loc,
+                    const uint64_t* evkP_loc, uint64_t* ct0_loc, uint64_t* ct1_loc, uint64_t* accP0_loc, uint64_t* accP1_loc,
+                    int npoly);
+/* ModDownQPtoQNTT (ring/basis_extension.go:241-258) for the owned Q limbs.  srcP_dev: (npoly, levelP+1, N), the
+ * INTTLazy of the P part gathered from its owners. */
+int rh_kshard_moddown(rh_kshard* ks, const uint64_t* srcP_dev, const uint64_t* ctQ_in_loc, uint64_t* ctQ_out_loc, int npoly);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,20 +17,8 @@
 #include <array>
 #include <cstring>
 #include "engine_internal.hpp"
+#include "bext_internal.hpp"
 #include "hostmath.hpp"
-
-struct BextSource { u64 q, qinv, qstar_inv /* ((Q/q_i)^-1) Montgomery form */, half /* floor(Q/2) mod q_i */; };
-struct BextTarget {
-  u64 p, pinv;
-  u64 half;        // floor(Q/2) mod p (centred subtraction), used when post >= 1
-  u64 md_scalar;   // ModDown: p - (P^-1 mod p) in Montgomery form, used when post == 2
-  int buf;         // 0 / 1: which output block
-  int limb;        // limb row inside that block
-  int post;        // 0 none, 1 CRed(x + p - half), 2 = 1 then MRed(2p - other + x, md_scalar)
-  int skip;        // 1: no extension for this limb (digit limbs of DecomposeAndSplit); post 1 applies to prior content
-};
-
-enum { BEXT_ADD_NONE = 0, BEXT_ADD_CRED = 1, BEXT_ADD_RAW = 2 };
 
 __global__ void __launch_bounds__(256)
 bext_kernel(const u64* in, int in_rows, int src_limb0, int nsrc, const BextSource* __restrict__ S,
@@ -85,7 +73,6 @@ bext_kernel(const u64* in, int in_rows, int src_limb0, int nsrc, const BextSourc
 }
 
 // DecomposeAndSplit, single-prime digit (decompLvl < 0): sign-aware copy/reduce into every limb (:402-436)
-struct SignTarget { u64 p, bred0; int buf, limb; };
 __global__ void __launch_bounds__(256)
 bext_sign_copy_kernel(const u64* in, int in_rows, int src_limb, u64 qd, int ntgt, const SignTarget* __restrict__ T,
                       u64* out0, int out0_rows, u64* out1, int out1_rows, int N) {
@@ -107,12 +94,6 @@ bext_sign_copy_kernel(const u64* in, int in_rows, int src_limb, u64 qd, int ntgt
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-struct BextPlan {
-  int nsrc = 0, ntgt = 0;
-  BextSource* d_S = nullptr; BextTarget* d_T = nullptr; u64* d_coef = nullptr; u64* d_vt = nullptr;
-  SignTarget* d_sign = nullptr; u64 qd = 0;      // single-prime digit plan
-};
-
 struct rh_bext {
   rh_ring* Q = nullptr; rh_ring* P = nullptr;
   std::map<std::array<int, 5>, BextPlan> plans;
@@ -361,4 +342,46 @@ extern "C" int rh_bext_decompose_and_split(rh_bext* be, int levelQ, int levelP, 
     return RH_OK;
   }
   return launch_plan(be, p, p0Q, levelQ + 1, st, p1Q, levelQ + 1, p1P, nP, nullptr, 0, npoly, BEXT_ADD_RAW);
+}
+
+// ---- internals shared with kshard.hip (bext_internal.hpp) ----
+u64 rh_half_product_mod(const std::vector<u64>& M, u64 m) { return half_product_mod(M, m); }
+void rh_gen_modup(const std::vector<u64>& Qs, const std::vector<u64>& tg, std::vector<u64>& qstar_inv_mont, std::vector<u64>& coef,
+                  std::vector<u64>& vt) { gen_modup(Qs, tg, qstar_inv_mont, coef, vt); }
+u64 rh_moddown_const(const std::vector<u64>& Ps, u64 qi) { return moddown_const(Ps, qi); }
+int rh_bext_upload_plan(BextPlan& p, const std::vector<BextSource>& S, const std::vector<BextTarget>& T, const std::vector<u64>& coef,
+                        const std::vector<u64>& vt) {
+  p.nsrc = (int)S.size(); p.ntgt = (int)T.size();
+  int rc = upv(&p.d_S, S); if (!rc) rc = upv(&p.d_T, T); if (!rc) rc = upv(&p.d_coef, coef); if (!rc) rc = upv(&p.d_vt, vt);
+  return rc;
+}
+int rh_bext_upload_sign_plan(BextPlan& p, const std::vector<SignTarget>& T, u64 qd) {
+  p.ntgt = (int)T.size(); p.qd = qd;
+  return upv(&p.d_sign, T);
+}
+void rh_bext_free_plan(BextPlan& p) {
+  void* ptrs[] = {p.d_S, p.d_T, p.d_coef, p.d_vt, p.d_sign};
+  for (void* q : ptrs) if (q) (void)hipFree(q);
+  p = BextPlan();
+}
+int rh_bext_launch_raw(hipStream_t st, int N, const BextPlan& p, const u64* in, int in_rows, int src_limb0, u64* out0, int out0_rows,
+                       u64* out1, int out1_rows, const u64* other, int other_rows, int npoly, int add_mode) {
+  if (npoly <= 0 || p.ntgt == 0) return RH_OK;
+  dim3 grid((N + 255) / 256, npoly);
+  (void)hipGetLastError();
+  bext_kernel<<<grid, 256, (size_t)p.nsrc * 256 * 8, st>>>(in, in_rows, src_limb0, p.nsrc, p.d_S, p.ntgt, p.d_T, p.d_coef, p.d_vt,
+                                                          out0, out0_rows, out1, out1_rows, other, other_rows, N, add_mode);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "bext_kernel launch failed: %s", hipGetErrorString(e));
+  return RH_OK;
+}
+int rh_bext_launch_sign(hipStream_t st, int N, const BextPlan& p, const u64* in, int in_rows, int src_limb, u64* out0, int out0_rows,
+                        u64* out1, int out1_rows, int npoly) {
+  if (npoly <= 0 || p.ntgt == 0) return RH_OK;
+  dim3 grid((N + 255) / 256, npoly);
+  (void)hipGetLastError();
+  bext_sign_copy_kernel<<<grid, 256, 0, st>>>(in, in_rows, src_limb, p.qd, p.ntgt, p.d_sign, out0, out0_rows, out1, out1_rows, N);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "bext_sign_copy_kernel launch failed: %s", hipGetErrorString(e));
+  return RH_OK;
 }

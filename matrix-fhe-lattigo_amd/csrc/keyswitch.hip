@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <vector>
 #include "engine_internal.hpp"
+#include "bext_internal.hpp"
 
 // acc_c[row] (=|+=) MRedLazy(evk_c[limb], c2[row]) for c = 0,1.  rows = npoly * L; evk is shared by every poly.
 __global__ void __launch_bounds__(256)
@@ -35,7 +36,7 @@ gadget_mac_kernel(const u64* c2, const u64* __restrict__ evk0, const u64* __rest
   }
 }
 
-static int mac(rh_ring* r, const u64* c2, const u64* e0, const u64* e1, u64* a0, u64* a1, int npoly, int L, int first) {
+int rh_gadget_mac(rh_ring* r, const u64* c2, const u64* e0, const u64* e1, u64* a0, u64* a1, int npoly, int L, int first) {
   const unsigned rows = (unsigned)npoly * L, n = (unsigned)r->N;
   unsigned chunks = (n / 2 + 1023) / 1024; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
   gadget_mac_kernel<<<dim3(rows, chunks), 256, 0, r->stream>>>(c2, e0, e1, a0, a1, n, r->d_consts, L, first);
@@ -44,7 +45,7 @@ static int mac(rh_ring* r, const u64* c2, const u64* e0, const u64* e1, u64* a0,
   return RH_OK;
 }
 
-static int overflow_margin(const std::vector<u64>& m, int level) {     // QiOverflowMargin / PiOverflowMargin, core/rlwe/params.go
+int rh_overflow_margin(const std::vector<u64>& m, int level) {     // QiOverflowMargin / PiOverflowMargin, core/rlwe/params.go
   u64 mx = 0; for (int i = 0; i <= level; ++i) if (m[i] > mx) mx = m[i];
   return (int)(18446744073709551616.0 / (double)mx);
 }
@@ -71,7 +72,7 @@ extern "C" int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const
   if (int rc = rh_bext_scratch(be, 6, wp, &aP1)) return rc;
   // ringQ.INTT(cxNTT, cxInvNTT)  (:138)
   if (int rc = rh_std_ntt_launch(RQ, cx, cxInv, npoly, LQ, 0, true, false, 0)) return rc;
-  const int QiOverF = overflow_margin(RQ->moduli, levelQ) >> 1, PiOverF = overflow_margin(RP->moduli, levelP) >> 1;
+  const int QiOverF = rh_overflow_margin(RQ->moduli, levelQ) >> 1, PiOverF = rh_overflow_margin(RP->moduli, levelP) >> 1;
   const size_t evq_stride = (size_t)RQ->L * N, evp_stride = (size_t)RP->L * N;     // one (digit, component) block
   int reduce = 0;
   for (int i = 0; i < beta; ++i) {
@@ -85,8 +86,8 @@ extern "C" int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const
     if (int rc = rh_std_ntt_launch(RP, c2P, c2P, npoly, LP, 0, false, false, 0)) return rc;
     const u64* eq0 = evkQ + ((size_t)i * 2 + 0) * evq_stride; const u64* eq1 = evkQ + ((size_t)i * 2 + 1) * evq_stride;
     const u64* ep0 = evkP + ((size_t)i * 2 + 0) * evp_stride; const u64* ep1 = evkP + ((size_t)i * 2 + 1) * evp_stride;
-    if (int rc = mac(RQ, c2Q, eq0, eq1, ct0, ct1, npoly, LQ, i == 0)) return rc;
-    if (int rc = mac(RP, c2P, ep0, ep1, aP0, aP1, npoly, LP, i == 0)) return rc;
+    if (int rc = rh_gadget_mac(RQ, c2Q, eq0, eq1, ct0, ct1, npoly, LQ, i == 0)) return rc;
+    if (int rc = rh_gadget_mac(RP, c2P, ep0, ep1, aP0, aP1, npoly, LP, i == 0)) return rc;
     if (reduce % QiOverF == QiOverF - 1) {
       if (int rc = rh_vec_launch(RQ, RH_OP_REDUCE, ct0, nullptr, ct0, npoly, LQ, 0, nullptr, nullptr)) return rc;
       if (int rc = rh_vec_launch(RQ, RH_OP_REDUCE, ct1, nullptr, ct1, npoly, LQ, 0, nullptr, nullptr)) return rc;

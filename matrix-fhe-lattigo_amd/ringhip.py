@@ -36,6 +36,30 @@ def _opcodes():
 OPS = _opcodes()
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP/HSA runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7).
+    When torch is imported first, this library's NEEDED libamdhip64.so.7 binds to torch's copy by SONAME and all is
+    well; when this library is loaded first it pulls in /opt/rocm's copy, torch later loads its own next to it, and
+    the second runtime finds no GPU.  So: if torch is installed but not yet imported, load torch's libamdhip64.so
+    first -- the same binding as in the other order.  Nothing is imported from torch; no torch -> nothing to do."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand)
+        except OSError:
+            pass
+
+
 def lib():
     """Loads the HIP library.  No fallback: a missing library is a hard error."""
     global _lib
@@ -44,6 +68,7 @@ def lib():
     path = library_path()
     if not os.path.exists(path):
         raise RingHipError("libringhip.so not built (%s): run `make` or __graft_entry__.build()" % path)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(path)
     i, vp, sz = C.c_int, C.c_void_p, C.c_size_t
     sig = {
@@ -74,6 +99,11 @@ def lib():
         "rh_bext_moddown_qp_to_p": (i, [vp, i, i, vp, vp, vp, i]),
         "rh_bext_decompose_and_split": (i, [vp, i, i, i, i, vp, vp, vp, i]),
         "rh_bext_gadget_product": (i, [vp, i, i, vp, vp, vp, i, vp, vp, i]),
+        "rh_kshard_create": (i, [C.POINTER(vp), vp, vp, U64P, i, U64P, i, C.POINTER(i), i, C.POINTER(i), i]),
+        "rh_kshard_destroy": (None, [vp]), "rh_kshard_num_digits": (i, [vp]),
+        "rh_kshard_digit_range": (i, [vp, i, C.POINTER(i), C.POINTER(i)]),
+        "rh_kshard_digit": (i, [vp, i, vp, vp, vp, vp, vp, vp, vp, vp, i]),
+        "rh_kshard_moddown": (i, [vp, vp, vp, vp, i]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)

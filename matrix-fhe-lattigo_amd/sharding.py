@@ -31,3 +31,145 @@ def gather_shards(local, dist):
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, local)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Limb-sharded hybrid key switch (BASELINE config 5)
+# ---------------------------------------------------------------------------------------------------------------
+def qp_owner(i, world):
+    """owner of limb i of the concatenation Q ++ P (P limb j has index len(Q) + j)"""
+    return i % world
+
+
+class LimbShardedKeySwitch:
+    """rlwe.Evaluator.GadgetProduct (core/rlwe/evaluator_gadget_product.go:16-30) with the limbs of Q ++ P dealt
+    round-robin over the ranks of one node: rank r owns limbs {i : i mod world == r} and the matching slice of the
+    evaluation key.  All arithmetic is the HIP library's (rh_kshard_*, csrc/kshard.hip); this class only moves limbs:
+
+      * per digit, an all-gather of the digit's alpha source limbs of INTT(cx)   (alpha*8*N bytes per poly),
+      * before ModDown, an all-gather of the k+1 limbs of each P-part accumulator.
+
+    Collectives run through torch.distributed on device tensors (backend "nccl" = RCCL over xGMI); with the "gloo"
+    backend (tests) the same blocks are staged through the host.  Outputs stay limb-sharded.
+    Tensors are int64 views of the uint64 words, shape (npoly, owned limbs, N), on `device`."""
+
+    def __init__(self, N, Q, P, rank, world, dist=None, device=0):
+        import ctypes as C
+        import numpy as np
+        import torch
+        from . import ringhip as rh
+        self.rh, self.torch, self.dist = rh, torch, dist
+        self.N, self.Q, self.P, self.rank, self.world = int(N), [int(q) for q in Q], [int(p) for p in P], rank, world
+        self.levelQ, self.levelP = len(Q) - 1, len(P) - 1
+        self.device = torch.device("cuda", device)
+        nq = len(Q)
+        self.ownQ = [i for i in range(nq) if qp_owner(i, world) == rank]
+        self.ownP = [j for j in range(len(P)) if qp_owner(nq + j, world) == rank]
+        if not self.ownQ:
+            raise rh.RingHipError("rank %d owns no Q limb (%d limbs over %d ranks)" % (rank, nq, world))
+        self.ringQ = rh.Ring(N, [self.Q[i] for i in self.ownQ], device=device)
+        self.ringP = rh.Ring(N, [self.P[j] for j in self.ownP], device=device) if self.ownP else None
+        h = C.c_void_p()
+        allQ, allP = rh._u64(self.Q), rh._u64(self.P)
+        oq = (C.c_int * len(self.ownQ))(*self.ownQ)
+        op = (C.c_int * max(len(self.ownP), 1))(*self.ownP)
+        rh._check(rh.lib().rh_kshard_create(C.byref(h), self.ringQ._h, self.ringP._h if self.ringP else None, rh._p(allQ), self.levelQ,
+                                            rh._p(allP), self.levelP, oq, len(self.ownQ), op, len(self.ownP)))
+        self._h = h
+        self.beta = rh.lib().rh_kshard_num_digits(h)
+        stream = torch.cuda.current_stream(self.device).cuda_stream       # kernels and collectives in one stream order
+        self.ringQ.set_stream(stream)
+        if self.ringP:
+            self.ringP.set_stream(stream)
+
+    # ---- helpers -------------------------------------------------------------------------------------------
+    def digit_range(self, d):
+        import ctypes as C
+        st, ed = C.c_int(), C.c_int()
+        self.rh._check(self.rh.lib().rh_kshard_digit_range(self._h, d, C.byref(st), C.byref(ed)))
+        return st.value, ed.value
+
+    def shard_q(self, full):
+        """(npoly, len(Q), N) array -> this rank's (npoly, owned, N) rows"""
+        return full[:, self.ownQ]
+
+    def shard_key(self, evkQ_full, evkP_full):
+        """(beta, 2, len(Q), N) / (beta, 2, len(P), N) -> the owned limb slices, same leading layout"""
+        return evkQ_full[:, :, self.ownQ], (evkP_full[:, :, self.ownP] if self.ownP else None)
+
+    def to_device(self, arr):
+        import numpy as np
+        return self.torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).to(self.device)
+
+    def _dp(self, ring, t):
+        return self.rh.DevicePoly.from_torch(ring, t)
+
+    def _all_gather(self, block):
+        """all-gather of equally shaped device blocks -> list indexed by rank"""
+        torch, dist = self.torch, self.dist
+        if dist is None or self.world == 1:
+            return [block]
+        if dist.get_backend() == "nccl":
+            out = [torch.empty_like(block) for _ in range(self.world)]
+            dist.all_gather(out, block)
+            return out
+        host = block.cpu()                                               # gloo (tests): staged through the host
+        outs = [torch.empty_like(host) for _ in range(self.world)]
+        dist.all_gather(outs, host)
+        return [o.to(self.device) for o in outs]
+
+    def _gather_limbs(self, local, own, base, st, ed):
+        """limbs [st, ed) (indices in the local numbering of the chain that `own` refers to; `base` = their offset in
+        Q ++ P) of a limb-sharded block -> (npoly, ed-st, N) on every rank, global order"""
+        torch = self.torch
+        npoly = local.shape[0]
+        mine = [k for k, g in enumerate(own) if st <= g < ed]
+        counts = [sum(1 for g in range(st, ed) if qp_owner(base + g, self.world) == r) for r in range(self.world)]
+        cmax = max(counts)
+        block = torch.zeros((npoly, cmax, self.N), dtype=torch.int64, device=self.device)
+        if mine:
+            block[:, :len(mine)] = local[:, mine]
+        parts = self._all_gather(block)
+        src = torch.empty((npoly, ed - st, self.N), dtype=torch.int64, device=self.device)
+        pos = [0] * self.world
+        for g in range(st, ed):
+            r = qp_owner(base + g, self.world)
+            src[:, g - st] = parts[r][:, pos[r]]
+            pos[r] += 1
+        return src
+
+    # ---- the product ---------------------------------------------------------------------------------------
+    def GadgetProduct(self, cx, evkQ, evkP, ct0, ct1):
+        """cx: owned limbs of the NTT-domain input, (npoly, owned Q, N); evkQ / evkP: owned key slices
+        (beta, 2, owned, N) on the device; ct0 / ct1: outputs, owned Q limbs (NTT domain, canonical)."""
+        torch, rh, L = self.torch, self.rh, self.rh.lib()
+        npoly, nq, npl = cx.shape[0], len(self.ownQ), len(self.ownP)
+        cxinv = torch.empty_like(cx)
+        self.ringQ.INTT(self._dp(self.ringQ, cx), self._dp(self.ringQ, cxinv))                   # ringQ.INTT (:138)
+        acc0 = torch.empty((npoly, max(npl, 1), self.N), dtype=torch.int64, device=self.device)
+        acc1 = torch.empty_like(acc0)
+        pP = lambda t: t.data_ptr() if npl else None
+        for d in range(self.beta):
+            st, ed = self.digit_range(d)
+            src = self._gather_limbs(cxinv, self.ownQ, 0, st, ed)
+            rh._check(L.rh_kshard_digit(self._h, d, src.data_ptr(), cx.data_ptr(), evkQ.data_ptr(), pP(evkP) if npl else None,
+                                        ct0.data_ptr(), ct1.data_ptr(), pP(acc0), pP(acc1), npoly))
+        for acc, ct in ((acc0, ct0), (acc1, ct1)):                                              # eval.ModDown (:33-46)
+            if npl:
+                self.ringP.INTTLazy(self._dp(self.ringP, acc), self._dp(self.ringP, acc))
+            srcP = self._gather_limbs(acc, self.ownP, len(self.Q), 0, self.levelP + 1)
+            rh._check(L.rh_kshard_moddown(self._h, srcP.data_ptr(), ct.data_ptr(), ct.data_ptr(), npoly))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.rh.lib().rh_kshard_destroy(self._h)
+            self._h = None
+            self.ringQ.close()
+            if self.ringP:
+                self.ringP.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,111 @@
+"""GPU: limb-sharded hybrid key switch against the unsharded rh_bext_gadget_product, which
+tests/test_gpu_keyswitch.py pins to the oracle composition.  Multi-rank cases run as separate processes that share
+the box's one GPU and exchange limbs over gloo (host-staged); on a multi-GPU node the same class uses RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import QI60, PI60
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _case(N, nq, np_, npoly, seed):
+    Q, P = QI60[:nq], PI60[:np_]
+    rng = np.random.default_rng(seed)
+    beta = (nq - 1 + np_) // np_
+    u = lambda q, shape: (rng.integers(0, 1 << 62, size=shape, dtype=np.uint64) % np.uint64(q))
+    cx = np.stack([np.stack([u(q, N) for q in Q]) for _ in range(npoly)])
+    evkQ = np.stack([np.stack([np.stack([u(q, N) for q in Q]) for _ in range(2)]) for _ in range(beta)])
+    evkP = np.stack([np.stack([np.stack([u(p, N) for p in P]) for _ in range(2)]) for _ in range(beta)])
+    return Q, P, beta, cx, evkQ, evkP
+
+
+def _unsharded(rh, N, Q, P, beta, cx, evkQ, evkP):
+    rq, rp = rh.Ring(N, Q), rh.Ring(N, P)
+    be = rh.BasisExtender(rq, rp)
+    npoly, nq, np_ = cx.shape[0], len(Q), len(P)
+    pcx = rh.DevicePoly.from_numpy(rq, cx)
+    dq = rh.DevicePoly.from_numpy(rq, evkQ.reshape(beta * 2, nq, N))
+    dp = rh.DevicePoly.from_numpy(rp, evkP.reshape(beta * 2, np_, N))
+    ct0, ct1 = rh.DevicePoly(rq, npoly, nq), rh.DevicePoly(rq, npoly, nq)
+    be.GadgetProduct(nq - 1, np_ - 1, pcx, dq.ptr, dp.ptr, beta, ct0, ct1)
+    out = ct0.numpy(), ct1.numpy()
+    be.close(); rq.close(); rp.close()
+    return out
+
+
+def _run_shard(rh, sharding, N, Q, P, cx, evkQ, evkP, rank, world, dist):
+    import torch
+    ks = sharding.LimbShardedKeySwitch(N, Q, P, rank, world, dist=dist)
+    kq, kp = ks.shard_key(evkQ, evkP)
+    dcx = ks.to_device(ks.shard_q(cx))
+    dkq = ks.to_device(kq)
+    dkp = ks.to_device(kp) if kp is not None else None
+    ct0, ct1 = torch.empty_like(dcx), torch.empty_like(dcx)
+    ks.GadgetProduct(dcx, dkq, dkp, ct0, ct1)
+    torch.cuda.synchronize()
+    res = ct0.cpu().numpy().view(np.uint64), ct1.cpu().numpy().view(np.uint64), list(ks.ownQ), list(ks.ownP), ks.beta
+    ks.close()
+    return res
+
+
+@pytest.mark.parametrize("N,nq,np_", [(4096, 5, 2), (64, 6, 3), (8192, 7, 1 + 1)])
+def test_single_rank_shard_path_equals_unsharded(rh, N, nq, np_):
+    from matrix_fhe_lattigo_amd import sharding
+    Q, P, beta, cx, evkQ, evkP = _case(N, nq, np_, 2, N + nq)
+    e0, e1 = _unsharded(rh, N, Q, P, beta, cx, evkQ, evkP)
+    g0, g1, ownQ, ownP, b = _run_shard(rh, sharding, N, Q, P, cx, evkQ, evkP, 0, 1, None)
+    assert b == beta and ownQ == list(range(nq)) and ownP == list(range(np_))
+    assert np.array_equal(g0, e0) and np.array_equal(g1, e1)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q, N, nq, np_):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import matrix_fhe_lattigo_amd as rh
+    from matrix_fhe_lattigo_amd import sharding
+    Q, P, beta, cx, evkQ, evkP = _case(N, nq, np_, 2, 99)              # same case on every rank; each keeps its limbs
+    g0, g1, ownQ, ownP, _ = _run_shard(rh, sharding, N, Q, P, cx, evkQ, evkP, rank, world, dist)
+    ok = None
+    if rank == 0:
+        e0, e1 = _unsharded(rh, N, Q, P, beta, cx, evkQ, evkP)
+        ok = (e0, e1)
+    parts = sharding.gather_shards((g0, g1, ownQ, ownP), dist)          # the final gather
+    if rank == 0:
+        full0, full1 = np.zeros_like(ok[0]), np.zeros_like(ok[1])
+        seen = []
+        for p0, p1, oq, _op in parts:
+            full0[:, oq] = p0; full1[:, oq] = p1; seen += oq
+        q.put((sorted(seen) == list(range(nq)), bool(np.array_equal(full0, ok[0])), bool(np.array_equal(full1, ok[1])),
+               [len(p[3]) for p in parts]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,N,nq,np_", [(2, 4096, 5, 2), (4, 64, 5, 2), (3, 8192, 6, 3)])
+def test_multi_rank_limb_shard_gloo(world, N, nq, np_):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, N, nq, np_)) for r in range(world)]
+    for p in ps:
+        p.start()
+    covered, ok0, ok1, pcounts = q.get(timeout=300)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert covered and ok0 and ok1
+    if world == 4:
+        assert 0 in pcounts                                             # a rank that owns no P limb took part

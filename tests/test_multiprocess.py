@@ -65,3 +65,11 @@ def test_shard_helpers():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
     assert sorted(sum((sharding.limb_shard(30, r, 8) for r in range(8)), [])) == list(range(30))
+    # limb-sharded key switch (config 5): Q ++ P dealt round-robin; every limb has exactly one owner, ranks may own no P limb
+    nq, np_ = 24, 6
+    for world in (1, 2, 3, 8):
+        owners = [sharding.qp_owner(i, world) for i in range(nq + np_)]
+        assert all(0 <= o < world for o in owners)
+        per = [owners.count(r) for r in range(world)]
+        assert sum(per) == nq + np_ and max(per) - min(per) <= 1
+    assert [sharding.qp_owner(nq + j, 8) for j in range(np_)] == [0, 1, 2, 3, 4, 5]        # ranks 6, 7 own no P limb
