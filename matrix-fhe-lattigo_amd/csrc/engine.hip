@@ -333,6 +333,7 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
       if (phase != 2) {
         if (lazy) launch_fwd_cols<MontPolicy>(S1, g1, st, in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN);
         else if (r->cols2) launch_fwd_cols2<ShoupPolicy>(S1, dim3(rows * 8), st, in, out, r->d_tw_fwd + toff, c, Lrows, logN);
+        else if (S1 == 4 && r->asm_cols && r->asm_tile) ntt_fwd_cols16_asm<<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows);
       else      launch_fwd_cols<ShoupPolicy>(S1, g1, st, in, out, r->d_tw_fwd + toff, c, Lrows, logN);
       }
       src = out;
@@ -358,8 +359,10 @@ static void launch_fused(rh_ring* r, const u64* in1, u64* out1, unsigned n1, u64
   const unsigned grid = n1 > n2 ? n1 : n2;
   if (r->asm_tile && r->prefetch)
     ntt_fwd_fused_pre<S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN);
+  else if (r->asm_tile && S1 == 4 && r->asm_cols)
+    ntt_fwd_fused_asm<S1, true><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN, r->order_mix);
   else if (r->asm_tile)
-    ntt_fwd_fused_asm<S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN, r->order_mix);
+    ntt_fwd_fused_asm<S1, false><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN, r->order_mix);
   else
     ntt_fwd_fused<ShoupPolicy, S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff,
                                                              c, Lrows, r->logN, 1);
@@ -578,6 +581,7 @@ extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
   if (!r || !key) return rh_fail(RH_ERR_ARG, "set_tuning: null argument");
   if (!strcmp(key, "chunk_polys")) { r->chunk_polys = (int)value; return RH_OK; }
   if (!strcmp(key, "asm_tile")) { r->asm_tile = value != 0; return RH_OK; }
+  if (!strcmp(key, "asm_cols")) { r->asm_cols = (int)value; return RH_OK; }
   if (!strcmp(key, "prefetch")) { r->prefetch = (int)value; return RH_OK; }
   if (!strcmp(key, "order_mix")) { r->order_mix = (int)value; return RH_OK; }
   if (!strcmp(key, "cols2")) { r->cols2 = (int)value; return RH_OK; }

@@ -44,6 +44,36 @@ RH_DEV void fwd_tile_asm_body(u64* lds, const u32 b, const u64* in, u64* out, co
                  : NTT_TILE_ASM_CLOBBERS);
 }
 
+// column stages, N = 2^16 only (S1 = 4): hand-scheduled radix-16 round with wave-uniform twiddles; same contract as
+// fwd_cols_body<ShoupPolicy, 4> (outputs < 8q, any representative: the tile stages that follow reduce canonically)
+RH_DEV void fwd_cols16_asm_body(const u32 b, const u64* in, u64* out, const tw2* __restrict__ twn,
+                                const LimbConsts* __restrict__ consts, int L) {
+  const u32 limb = b % (u32)L;
+  const u32 r = b / (u32)L;
+  const size_t base = (((size_t)(r >> 4) * L + limb) << 16) + (r & 15) * 256;
+  const u64 pin = uni64((u64)(size_t)(in + base));
+  const u64 pout = uni64((u64)(size_t)(out + base));
+  const u64 tw = uni64((u64)(size_t)(twn + ((size_t)limb << 16)));
+  const u64 q = uni64(consts[limb].q);
+  const u64 nq = (u64)0 - q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
+  const u32 tid = threadIdx.x;
+  asm volatile(NTT_COLS16_ASM_BODY
+               :
+               : [tid] "v"(tid), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw),
+                 [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4)
+               : NTT_TILE_ASM_CLOBBERS);
+}
+template <int S1, bool ASMCOLS>
+RH_DEV void fwd_cols_best(const u32 b, const u64* in, u64* out, const tw2* __restrict__ twn,
+                          const LimbConsts* __restrict__ consts, int L, int logN) {
+  if constexpr (S1 == 4 && ASMCOLS) fwd_cols16_asm_body(b, in, out, twn, consts, L);
+  else fwd_cols_body<ShoupPolicy, S1>(b, in, out, twn, consts, L, logN);
+}
+__global__ void __launch_bounds__(256)
+ntt_fwd_cols16_asm(const u64* in, u64* out, const tw2* __restrict__ twn, const LimbConsts* __restrict__ consts, int L) {
+  fwd_cols16_asm_body(blockIdx.x, in, out, twn, consts, L);
+}
+
 __global__ void __launch_bounds__(256)
 ntt_fwd_tile_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts,
                  int L, int logN, int npoly) {
@@ -52,7 +82,7 @@ ntt_fwd_tile_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const Lim
 }
 
 // software-pipelined launch (see ntt_fwd_fused): column stages of span j (C++ body), then the asm tile body of span j-1
-template <int S1>
+template <int S1, bool ASMCOLS = false>
 __global__ void __launch_bounds__(256)
 ntt_fwd_fused_asm(const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n2, int npoly2,
                   const tw2* __restrict__ twn, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts, int L, int logN,
@@ -63,9 +93,9 @@ ntt_fwd_fused_asm(const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n
   // compute-phase workgroups are co-resident from the first instant of the launch
   if (order_mix && ((blockIdx.x >> 8) & 1u)) {
     if (blockIdx.x < n2) fwd_tile_asm_body(lds, blockIdx.x, data2, data2, twk, consts, L, logN, npoly2);
-    if (blockIdx.x < n1) fwd_cols_body<ShoupPolicy, S1>(blockIdx.x, in1, out1, twn, consts, L, logN);
+    if (blockIdx.x < n1) fwd_cols_best<S1, ASMCOLS>(blockIdx.x, in1, out1, twn, consts, L, logN);
   } else {
-    if (blockIdx.x < n1) fwd_cols_body<ShoupPolicy, S1>(blockIdx.x, in1, out1, twn, consts, L, logN);
+    if (blockIdx.x < n1) fwd_cols_best<S1, ASMCOLS>(blockIdx.x, in1, out1, twn, consts, L, logN);
     if (blockIdx.x < n2) fwd_tile_asm_body(lds, blockIdx.x, data2, data2, twk, consts, L, logN, npoly2);
   }
 }

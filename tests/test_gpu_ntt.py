@@ -270,3 +270,22 @@ def test_fused_prefetch_identical(rh, oracle, logN, L, B):
     sr = oracle.SubRingConsts(N, mods[0])
     assert np.array_equal(p.numpy()[B - 1, 0], oracle.ntt(a[B - 1, 0], sr))
     ring.close()
+
+
+@pytest.mark.parametrize("L,B", [(3, 2), (16, 5), (2, 300)])
+def test_asm_column_stages_identical(rh, oracle, L, B):
+    # N = 2^16: hand-scheduled column stages (standalone launch for small batches, fused launch for B >= 256) vs the C++ body
+    N, mods = 1 << 16, QI60[:L]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(L * 31 + B)
+    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    p = rh.DevicePoly.from_numpy(ring, a)
+    ref, o = ring.NewPoly(B), ring.NewPoly(B)
+    ring.set_tuning("asm_cols", 0); ring.NTT(p, ref)
+    ring.set_tuning("asm_cols", 1); ring.NTT(p, o); ring.sync()
+    assert np.array_equal(o.numpy(), ref.numpy())
+    ring.NTT(p, p); ring.sync()
+    assert np.array_equal(p.numpy(), ref.numpy())
+    sr = oracle.SubRingConsts(N, mods[L - 1])
+    assert np.array_equal(p.numpy()[B - 1, L - 1], oracle.ntt(a[B - 1, L - 1], sr))
+    ring.close()

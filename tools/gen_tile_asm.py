@@ -394,6 +394,34 @@ def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True):
 
 
 
+def gen_cols():
+    """Column stages for N = 2^16 (S1 = 4): x[k] = in[c + 4096 k], k < 16, one radix-16 round with the wave-uniform
+    twiddles tw[1..15] (natural order: stage s, group g -> tw[2^s + g] = slot 2^s - 1 + g), outputs < 8q stored back.
+    Same contract as fwd_cols_body<ShoupPolicy, 4> (ntt_kernels.cuh); operands: tid, pin, pout (row base + 256*cb
+    columns, bytes), tw (limb's natural-order table), nq0, nq1, nq4, q4."""
+    A0 = ADDR
+    for t in (T0, T1):
+        emit("v_mov_b32 v%d, 0" % (t.H + 1))
+        emit("v_mov_b32 v%d, 0" % (t.G + 1))
+    for slot in range(15):
+        emit("s_load_dwordx4 s[%d:%d], %%[tw], %d" % (36 + 4 * slot, 39 + 4 * slot, 16 * (slot + 1)))
+    emit("v_lshlrev_b32 v%d, 3, %%[tid]" % TW0)                # byte offset of column c; element k adds 32768*k
+    for k in range(1, 16):
+        emit("v_add_u32 v%d, %d, v%d" % (TW0 + k, 32768 * k, TW0))
+    for kk in range(16):
+        k = (kk >> 1) + 8 * (kk & 1)
+        emit("global_load_dwordx2 %s, v%d, %%[pin]" % (pair(X(k)), TW0 + k))
+    emit("s_waitcnt lgkmcnt(0)")
+
+    def pair_hook(u, i):
+        if u == 0:
+            emit("s_waitcnt vmcnt(%d)" % (16 - (2 * i + 4)))
+    round16(lambda slot: (None, ("s%d" % (36 + 4 * slot), "s%d" % (37 + 4 * slot), "s%d" % (38 + 4 * slot), "s%d" % (39 + 4 * slot))),
+            pair_hook=pair_hook)
+    for k in range(16):
+        emit("global_store_dwordx2 v%d, %s, %%[pout]" % (TW0 + k, pair(X(k))))
+
+
 def render(name, lines):
     body = "\n".join('  "%s\\n\\t"' % l for l in lines)
     return "#define %s \\\n%s\n" % (name, body.replace("\n", " \\\n"))
@@ -408,12 +436,15 @@ del out[:]
 gen(preloaded=True, tail_wait=False)   # fused launch: the caller issued the data loads ahead of its column stages
 fwd_pre = list(out)
 del out[:]
+gen_cols()
+cols = list(out)
+del out[:]
 gen_inverse()
 inv = list(out)
 clob_v = ", ".join('"v%d"' % i for i in range(NVGPR_USED))
 clob_s = ", ".join('"s%d"' % i for i in range(36, 102))
 text = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  forward: %d instructions, inverse: %d.\n" % (len(fwd), len(inv))
-text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_SC1_ASM_BODY", fwd_sc1) + render("NTT_TILE_PRE_ASM_BODY", fwd_pre) + render("NTT_TILE_INV_ASM_BODY", inv)
+text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_SC1_ASM_BODY", fwd_sc1) + render("NTT_TILE_PRE_ASM_BODY", fwd_pre) + render("NTT_COLS16_ASM_BODY", cols) + render("NTT_TILE_INV_ASM_BODY", inv)
 text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v, clob_s)
 clob_v_pre = ", ".join('"v%d"' % i for i in range(32, NVGPR_USED))     # v0..v31 are read-write operands there
 text += "#define NTT_TILE_PRE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v_pre, clob_s)
