@@ -41,6 +41,45 @@ def qp_owner(i, world):
     return i % world
 
 
+def all_gather_blocks(block, world, dist, device=None):
+    """all-gather of equally shaped blocks -> list indexed by rank.  Device tensors go through RCCL (backend "nccl");
+    with "gloo" (tests) device blocks are staged through the host, host blocks are gathered as they are."""
+    import torch
+    if dist is None or world == 1:
+        return [block]
+    if dist.get_backend() == "nccl":
+        out = [torch.empty_like(block) for _ in range(world)]
+        dist.all_gather(out, block)
+        return out
+    host = block.cpu()
+    outs = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(outs, host)
+    return [o.to(block.device) for o in outs]
+
+
+def gather_limbs(local, own, base, st, ed, world, dist):
+    """The key switch's exchange step.  `local`: (npoly, len(own), N) block of the limbs this rank owns of one chain
+    (Q or P), `own` their indices in that chain, `base` the chain's offset in Q ++ P (0 for Q, len(Q) for P).
+    Returns limbs [st, ed) of the chain, (npoly, ed-st, N) in chain order, on every rank: each rank contributes its
+    owned limbs of the range padded to the largest per-rank count, ONE all-gather, then a local reorder."""
+    import torch
+    npoly, N = local.shape[0], local.shape[2]
+    mine = [k for k, g in enumerate(own) if st <= g < ed]
+    counts = [sum(1 for g in range(st, ed) if qp_owner(base + g, world) == r) for r in range(world)]
+    cmax = max(counts)
+    block = torch.zeros((npoly, cmax, N), dtype=local.dtype, device=local.device)
+    if mine:
+        block[:, :len(mine)] = local[:, mine]
+    parts = all_gather_blocks(block, world, dist)
+    src = torch.empty((npoly, ed - st, N), dtype=local.dtype, device=local.device)
+    pos = [0] * world
+    for g in range(st, ed):
+        r = qp_owner(base + g, world)
+        src[:, g - st] = parts[r][:, pos[r]]
+        pos[r] += 1
+    return src
+
+
 class LimbShardedKeySwitch:
     """rlwe.Evaluator.GadgetProduct (core/rlwe/evaluator_gadget_product.go:16-30) with the limbs of Q ++ P dealt
     round-robin over the ranks of one node: rank r owns limbs {i : i mod world == r} and the matching slice of the
@@ -104,39 +143,8 @@ class LimbShardedKeySwitch:
     def _dp(self, ring, t):
         return self.rh.DevicePoly.from_torch(ring, t)
 
-    def _all_gather(self, block):
-        """all-gather of equally shaped device blocks -> list indexed by rank"""
-        torch, dist = self.torch, self.dist
-        if dist is None or self.world == 1:
-            return [block]
-        if dist.get_backend() == "nccl":
-            out = [torch.empty_like(block) for _ in range(self.world)]
-            dist.all_gather(out, block)
-            return out
-        host = block.cpu()                                               # gloo (tests): staged through the host
-        outs = [torch.empty_like(host) for _ in range(self.world)]
-        dist.all_gather(outs, host)
-        return [o.to(self.device) for o in outs]
-
     def _gather_limbs(self, local, own, base, st, ed):
-        """limbs [st, ed) (indices in the local numbering of the chain that `own` refers to; `base` = their offset in
-        Q ++ P) of a limb-sharded block -> (npoly, ed-st, N) on every rank, global order"""
-        torch = self.torch
-        npoly = local.shape[0]
-        mine = [k for k, g in enumerate(own) if st <= g < ed]
-        counts = [sum(1 for g in range(st, ed) if qp_owner(base + g, self.world) == r) for r in range(self.world)]
-        cmax = max(counts)
-        block = torch.zeros((npoly, cmax, self.N), dtype=torch.int64, device=self.device)
-        if mine:
-            block[:, :len(mine)] = local[:, mine]
-        parts = self._all_gather(block)
-        src = torch.empty((npoly, ed - st, self.N), dtype=torch.int64, device=self.device)
-        pos = [0] * self.world
-        for g in range(st, ed):
-            r = qp_owner(base + g, self.world)
-            src[:, g - st] = parts[r][:, pos[r]]
-            pos[r] += 1
-        return src
+        return gather_limbs(local, own, base, st, ed, self.world, self.dist)
 
     # ---- the product ---------------------------------------------------------------------------------------
     def GadgetProduct(self, cx, evkQ, evkP, ct0, ct1):

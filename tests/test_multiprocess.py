@@ -73,3 +73,47 @@ def test_shard_helpers():
         per = [owners.count(r) for r in range(world)]
         assert sum(per) == nq + np_ and max(per) - min(per) <= 1
     assert [sharding.qp_owner(nq + j, 8) for j in range(np_)] == [0, 1, 2, 3, 4, 5]        # ranks 6, 7 own no P limb
+
+
+def _gather_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import matrix_fhe_lattigo_amd  # noqa: F401
+    from matrix_fhe_lattigo_amd import sharding
+    nq, np_, npoly, N = 7, 3, 2, 16
+    full_q = torch.arange(npoly * nq * N, dtype=torch.int64).reshape(npoly, nq, N)            # limb i of poly k is recognisable
+    full_p = -torch.arange(npoly * np_ * N, dtype=torch.int64).reshape(npoly, np_, N) - 1
+    ownq = [i for i in range(nq) if sharding.qp_owner(i, world) == rank]
+    ownp = [j for j in range(np_) if sharding.qp_owner(nq + j, world) == rank]
+    ok = True
+    for st, ed in ((0, 3), (3, 6), (6, 7), (0, 7)):                                           # digits of alpha = 3, and the whole chain
+        got = sharding.gather_limbs(full_q[:, ownq], ownq, 0, st, ed, world, dist)
+        ok = ok and bool(torch.equal(got, full_q[:, st:ed]))
+    lp = full_p[:, ownp] if ownp else torch.zeros((npoly, 0, N), dtype=torch.int64)           # a rank may own no P limb
+    got = sharding.gather_limbs(lp, ownp, nq, 0, np_, world, dist)
+    ok = ok and bool(torch.equal(got, full_p))
+    q.put((rank, ok, len(ownp)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_limb_exchange_gloo(world):
+    # the key switch's only data-path collective, on host tensors: padding, ownership, reorder
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)
+    if world == 4:
+        assert any(r[2] == 0 for r in res)
