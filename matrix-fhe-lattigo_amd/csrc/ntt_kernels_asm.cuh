@@ -3,7 +3,7 @@
 // Same contract as ntt_fwd_tile<ShoupPolicy> with canonical output (ntt_kernels.cuh): last 12 stages of the
 // forward negacyclic NTT (ring/ntt.go:209-552 + reducevec) on one contiguous 4096-coefficient tile.  The C++ wrapper
 // resolves (poly, limb, tile), loads the per-limb constants through the scalar cache and hands everything to one asm
-// statement that owns v0..v123 and s36..s101.
+// statement that owns v0..v123, s36..s99 and vcc.
 #pragma once
 #include "ring_types.cuh"
 #include "ntt_kernels.cuh"

@@ -58,7 +58,7 @@ T0 = Tmp(TMP0)
 T1 = Tmp(TMP0 + NTMP)
 T0.cc = "s[96:97]"
 T1.cc = "s[98:99]"
-DUMMY = "s[100:101]"   # carry-out sink of v_mad_u64_u32
+DUMMY = "vcc"           # carry-out sink of v_mad_u64_u32 (vcc is otherwise only address scratch between rounds)
 
 
 def butterfly_steps(u, v, w, t, sgpr_tw=None):
@@ -442,7 +442,7 @@ del out[:]
 gen_inverse()
 inv = list(out)
 clob_v = ", ".join('"v%d"' % i for i in range(NVGPR_USED))
-clob_s = ", ".join('"s%d"' % i for i in range(36, 102))
+clob_s = ", ".join('"s%d"' % i for i in range(36, 100))
 text = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  forward: %d instructions, inverse: %d.\n" % (len(fwd), len(inv))
 text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_SC1_ASM_BODY", fwd_sc1) + render("NTT_TILE_PRE_ASM_BODY", fwd_pre) + render("NTT_COLS16_ASM_BODY", cols) + render("NTT_TILE_INV_ASM_BODY", inv)
 text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v, clob_s)
