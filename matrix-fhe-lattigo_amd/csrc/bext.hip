@@ -9,7 +9,8 @@
 //   out_j = (sum_i y_i * (Q/q_i mod p_j)) reduced once (lazy Montgomery) + vtimesqmodp[j][v]       -- NOT canonical,
 // then the caller's post step (centred subtraction, ModDown's fused subtract-multiply).  The non-canonical values are
 // reproduced exactly, so results are bit-identical to the reference even before its later Reduce.
-// The y_i live in LDS ([limb][thread], conflict-free) because the source limb count is a run-time value.
+// The y_i live in registers (kernel instantiated per source-limb count up to 8, bounded variants for 16 / 32; a generic
+// fallback keeps them in LDS [limb][thread]).
 // Traffic: 8*(nsrc + ntgt) bytes per coefficient; nsrc*ntgt 64x64->128 multiply-accumulates per coefficient.
 #include <hip/hip_runtime.h>
 #include <vector>
@@ -20,56 +21,108 @@
 #include "bext_internal.hpp"
 #include "hostmath.hpp"
 
+// NS: compile-time bound on the source-limb count (y_i live in registers, loops fully unrolled); EXACT: nsrc == NS.
+// NS == 0: generic fallback with the y_i in dynamic LDS ([limb][thread]).
+template <int NS, bool EXACT>
 __global__ void __launch_bounds__(256)
 bext_kernel(const u64* in, int in_rows, int src_limb0, int nsrc, const BextSource* __restrict__ S,
-            int ntgt, const BextTarget* __restrict__ T, const u64* __restrict__ coef, const u64* __restrict__ vt,
-            u64* out0, int out0_rows, u64* out1, int out1_rows, const u64* other, int other_rows, int N, int add_mode) {
-  extern __shared__ u64 ylds[];                     // [nsrc][256]
+            int ntgt_c, int ntgt, const BextTarget* __restrict__ T, const u64* __restrict__ coef, const u64* __restrict__ vt,
+            u64* out0, int out0_rows, u64* out1, int out1_rows, const u64* other, int other_rows, int N, int add_mode, int post) {
+  // targets [0, ntgt_c) are extended (all with the plan-uniform post step `post`); [ntgt_c, ntgt) are the digit limbs of
+  // DecomposeAndSplit: no extension, the centred subtraction applies to what the output already holds
+  extern __shared__ u64 ylds[];                     // [nsrc][256], NS == 0 only
   const int tid = threadIdx.x;
   const int k = blockIdx.x * 256 + tid;
   const int poly = blockIdx.y;
   const bool live = k < N;
+  constexpr int NY = NS > 0 ? NS : 1;
+  u64 yr[NY];
   double vi = 0.0;
-  for (int i = 0; i < nsrc; ++i) {
+  auto source = [&](int i) {
     const BextSource s = S[i];
     u64 x = live ? in[((size_t)poly * in_rows + src_limb0 + i) * N + k] : 0;
     if (add_mode == BEXT_ADD_CRED) x = cred(x + s.half, s.q);            // AddScalarBigint -> addscalarvec
     else if (add_mode == BEXT_ADD_RAW) x = x + s.half;                    // reconstructRNSCentered :522
     const u64 y = mred(x, s.qstar_inv, s.q, s.qinv);
-    ylds[i * 256 + tid] = y;
     vi += (double)y / (double)s.q;                                        // :576-593, one rounding per op
+    return y;
+  };
+  if constexpr (NS > 0) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { yr[i] = 0; if (EXACT || i < nsrc) yr[i] = source(i); }
+  } else {
+    for (int i = 0; i < nsrc; ++i) ylds[i * 256 + tid] = source(i);
   }
   const u64 v = (u64)vi;
-  for (int j = 0; j < ntgt; ++j) {
+#pragma unroll 2
+  for (int j = 0; j < ntgt_c; ++j) {                // branch-free body: two targets' constant loads and vt gathers overlap
     const BextTarget t = T[j];
     u64* outp = t.buf ? out1 : out0;
     const int rows = t.buf ? out1_rows : out0_rows;
     const size_t o = ((size_t)poly * rows + t.limb) * N + k;
-    u64 r;
-    if (t.skip) {
-      if (t.post == 0 || !live) continue;
-      r = outp[o];
+    const u64* cj = coef + (size_t)j * nsrc;
+    u64 rlo, rhi;
+    if constexpr (NS > 0) {
+      u128 acc = (u128)yr[0] * cj[0];
+      rlo = (u64)acc; rhi = (u64)(acc >> 64);
+#pragma unroll
+      for (int i = 1; i < NS; ++i) {                                      // multSum :612-649
+        if (EXACT || i < nsrc) {
+          const u128 m = (u128)yr[i] * cj[i];
+          const u64 mlo = (u64)m, mhi = (u64)(m >> 64);
+          const u64 s = rlo + mlo;
+          rhi += mhi + (u64)(s < rlo);
+          rlo = s;
+        }
+      }
     } else {
-      const u64* cj = coef + (size_t)j * nsrc;
       u128 acc = (u128)ylds[tid] * cj[0];
-      u64 rlo = (u64)acc, rhi = (u64)(acc >> 64);
-      for (int i = 1; i < nsrc; ++i) {                                    // multSum :612-649
+      rlo = (u64)acc; rhi = (u64)(acc >> 64);
+      for (int i = 1; i < nsrc; ++i) {
         const u128 m = (u128)ylds[i * 256 + tid] * cj[i];
         const u64 mlo = (u64)m, mhi = (u64)(m >> 64);
         const u64 s = rlo + mlo;
         rhi += mhi + (u64)(s < rlo);
         rlo = s;
       }
-      const u64 hhi = mulhi64(rlo * t.pinv, t.p);
-      r = rhi - hhi + t.p + vt[(size_t)j * (nsrc + 1) + v];               // :651-672
     }
-    if (t.post >= 1) r = cred(r + t.p - t.half, t.p);                     // SubScalarBigint -> subscalarvec
-    if (t.post == 2) {
+    const u64 hhi = mulhi64(rlo * t.pinv, t.p);
+    u64 r = rhi - hhi + t.p + vt[(size_t)j * (nsrc + 1) + v];             // :651-672
+    if (post >= 1) r = cred(r + t.p - t.half, t.p);                       // SubScalarBigint -> subscalarvec
+    if (post == 2) {
       const u64 y = live ? other[((size_t)poly * other_rows + t.limb) * N + k] : 0;
       r = mred(2 * t.p - y + r, t.md_scalar, t.p, t.pinv);                // SubThenMulScalarMontgomeryTwoModulus
     }
     if (live) outp[o] = r;
   }
+  if (post >= 1 && live) {
+    for (int j = ntgt_c; j < ntgt; ++j) {
+      const BextTarget t = T[j];
+      u64* outp = t.buf ? out1 : out0;
+      const int rows = t.buf ? out1_rows : out0_rows;
+      const size_t o = ((size_t)poly * rows + t.limb) * N + k;
+      outp[o] = cred(outp[o] + t.p - t.half, t.p);
+    }
+  }
+}
+
+#define RH_BEXT_ARGS in, in_rows, src_limb0, p.nsrc, p.d_S, p.ntgt_c, p.ntgt, p.d_T, p.d_coef, p.d_vt, out0, out0_rows, out1, out1_rows, other, other_rows, N, add_mode, p.post
+static void bext_dispatch(dim3 grid, hipStream_t st, const BextPlan& p, const u64* in, int in_rows, int src_limb0, u64* out0, int out0_rows,
+                          u64* out1, int out1_rows, const u64* other, int other_rows, int N, int add_mode) {
+  switch (p.nsrc) {
+    case 1: bext_kernel<1, true><<<grid, 256, 0, st>>>(RH_BEXT_ARGS); return;
+    case 2: bext_kernel<2, true><<<grid, 256, 0, st>>>(RH_BEXT_ARGS); return;
+    case 3: bext_kernel<3, true><<<grid, 256, 0, st>>>(RH_BEXT_ARGS); return;
+    case 4: bext_kernel<4, true><<<grid, 256, 0, st>>>(RH_BEXT_ARGS); return;
+    case 5: bext_kernel<5, true><<<grid, 256, 0, st>>>(RH_BEXT_ARGS); return;
+    case 6: bext_kernel<6, true><<<grid, 256, 0, st>>>(RH_BEXT_ARGS); return;
+    case 7: bext_kernel<7, true><<<grid, 256, 0, st>>>(RH_BEXT_ARGS); return;
+    case 8: bext_kernel<8, true><<<grid, 256, 0, st>>>(RH_BEXT_ARGS); return;
+    default: break;
+  }
+  if (p.nsrc <= 16) bext_kernel<16, false><<<grid, 256, 0, st>>>(RH_BEXT_ARGS);
+  else if (p.nsrc <= 32) bext_kernel<32, false><<<grid, 256, 0, st>>>(RH_BEXT_ARGS);
+  else bext_kernel<0, false><<<grid, 256, (size_t)p.nsrc * 256 * 8, st>>>(RH_BEXT_ARGS);
 }
 
 // DecomposeAndSplit, single-prime digit (decompLvl < 0): sign-aware copy/reduce into every limb (:402-436)
@@ -205,9 +258,8 @@ static int get_modup_plan(rh_bext* be, int kind, int dir, int lvlS, int lvlT, Be
     t.buf = 0; t.limb = (int)j; t.post = kind == 1 ? 2 : 1; t.skip = 0;
     T[j] = t;
   }
-  BextPlan p; p.nsrc = (int)Qs.size(); p.ntgt = (int)tg.size();
-  int rc = upv(&p.d_S, S); if (!rc) rc = upv(&p.d_T, T); if (!rc) rc = upv(&p.d_coef, coef); if (!rc) rc = upv(&p.d_vt, vt);
-  if (rc) return rc;
+  BextPlan p;
+  if (int rc = rh_bext_upload_plan(p, S, T, coef, vt)) return rc;
   auto ins = be->plans.emplace(key, p);
   *out = &ins.first->second;
   return 0;
@@ -219,10 +271,8 @@ static int launch_plan(rh_bext* be, const BextPlan& p, const u64* in, int in_row
   const int N = R->N;
   if (npoly <= 0) return RH_OK;
   dim3 grid((N + 255) / 256, npoly);
-  const size_t lds = (size_t)p.nsrc * 256 * 8;
   (void)hipGetLastError();
-  bext_kernel<<<grid, 256, lds, R->stream>>>(in, in_rows, src_limb0, p.nsrc, p.d_S, p.ntgt, p.d_T, p.d_coef, p.d_vt,
-                                             out0, out0_rows, out1, out1_rows, other, other_rows, N, add_mode);
+  bext_dispatch(grid, R->stream, p, in, in_rows, src_limb0, out0, out0_rows, out1, out1_rows, other, other_rows, N, add_mode);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "bext_kernel launch failed: %s", hipGetErrorString(e));
   return RH_OK;
@@ -311,23 +361,25 @@ extern "C" int rh_bext_decompose_and_split(rh_bext* be, int levelQ, int levelP, 
       // constants: GenModUpConstants(Q[st:ed], Q_all ++ P[:nbPi]) (NewDecomposer :345-372); only the rows of the
       // limbs actually written are kept.  Row u of the reference = limb u of Q (u < len(Q)) or len(Q)+j for P_j.
       std::vector<u64> tg; std::vector<BextTarget> T;
-      for (int j = 0; j <= levelQ; ++j) {
-        BextTarget t{}; t.p = RQ->moduli[j]; t.pinv = RQ->mred[j]; t.half = half_product_mod(Qs, t.p);
-        t.buf = 0; t.limb = j; t.post = 1; t.skip = (j >= st && j < ed) ? 1 : 0;
-        T.push_back(t); tg.push_back(t.p);
-      }
-      for (int j = 0; j < nP; ++j) {
-        BextTarget t{}; t.p = RP->moduli[j]; t.pinv = RP->mred[j]; t.half = half_product_mod(Qs, t.p);
-        t.buf = 1; t.limb = j; t.post = 1; t.skip = 0;
-        T.push_back(t); tg.push_back(t.p);
+      for (int pass = 0; pass < 2; ++pass) {                              // extended limbs first, the digit's own limbs last
+        for (int j = 0; j <= levelQ; ++j) {
+          const int skip = (j >= st && j < ed) ? 1 : 0;
+          if (skip != pass) continue;
+          BextTarget t{}; t.p = RQ->moduli[j]; t.pinv = RQ->mred[j]; t.half = half_product_mod(Qs, t.p);
+          t.buf = 0; t.limb = j; t.post = 1; t.skip = skip;
+          T.push_back(t); tg.push_back(t.p);
+        }
+        if (pass == 0) for (int j = 0; j < nP; ++j) {
+          BextTarget t{}; t.p = RP->moduli[j]; t.pinv = RP->mred[j]; t.half = half_product_mod(Qs, t.p);
+          t.buf = 1; t.limb = j; t.post = 1; t.skip = 0;
+          T.push_back(t); tg.push_back(t.p);
+        }
       }
       std::vector<u64> qsi, coef, vt;
       gen_modup(Qs, tg, qsi, coef, vt);
       std::vector<BextSource> S(Qs.size());
       for (size_t i = 0; i < Qs.size(); ++i) S[i] = BextSource{Qs[i], RQ->mred[st + i], qsi[i], half_product_mod(Qs, Qs[i])};
-      p.nsrc = (int)Qs.size(); p.ntgt = (int)T.size();
-      int rc = upv(&p.d_S, S); if (!rc) rc = upv(&p.d_T, T); if (!rc) rc = upv(&p.d_coef, coef); if (!rc) rc = upv(&p.d_vt, vt);
-      if (rc) return rc;
+      if (int rc = rh_bext_upload_plan(p, S, T, coef, vt)) return rc;
     }
     it = be->plans.emplace(key, p).first;
   }
@@ -352,6 +404,11 @@ u64 rh_moddown_const(const std::vector<u64>& Ps, u64 qi) { return moddown_const(
 int rh_bext_upload_plan(BextPlan& p, const std::vector<BextSource>& S, const std::vector<BextTarget>& T, const std::vector<u64>& coef,
                         const std::vector<u64>& vt) {
   p.nsrc = (int)S.size(); p.ntgt = (int)T.size();
+  p.ntgt_c = 0; p.post = T.empty() ? 0 : T[0].post;
+  for (const BextTarget& t : T) {                  // extended targets first, then the skipped (digit) limbs; one post step per plan
+    if (!t.skip) { if (p.ntgt_c != (int)(&t - T.data())) return rh_fail(RH_ERR_ARG, "basis-extension plan: skipped limbs must come last"); ++p.ntgt_c; }
+    if (t.post != p.post) return rh_fail(RH_ERR_ARG, "basis-extension plan: mixed post steps");
+  }
   int rc = upv(&p.d_S, S); if (!rc) rc = upv(&p.d_T, T); if (!rc) rc = upv(&p.d_coef, coef); if (!rc) rc = upv(&p.d_vt, vt);
   return rc;
 }
@@ -369,8 +426,7 @@ int rh_bext_launch_raw(hipStream_t st, int N, const BextPlan& p, const u64* in, 
   if (npoly <= 0 || p.ntgt == 0) return RH_OK;
   dim3 grid((N + 255) / 256, npoly);
   (void)hipGetLastError();
-  bext_kernel<<<grid, 256, (size_t)p.nsrc * 256 * 8, st>>>(in, in_rows, src_limb0, p.nsrc, p.d_S, p.ntgt, p.d_T, p.d_coef, p.d_vt,
-                                                          out0, out0_rows, out1, out1_rows, other, other_rows, N, add_mode);
+  bext_dispatch(grid, st, p, in, in_rows, src_limb0, out0, out0_rows, out1, out1_rows, other, other_rows, N, add_mode);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "bext_kernel launch failed: %s", hipGetErrorString(e));
   return RH_OK;

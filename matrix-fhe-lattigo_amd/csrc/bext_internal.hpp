@@ -19,6 +19,8 @@ enum { BEXT_ADD_NONE = 0, BEXT_ADD_CRED = 1, BEXT_ADD_RAW = 2 };
 struct SignTarget { u64 p, bred0; int buf, limb; };
 struct BextPlan {
   int nsrc = 0, ntgt = 0;
+  int ntgt_c = 0;  // targets [0, ntgt_c) are extended, the rest skipped (digit limbs)
+  int post = 0;    // the plan's post step (uniform over its targets)
   BextSource* d_S = nullptr; BextTarget* d_T = nullptr; u64* d_coef = nullptr; u64* d_vt = nullptr;
   SignTarget* d_sign = nullptr; u64 qd = 0;      // single-prime digit plan
 };
