@@ -188,6 +188,14 @@ def main():
         out["cpu_baseline"] = {"value": reps / t_cpu, "unit": "NTT/s", "cores": 1, "kind": "port",
                                "sample": "%d forward NTTs of one 16-limb N=2^%d poly, single thread (the Go loop is single-threaded), "
                                          "C restatement of nttUnrolled16Lazy+reducevec (oracle/ring_oracle.c), host has %d cores" % (reps, args.logn, ncpu)}
+        # the same work spread over this process's share of the host cores (limbs of a poly are independent): what a
+        # goroutine-per-limb caller of the reference could reach; a short extra sample, reported beside the like-for-like one
+        nthr = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else ncpu, L)
+        if nthr > 1:
+            reps_mt = max(nthr, int(0.4 * args.cpu_seconds * nthr / max(t_probe, 1e-6)))
+            t_mt = oracle.time_ntt_forward(N, mods, reps_mt, nthr)
+            out["cpu_baseline"]["all_cores"] = {"value": reps_mt / t_mt, "unit": "NTT/s", "cores": nthr,
+                                                "sample": "%d forward NTTs, limbs spread over %d threads" % (reps_mt, nthr)}
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
