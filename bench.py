@@ -168,6 +168,17 @@ def main():
                 traffic = tj["hbm_bytes_per_poly"] * B
         except Exception:
             traffic = None
+    # what is actually launched inside the timed region (engine.hip: rh_std_ntt_launch)
+    chunk = args.chunk if args.chunk >= 0 else (128 if B >= 256 else 0)
+    special = args.cluster == 1 or args.persistent == 1
+    if special:
+        launches, kname = 1, "ntt_fwd_cluster / ntt_fwd_persistent (experimental single launch)"
+    elif args.logn > 12 and chunk > 0 and B > chunk:
+        launches = -(-B // chunk) + 1
+        kname = ("ntt_fwd_fused_asm<%d>: column stages of one %d-poly span + tile stages of the previous span; %d launches per step "
+                 "(first and last carry one half), each moves the algorithmic bytes of one span's whole transform" % (args.logn - 12, chunk, launches))
+    else:
+        launches, kname = (2 if args.logn > 12 else 1), "ntt_fwd_cols + ntt_fwd_tile_asm (two launches = one forward transform)"
     out = {
         "metric": "forward-NTT/s at N=2^16, 16 RNS limbs; achieved HBM GB/s vs peak",
         "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -176,8 +187,11 @@ def main():
         "config": {"workload": "Ring.NTT forward, N=2^%d, %d limbs (Qi60[0:%d]), batch %d polys/GPU, in place, device-resident" % (args.logn, L, L, B),
                    "parallelism": "batch-shard x%d, no collective" % world, "limb_ntt_per_s": value * L},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "ntt_fwd_cols+ntt_fwd_tile (one forward transform = both)",
-                     "algorithmic_bytes_per_step": alg_bytes, "device_ms_per_step": launch_ms, "kernel_ms": kern},
+                     "traffic": (traffic / launches) if traffic is not None else None,      # PMC bytes per launch, like algorithmic_bytes_per_launch
+                     "traffic_per_step": traffic, "kernel": kname, "launches_per_step": launches,
+                     "avg_launch_ms": launch_ms / launches, "algorithmic_bytes_per_launch": alg_bytes / launches,
+                     "algorithmic_bytes_per_step": alg_bytes, "device_ms_per_step": launch_ms,
+                     "standalone_kernel_ms": kern},
     }
     if world == 1 and not args.no_cpu:
         import oracle

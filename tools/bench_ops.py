@@ -111,6 +111,20 @@ for N, L, B in ((3 << 13, 1, 1024), (3 << 16, 24, 16)):
     px = rh.DevicePoly.from_torch(ring, x)
     res.append(entry("3N NTT N=%d L=%d" % (N, L), timed(lambda: ring.NTT(px, px), reps=5), 16.0 * N * L * B, B, "poly"))
     res.append(entry("3N INTT N=%d L=%d" % (N, L), timed(lambda: ring.INTT(px, px), reps=5), 16.0 * N * L * B, B, "poly"))
+    if L == 24:
+        # config 4: matrix_ckks.Evaluator.Mul on degree-1 ciphertexts given in the coefficient domain
+        # (schemes/matrix_ckks/evaluator.go:114-192): 4 NTT + 3 MulCoeffsMontgomery + 1 ...ThenAdd + 3 INTT
+        blocks = [rh.DevicePoly.from_torch(ring, rand_block(B, mods, N)) for _ in range(7)]
+        ct0, ct1 = rh.Ciphertext(blocks[0:2]), rh.Ciphertext(blocks[2:4])
+        out = rh.Ciphertext(blocks[4:7])
+        ev = rh.MatrixCKKSEvaluator(ring)
+
+        def mul():
+            ct0.IsNTT = ct1.IsNTT = False
+            ev.Mul(ct0, ct1, out)
+        res.append(entry("config4 matrix_ckks Mul N=%d L=%d (4 NTT, 3 MulCoeffsMontgomery, 1 ThenAdd, 3 INTT)" % (N, L),
+                         timed(mul, reps=5), (7 * 16.0 + 3 * 24.0 + 32.0) * N * L * B, B, "ctmul"))
+        del blocks, ct0, ct1, out
     del px, x
     ring.close(); torch.cuda.empty_cache()
 print(json.dumps({"device": torch.cuda.get_device_name(0), "results": res}, indent=1))
