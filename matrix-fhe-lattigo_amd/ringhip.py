@@ -22,7 +22,8 @@ class RingHipError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", "libringhip.so")
+    """RINGHIP_LIB overrides the in-tree build (A/B runs of kernel variants); there is no other search path."""
+    return os.environ.get("RINGHIP_LIB") or os.path.join(_HERE, "lib", "libringhip.so")
 
 
 _lib = None

@@ -16,8 +16,10 @@ Same math as ShoupPolicy::fwd / shoup_mul_acc (modarith.cuh); outputs are canoni
 the C++ kernel and to the reference's Forward.  Layouts (LDS padding j + j/16, kernel-order twiddles) as in
 ntt_kernels.cuh: fwd_tile_body.
 """
+import os
 import sys
 
+PRIO = int(os.environ.get("RH_ASM_PRIO", "0"))   # s_setprio around the load-issue and store phases (0 = off, for A/B runs)
 out = []
 
 
@@ -302,6 +304,8 @@ def csub_all(const_name):
 def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True):
     A0, A1, A2, A3 = ADDR, ADDR + 1, ADDR + 2, ADDR + 3
     emit("; ---- prologue: zero halves of the zero-extended pairs, addresses")
+    if PRIO in (1, 2):
+        emit("s_setprio 3")                                   # a young wave issues its loads ahead of the older waves' butterflies
     for t in (T0, T1):
         emit("v_mov_b32 v%d, 0" % (t.H + 1))
         emit("v_mov_b32 v%d, 0" % (t.G + 1))
@@ -331,6 +335,8 @@ def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True):
     emit("v_lshlrev_b32 v%d, 3, v%d" % (A3, A3))              # addrA
     emit("v_add_u32 v%d, %%[lds], v%d" % (A3, A3))
     emit("s_waitcnt lgkmcnt(0)")                              # round A twiddles (scalar loads)
+    if PRIO in (1, 2):
+        emit("s_setprio 0")
     emit("; ---- round A (twiddles in SGPRs)")
 
     def a_pair_hook(u, i):
@@ -373,6 +379,8 @@ def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True):
     emit("; ---- round C (twiddle quads arrive in slot order; stage u needs slots < 2^(u+1) - 1)")
     round16(lambda slot: (TW0 + 4 * slot, None), stage_hook=lambda u: emit("s_waitcnt vmcnt(%d)" % (15 - ((2 << u) - 1))))
     emit("; ---- canonical reduction: x < 8q -> [0,q)")
+    if PRIO in (1, 3):
+        emit("s_setprio 2")                                   # finish: reduce, transpose, store -> frees the CU slot sooner
     csub_all("nq4")
     csub_all("nq2")
     csub_all("nq")
@@ -400,6 +408,8 @@ def gen_cols():
     Same contract as fwd_cols_body<ShoupPolicy, 4> (ntt_kernels.cuh); operands: tid, pin, pout (row base + 256*cb
     columns, bytes), tw (limb's natural-order table), nq0, nq1, nq4, q4."""
     A0 = ADDR
+    if PRIO in (1, 2):
+        emit("s_setprio 3")
     for t in (T0, T1):
         emit("v_mov_b32 v%d, 0" % (t.H + 1))
         emit("v_mov_b32 v%d, 0" % (t.G + 1))
@@ -412,6 +422,8 @@ def gen_cols():
         k = (kk >> 1) + 8 * (kk & 1)
         emit("global_load_dwordx2 %s, v%d, %%[pin]" % (pair(X(k)), TW0 + k))
     emit("s_waitcnt lgkmcnt(0)")
+    if PRIO in (1, 2):
+        emit("s_setprio 0")
 
     def pair_hook(u, i):
         if u == 0:
