@@ -144,6 +144,16 @@ int rh_bext_decompose_and_split(rh_bext* be, int levelQ, int levelP, int nbPi, i
 int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const uint64_t* cx_dev, const uint64_t* evkQ_dev,
                            const uint64_t* evkP_dev, int beta_key, uint64_t* ct0_dev, uint64_t* ct1_dev, int npoly);
 
+/* Hoisted form (rotations of one ciphertext share the decomposition).  Evaluator.DecomposeNTT
+ * (core/rlwe/evaluator_gadget_product.go:431-453): c2 (levelQ+1 limbs, NTT or coefficient domain per c2_is_ntt) ->
+ * decompQ [beta][npoly][levelQ+1][N], decompP [beta][npoly][levelP+1][N], NTT domain, beta = BaseRNSDecompositionVectorSize. */
+int rh_bext_decompose_ntt(rh_bext* be, int levelQ, int levelP, const uint64_t* c2_dev, int c2_is_ntt, uint64_t* decompQ_dev,
+                          uint64_t* decompP_dev, int npoly);
+/* Evaluator.GadgetProductHoisted (:326-349, :373-429) on such a decomposition; key and outputs as rh_bext_gadget_product */
+int rh_bext_gadget_product_hoisted(rh_bext* be, int levelQ, int levelP, const uint64_t* decompQ_dev, const uint64_t* decompP_dev,
+                                   const uint64_t* evkQ_dev, const uint64_t* evkP_dev, int beta_key, uint64_t* ct0_dev,
+                                   uint64_t* ct1_dev, int npoly);
+
 /* ---- limb-sharded hybrid key switch (BASELINE config 5): one process per GPU owns a subset of the limbs
  * of Q and P and the matching slice of the evaluation key.  Same arithmetic as rh_bext_gadget_product, cut where
  * reconstructRNS (ring/basis_extension.go:550-594) needs limbs of other owners; the exchange (an all-gather of the

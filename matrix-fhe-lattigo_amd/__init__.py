@@ -8,3 +8,4 @@ from .ringhip import (  # noqa: F401
     RingHipError, Ring, SubRing, DevicePoly, BasisExtender, Standard, ConjugateInvariant, Matrix3N, OPS, lib, library_path,
 )
 from .schemes import Ciphertext, MatrixCKKSEvaluator, ckks_tensor_degree1, ckks_polymul  # noqa: F401,E402
+from . import rlwe  # noqa: F401,E402

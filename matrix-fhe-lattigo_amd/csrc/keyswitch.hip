@@ -50,19 +50,105 @@ int rh_overflow_margin(const std::vector<u64>& m, int level) {     // QiOverflow
   return (int)(18446744073709551616.0 / (double)mx);
 }
 
-extern "C" int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, const uint64_t* evkQ,
-                                      const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly) {
-  if (!be || !cx || !evkQ || !evkP || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "gadget_product: null argument");
+// DecomposeSingleNTT (:455-478): digit i of cx -> c2Q (levelQ+1 limbs), c2P (levelP+1 limbs), NTT domain.
+// cx: NTT-domain input (its digit limbs are copied as they are, :467-468), cxInv: its inverse transform.
+static int decompose_single_ntt(rh_bext* be, int levelQ, int levelP, int i, const u64* cx, const u64* cxInv, u64* c2Q, u64* c2P, int npoly) {
   rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
-  if (!RP) return rh_fail(RH_ERR_ARG, "gadget_product: basis extender has no P ring");
-  if (RQ->kind != RH_RING_STANDARD) return rh_fail(RH_ERR_UNSUPPORTED, "gadget_product: standard rings only");
-  if (levelQ < 0 || levelQ >= RQ->L || levelP < 1 || levelP >= RP->L) return rh_fail(RH_ERR_ARG, "gadget_product: need 0 <= levelQ < %d and 1 <= levelP < %d", RQ->L, RP->L);
   const int LQ = levelQ + 1, LP = levelP + 1, N = RQ->N;
-  const int beta = (levelQ + levelP + 1) / (levelP + 1);           // BaseRNSDecompositionVectorSize, params.go:635-642
-  if (beta > beta_key) return rh_fail(RH_ERR_ARG, "gadget_product: key has %d digits, level needs %d", beta_key, beta);
-  if (npoly <= 0) return RH_OK;
+  if (int rc = rh_bext_decompose_and_split(be, levelQ, levelP, LP, i, cxInv, c2Q, c2P, npoly)) return rc;
+  if (int rc = rh_std_ntt_launch(RQ, c2Q, c2Q, npoly, LQ, 0, false, false, 0)) return rc;
+  const int st = i * LP; int ed = st + LP; if (ed > LQ) ed = LQ;
+  if (hipMemcpy2DAsync(c2Q + (size_t)st * N, (size_t)LQ * N * 8, cx + (size_t)st * N, (size_t)LQ * N * 8, (size_t)(ed - st) * N * 8, npoly,
+                       hipMemcpyDeviceToDevice, RQ->stream) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_product: digit copy failed");
+  return rh_std_ntt_launch(RP, c2P, c2P, npoly, LP, 0, false, false, 0);
+}
+
+// the Reduce schedule of gadgetProductMultiplePLazy(Hoisted) (:166-187, :408-428)
+struct ReduceSchedule {
+  int reduce = 0, QiOverF, PiOverF;
+  ReduceSchedule(rh_ring* RQ, int levelQ, rh_ring* RP, int levelP)
+      : QiOverF(rh_overflow_margin(RQ->moduli, levelQ) >> 1), PiOverF(rh_overflow_margin(RP->moduli, levelP) >> 1) {}
+};
+static int reduce2(rh_ring* R, u64* a0, u64* a1, int npoly, int Lr) {
+  if (int rc = rh_vec_launch(R, RH_OP_REDUCE, a0, nullptr, a0, npoly, Lr, 0, nullptr, nullptr)) return rc;
+  return rh_vec_launch(R, RH_OP_REDUCE, a1, nullptr, a1, npoly, Lr, 0, nullptr, nullptr);
+}
+static int after_digit(ReduceSchedule& rs, rh_ring* RQ, rh_ring* RP, u64* ct0, u64* ct1, u64* aP0, u64* aP1, int npoly, int LQ, int LP) {
+  if (rs.reduce % rs.QiOverF == rs.QiOverF - 1) if (int rc = reduce2(RQ, ct0, ct1, npoly, LQ)) return rc;
+  if (rs.reduce % rs.PiOverF == rs.PiOverF - 1) if (int rc = reduce2(RP, aP0, aP1, npoly, LP)) return rc;
+  ++rs.reduce;
+  return RH_OK;
+}
+static int after_all(ReduceSchedule& rs, rh_ring* RQ, rh_ring* RP, u64* ct0, u64* ct1, u64* aP0, u64* aP1, int npoly, int LQ, int LP) {
+  if (rs.reduce % rs.QiOverF != 0) if (int rc = reduce2(RQ, ct0, ct1, npoly, LQ)) return rc;
+  if (rs.reduce % rs.PiOverF != 0) if (int rc = reduce2(RP, aP0, aP1, npoly, LP)) return rc;
+  return RH_OK;
+}
+
+static int ks_check(rh_bext* be, int levelQ, int levelP, int beta_key, const char* who, int* beta) {
+  if (!be) return rh_fail(RH_ERR_ARG, "%s: null basis extender", who);
+  rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
+  if (!RP) return rh_fail(RH_ERR_ARG, "%s: basis extender has no P ring", who);
+  if (RQ->kind != RH_RING_STANDARD) return rh_fail(RH_ERR_UNSUPPORTED, "%s: standard rings only", who);
+  if (levelQ < 0 || levelQ >= RQ->L || levelP < 1 || levelP >= RP->L) return rh_fail(RH_ERR_ARG, "%s: need 0 <= levelQ < %d and 1 <= levelP < %d", who, RQ->L, RP->L);
+  *beta = (levelQ + levelP + 1) / (levelP + 1);                    // BaseRNSDecompositionVectorSize, params.go:635-642
+  if (beta_key >= 0 && *beta > beta_key) return rh_fail(RH_ERR_ARG, "%s: key has %d digits, level needs %d", who, beta_key, *beta);
   (void)hipSetDevice(RQ->device);
   RP->stream = RQ->stream;
+  return RH_OK;
+}
+
+// Evaluator.DecomposeNTT (:431-453): decompQ [beta][npoly][levelQ+1][N], decompP [beta][npoly][levelP+1][N], NTT domain
+extern "C" int rh_bext_decompose_ntt(rh_bext* be, int levelQ, int levelP, const uint64_t* c2, int c2_is_ntt, uint64_t* decompQ,
+                                     uint64_t* decompP, int npoly) {
+  if (!c2 || !decompQ || !decompP) return rh_fail(RH_ERR_ARG, "decompose_ntt: null argument");
+  int beta; if (int rc = ks_check(be, levelQ, levelP, -1, "decompose_ntt", &beta)) return rc;
+  if (npoly <= 0) return RH_OK;
+  rh_ring* RQ = rh_bext_ringQ(be);
+  const int LQ = levelQ + 1, LP = levelP + 1, N = RQ->N;
+  const size_t wq = (size_t)npoly * LQ * N, wp = (size_t)npoly * LP * N;
+  u64* other;
+  if (int rc = rh_bext_scratch(be, 2, wq, &other)) return rc;
+  // :437-445: the missing domain of c2 goes to BuffInvNTT
+  if (int rc = rh_std_ntt_launch(RQ, c2, other, npoly, LQ, 0, c2_is_ntt != 0, false, 0)) return rc;
+  const u64* polyNTT = c2_is_ntt ? c2 : other;
+  const u64* polyInv = c2_is_ntt ? other : c2;
+  for (int i = 0; i < beta; ++i)
+    if (int rc = decompose_single_ntt(be, levelQ, levelP, i, polyNTT, polyInv, decompQ + (size_t)i * wq, decompP + (size_t)i * wp, npoly)) return rc;
+  return RH_OK;
+}
+
+// Evaluator.GadgetProductHoisted (:326-349) = gadgetProductMultiplePLazyHoisted (:373-429) + ModDown NTT->NTT (:33-46)
+extern "C" int rh_bext_gadget_product_hoisted(rh_bext* be, int levelQ, int levelP, const uint64_t* decompQ, const uint64_t* decompP,
+                                              const uint64_t* evkQ, const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly) {
+  if (!decompQ || !decompP || !evkQ || !evkP || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "gadget_product_hoisted: null argument");
+  int beta; if (int rc = ks_check(be, levelQ, levelP, beta_key, "gadget_product_hoisted", &beta)) return rc;
+  if (npoly <= 0) return RH_OK;
+  rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
+  const int LQ = levelQ + 1, LP = levelP + 1, N = RQ->N;
+  const size_t wq = (size_t)npoly * LQ * N, wp = (size_t)npoly * LP * N;
+  u64 *aP0, *aP1;
+  if (int rc = rh_bext_scratch(be, 5, wp, &aP0)) return rc;
+  if (int rc = rh_bext_scratch(be, 6, wp, &aP1)) return rc;
+  const size_t evq_stride = (size_t)RQ->L * N, evp_stride = (size_t)RP->L * N;
+  ReduceSchedule rs(RQ, levelQ, RP, levelP);
+  for (int i = 0; i < beta; ++i) {
+    if (int rc = rh_gadget_mac(RQ, decompQ + (size_t)i * wq, evkQ + ((size_t)i * 2) * evq_stride, evkQ + ((size_t)i * 2 + 1) * evq_stride, ct0, ct1, npoly, LQ, i == 0)) return rc;
+    if (int rc = rh_gadget_mac(RP, decompP + (size_t)i * wp, evkP + ((size_t)i * 2) * evp_stride, evkP + ((size_t)i * 2 + 1) * evp_stride, aP0, aP1, npoly, LP, i == 0)) return rc;
+    if (int rc = after_digit(rs, RQ, RP, ct0, ct1, aP0, aP1, npoly, LQ, LP)) return rc;
+  }
+  if (int rc = after_all(rs, RQ, RP, ct0, ct1, aP0, aP1, npoly, LQ, LP)) return rc;
+  if (int rc = rh_bext_moddown_qp_to_q_ntt(be, levelQ, levelP, ct0, aP0, ct0, npoly)) return rc;
+  return rh_bext_moddown_qp_to_q_ntt(be, levelQ, levelP, ct1, aP1, ct1, npoly);
+}
+
+extern "C" int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, const uint64_t* evkQ,
+                                      const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly) {
+  if (!cx || !evkQ || !evkP || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "gadget_product: null argument");
+  int beta; if (int rc = ks_check(be, levelQ, levelP, beta_key, "gadget_product", &beta)) return rc;
+  if (npoly <= 0) return RH_OK;
+  rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
+  const int LQ = levelQ + 1, LP = levelP + 1, N = RQ->N;
   const size_t wq = (size_t)npoly * LQ * N, wp = (size_t)npoly * LP * N;
   u64 *cxInv, *c2Q, *c2P, *aP0, *aP1;
   if (int rc = rh_bext_scratch(be, 2, wq, &cxInv)) return rc;
@@ -72,40 +158,15 @@ extern "C" int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const
   if (int rc = rh_bext_scratch(be, 6, wp, &aP1)) return rc;
   // ringQ.INTT(cxNTT, cxInvNTT)  (:138)
   if (int rc = rh_std_ntt_launch(RQ, cx, cxInv, npoly, LQ, 0, true, false, 0)) return rc;
-  const int QiOverF = rh_overflow_margin(RQ->moduli, levelQ) >> 1, PiOverF = rh_overflow_margin(RP->moduli, levelP) >> 1;
   const size_t evq_stride = (size_t)RQ->L * N, evp_stride = (size_t)RP->L * N;     // one (digit, component) block
-  int reduce = 0;
+  ReduceSchedule rs(RQ, levelQ, RP, levelP);
   for (int i = 0; i < beta; ++i) {
-    // DecomposeSingleNTT (:455-478)
-    if (int rc = rh_bext_decompose_and_split(be, levelQ, levelP, levelP + 1, i, cxInv, c2Q, c2P, npoly)) return rc;
-    if (int rc = rh_std_ntt_launch(RQ, c2Q, c2Q, npoly, LQ, 0, false, false, 0)) return rc;
-    const int st = i * LP; int ed = st + LP; if (ed > LQ) ed = LQ;
-    // digit limbs are taken from the NTT-domain input as they are (:467-468)
-    if (hipMemcpy2DAsync(c2Q + (size_t)st * N, (size_t)LQ * N * 8, cx + (size_t)st * N, (size_t)LQ * N * 8, (size_t)(ed - st) * N * 8, npoly,
-                         hipMemcpyDeviceToDevice, RQ->stream) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_product: digit copy failed");
-    if (int rc = rh_std_ntt_launch(RP, c2P, c2P, npoly, LP, 0, false, false, 0)) return rc;
-    const u64* eq0 = evkQ + ((size_t)i * 2 + 0) * evq_stride; const u64* eq1 = evkQ + ((size_t)i * 2 + 1) * evq_stride;
-    const u64* ep0 = evkP + ((size_t)i * 2 + 0) * evp_stride; const u64* ep1 = evkP + ((size_t)i * 2 + 1) * evp_stride;
-    if (int rc = rh_gadget_mac(RQ, c2Q, eq0, eq1, ct0, ct1, npoly, LQ, i == 0)) return rc;
-    if (int rc = rh_gadget_mac(RP, c2P, ep0, ep1, aP0, aP1, npoly, LP, i == 0)) return rc;
-    if (reduce % QiOverF == QiOverF - 1) {
-      if (int rc = rh_vec_launch(RQ, RH_OP_REDUCE, ct0, nullptr, ct0, npoly, LQ, 0, nullptr, nullptr)) return rc;
-      if (int rc = rh_vec_launch(RQ, RH_OP_REDUCE, ct1, nullptr, ct1, npoly, LQ, 0, nullptr, nullptr)) return rc;
-    }
-    if (reduce % PiOverF == PiOverF - 1) {
-      if (int rc = rh_vec_launch(RP, RH_OP_REDUCE, aP0, nullptr, aP0, npoly, LP, 0, nullptr, nullptr)) return rc;
-      if (int rc = rh_vec_launch(RP, RH_OP_REDUCE, aP1, nullptr, aP1, npoly, LP, 0, nullptr, nullptr)) return rc;
-    }
-    ++reduce;
+    if (int rc = decompose_single_ntt(be, levelQ, levelP, i, cx, cxInv, c2Q, c2P, npoly)) return rc;
+    if (int rc = rh_gadget_mac(RQ, c2Q, evkQ + ((size_t)i * 2) * evq_stride, evkQ + ((size_t)i * 2 + 1) * evq_stride, ct0, ct1, npoly, LQ, i == 0)) return rc;
+    if (int rc = rh_gadget_mac(RP, c2P, evkP + ((size_t)i * 2) * evp_stride, evkP + ((size_t)i * 2 + 1) * evp_stride, aP0, aP1, npoly, LP, i == 0)) return rc;
+    if (int rc = after_digit(rs, RQ, RP, ct0, ct1, aP0, aP1, npoly, LQ, LP)) return rc;
   }
-  if (reduce % QiOverF != 0) {
-    if (int rc = rh_vec_launch(RQ, RH_OP_REDUCE, ct0, nullptr, ct0, npoly, LQ, 0, nullptr, nullptr)) return rc;
-    if (int rc = rh_vec_launch(RQ, RH_OP_REDUCE, ct1, nullptr, ct1, npoly, LQ, 0, nullptr, nullptr)) return rc;
-  }
-  if (reduce % PiOverF != 0) {
-    if (int rc = rh_vec_launch(RP, RH_OP_REDUCE, aP0, nullptr, aP0, npoly, LP, 0, nullptr, nullptr)) return rc;
-    if (int rc = rh_vec_launch(RP, RH_OP_REDUCE, aP1, nullptr, aP1, npoly, LP, 0, nullptr, nullptr)) return rc;
-  }
+  if (int rc = after_all(rs, RQ, RP, ct0, ct1, aP0, aP1, npoly, LQ, LP)) return rc;
   // eval.ModDown, NTT -> NTT (:41-44)
   if (int rc = rh_bext_moddown_qp_to_q_ntt(be, levelQ, levelP, ct0, aP0, ct0, npoly)) return rc;
   return rh_bext_moddown_qp_to_q_ntt(be, levelQ, levelP, ct1, aP1, ct1, npoly);

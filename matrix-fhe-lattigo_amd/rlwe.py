@@ -1,0 +1,122 @@
+"""Host-side mirror of the key-switch callers in core/rlwe: the evaluator methods that
+sequence the ring hot path for rotations and relinearisation, on device-resident batches.  Every step is a call into
+the HIP library; no key generation, no encoders (those stay with the reference).
+
+  GadgetProduct          core/rlwe/evaluator_gadget_product.go:16-30
+  DecomposeNTT           :431-453        GadgetProductHoisted   :326-349
+  Automorphism           core/rlwe/evaluator_automorphism.go:14-60      AutomorphismHoisted  :62-105
+
+Restrictions (the reference's other branches are not built): ciphertexts in the NTT domain, levelP >= 1
+(gadgetProductMultiplePLazy; the single-P / bit-decomposition branch :190-324 is out of scope), BaseTwoDecomposition 0."""
+import numpy as np
+
+from .ringhip import BasisExtender, DevicePoly, RingHipError, _check, lib
+from .schemes import Ciphertext
+
+
+class GadgetCiphertext:
+    """rlwe.GadgetCiphertext (core/rlwe/gadgetciphertext.go:17-45) in the layout the kernels read:
+    Q part [digit][component < 2][limb of ringQ][N], P part [digit][component][limb of ringP][N], NTT domain, Montgomery
+    form, shared by every ciphertext of a batch."""
+
+    def __init__(self, ringQ, ringP, valueQ, valueP):
+        valueQ, valueP = np.asarray(valueQ, dtype=np.uint64), np.asarray(valueP, dtype=np.uint64)
+        if valueQ.ndim != 4 or valueP.ndim != 4 or valueQ.shape[:2] != valueP.shape[:2] or valueQ.shape[1] != 2:
+            raise RingHipError("GadgetCiphertext: expected (digits, 2, limbs, N) arrays for Q and P")
+        if valueQ.shape[2] != ringQ.L or valueP.shape[2] != ringP.L:
+            raise RingHipError("GadgetCiphertext: limb counts must be those of ringQ / ringP")
+        self.digits = valueQ.shape[0]
+        self.Q = DevicePoly.from_numpy(ringQ, valueQ.reshape(self.digits * 2, ringQ.L, ringQ.N))
+        self.P = DevicePoly.from_numpy(ringP, valueP.reshape(self.digits * 2, ringP.L, ringP.N))
+        self.levelQ, self.levelP = ringQ.L - 1, ringP.L - 1
+
+    def LevelQ(self):
+        return self.levelQ
+
+    def LevelP(self):
+        return self.levelP
+
+
+class Evaluator:
+    """rlwe.Evaluator restricted to the key-switch path; `galois_keys` maps a Galois element to its GadgetCiphertext."""
+
+    def __init__(self, ringQ, ringP, galois_keys=None):
+        self.ringQ, self.ringP = ringQ, ringP
+        self.be = BasisExtender(ringQ, ringP)
+        self.galois_keys = dict(galois_keys or {})
+
+    def close(self):
+        self.be.close()
+
+    # ---- core/rlwe/evaluator_gadget_product.go ---------------------------------------------------------------
+    def GadgetProduct(self, levelQ, cx, gadgetCt, ct):
+        """ct = (<decomp(cx), gadget[0]>, <decomp(cx), gadget[1]>) / P mod Q (:16-30); cx and ct in the NTT domain"""
+        levelQ = min(levelQ, gadgetCt.LevelQ())
+        _check(lib().rh_bext_gadget_product(self.be._h, levelQ, gadgetCt.LevelP(), cx.ptr, gadgetCt.Q.ptr, gadgetCt.P.ptr,
+                                            gadgetCt.digits, ct.Value[0].ptr, ct.Value[1].ptr, cx.npoly))
+
+    def BaseRNSDecompositionVectorSize(self, levelQ, levelP):
+        return (levelQ + levelP + 1) // (levelP + 1)                  # core/rlwe/params.go:635-642
+
+    def DecomposeNTT(self, levelQ, levelP, c2, c2IsNTT):
+        """(:431-453) -> (decompQ, decompP): digit i of poly k is row i*npoly + k of each block"""
+        beta = self.BaseRNSDecompositionVectorSize(levelQ, levelP)
+        rq, rp = self.ringQ.AtLevel(levelQ), self.ringP.AtLevel(levelP)
+        dq, dp = DevicePoly(rq, beta * c2.npoly, levelQ + 1), DevicePoly(rp, beta * c2.npoly, levelP + 1)
+        _check(lib().rh_bext_decompose_ntt(self.be._h, levelQ, levelP, c2.ptr, 1 if c2IsNTT else 0, dq.ptr, dp.ptr, c2.npoly))
+        return dq, dp
+
+    def GadgetProductHoisted(self, levelQ, decompQP, gadgetCt, ct):
+        """(:326-349) on the output of DecomposeNTT"""
+        dq, dp = decompQP
+        npoly = ct.Value[0].npoly
+        _check(lib().rh_bext_gadget_product_hoisted(self.be._h, levelQ, gadgetCt.LevelP(), dq.ptr, dp.ptr, gadgetCt.Q.ptr,
+                                                    gadgetCt.P.ptr, gadgetCt.digits, ct.Value[0].ptr, ct.Value[1].ptr, npoly))
+
+    # ---- core/rlwe/evaluator_automorphism.go -----------------------------------------------------------------
+    def _galois_key(self, galEl):
+        if galEl not in self.galois_keys:                             # CheckAndGetGaloisKey
+            raise RingHipError("cannot apply Automorphism: GaloisKey[%d] is missing" % galEl)
+        return self.galois_keys[galEl]
+
+    def _finish(self, ringQ, ctIn, tmp, galEl, opOut):
+        ringQ.Add(tmp.Value[0], ctIn.Value[0], tmp.Value[0])
+        ringQ.AutomorphismNTT(tmp.Value[0], galEl, opOut.Value[0])   # AutomorphismNTTWithIndex (ring/automorphism.go:52-73)
+        ringQ.AutomorphismNTT(tmp.Value[1], galEl, opOut.Value[1])
+
+    def _check_degree1_ntt(self, ctIn, opOut, who):
+        if ctIn.Degree() != 1 or opOut.Degree() != 1:
+            raise RingHipError("cannot apply %s: input and output Ciphertext must be of degree 1" % who)
+        if not ctIn.IsNTT:
+            raise RingHipError("%s: coefficient-domain ciphertexts are not supported by the device path" % who)
+
+    def Automorphism(self, ctIn, galEl, opOut):
+        """(:14-60): opOut = phi_galEl(ctIn[0] + KS(ctIn[1])_0, KS(ctIn[1])_1)"""
+        self._check_degree1_ntt(ctIn, opOut, "Automorphism")
+        level = min(ctIn.Level(), opOut.Level())
+        ringQ = self.ringQ.AtLevel(level)
+        if galEl == 1:
+            if opOut is not ctIn:
+                for a, b in zip(ctIn.Value, opOut.Value):
+                    ringQ.vec_op("ADD_SCALAR_LAZY", a, None, b, s0=[0] * (level + 1))    # opOut.Copy(ctIn): x + 0, no reduction
+            opOut.IsNTT = ctIn.IsNTT
+            return
+        evk = self._galois_key(galEl)
+        npoly = ctIn.Value[1].npoly
+        tmp = Ciphertext([DevicePoly(ringQ, npoly, level + 1), DevicePoly(ringQ, npoly, level + 1)], is_ntt=True)
+        self.GadgetProduct(level, ctIn.Value[1], evk, tmp)
+        self._finish(ringQ, ctIn, tmp, galEl, opOut)
+        opOut.IsNTT = ctIn.IsNTT
+
+    def AutomorphismHoisted(self, level, ctIn, c1DecompQP, galEl, opOut):
+        """(:62-105): as Automorphism with the decomposition of ctIn[1] shared between rotations"""
+        self._check_degree1_ntt(ctIn, opOut, "AutomorphismHoisted")
+        ringQ = self.ringQ.AtLevel(level)
+        if galEl == 1:
+            return self.Automorphism(ctIn, 1, opOut)
+        evk = self._galois_key(galEl)
+        npoly = ctIn.Value[1].npoly
+        tmp = Ciphertext([DevicePoly(ringQ, npoly, level + 1), DevicePoly(ringQ, npoly, level + 1)], is_ntt=True)
+        self.GadgetProductHoisted(level, c1DecompQP, evk, tmp)
+        self._finish(ringQ, ctIn, tmp, galEl, opOut)
+        opOut.IsNTT = ctIn.IsNTT

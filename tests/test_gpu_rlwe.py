@@ -1,0 +1,90 @@
+"""GPU: the key-switch callers of core/rlwe on device batches -- hoisted decomposition / gadget product and the
+automorphism (rotation) of a degree-1 ciphertext -- against the oracle composition of tests/test_gpu_keyswitch.py.
+Evaluation keys are uniformly random: arithmetic parity needs no key generation; the end-to-end noise
+statistics of a real key switch stay "parity unpinned" (core/rlwe/rlwe_test.go:690-798)."""
+import numpy as np
+import pytest
+
+from conftest import QI60, PI60, uniform_mod
+from test_gpu_keyswitch import oracle_gadget_product
+
+pytestmark = pytest.mark.gpu
+
+
+def make_case(rh, N, nq, np_, npoly, seed):
+    Q, P = QI60[:nq], PI60[:np_]
+    rq, rp = rh.Ring(N, Q), rh.Ring(N, P)
+    rng = np.random.default_rng(seed)
+    beta = (nq - 1 + np_) // np_
+    evkQ = np.stack([np.stack([np.stack([uniform_mod(rng, q, N) for q in Q]) for _ in range(2)]) for _ in range(beta)])
+    evkP = np.stack([np.stack([np.stack([uniform_mod(rng, p, N) for p in P]) for _ in range(2)]) for _ in range(beta)])
+    c0 = np.stack([np.stack([uniform_mod(rng, q, N) for q in Q]) for _ in range(npoly)])
+    c1 = np.stack([np.stack([uniform_mod(rng, q, N) for q in Q]) for _ in range(npoly)])
+    return Q, P, rq, rp, beta, evkQ, evkP, c0, c1
+
+
+@pytest.mark.parametrize("N,nq,np_", [(64, 6, 2), (4096, 7, 3), (8192, 5, 2)])
+def test_hoisted_equals_direct_and_oracle(rh, oracle, N, nq, np_):
+    Q, P, rq, rp, beta, evkQ, evkP, _c0, cx = make_case(rh, N, nq, np_, 2, N + nq)
+    ev = rh.rlwe.Evaluator(rq, rp)
+    gct = rh.rlwe.GadgetCiphertext(rq, rp, evkQ, evkP)
+    levelQ, levelP = nq - 1, np_ - 1
+    pcx = rh.DevicePoly.from_numpy(rq, cx)
+    direct = rh.Ciphertext([rq.NewPoly(2), rq.NewPoly(2)], is_ntt=True)
+    ev.GadgetProduct(levelQ, pcx, gct, direct)
+    d0, d1 = direct.Value[0].numpy(), direct.Value[1].numpy()
+    for k in range(2):
+        e0, e1 = oracle_gadget_product(oracle, rh, N, Q, P, levelQ, levelP, cx[k], evkQ, evkP)
+        assert np.array_equal(d0[k], e0) and np.array_equal(d1[k], e1)
+    # hoisted: decomposition from the NTT-domain input, and from its coefficient-domain form
+    pinv = rq.NewPoly(2); rq.INTT(pcx, pinv)
+    for src, is_ntt in ((pcx, True), (pinv, False)):
+        dq, dp = ev.DecomposeNTT(levelQ, levelP, src, is_ntt)
+        assert dq.npoly == beta * 2 and dp.npoly == beta * 2
+        h = rh.Ciphertext([rq.NewPoly(2), rq.NewPoly(2)], is_ntt=True)
+        ev.GadgetProductHoisted(levelQ, (dq, dp), gct, h)
+        assert np.array_equal(h.Value[0].numpy(), d0) and np.array_equal(h.Value[1].numpy(), d1)
+    # the decomposition itself: digit 1 of poly 1 against the oracle (DecomposeSingleNTT :455-478)
+    srQ = [oracle.SubRingConsts(N, q) for q in Q]; srP = [oracle.SubRingConsts(N, p) for p in P]
+    cxinv = np.stack([oracle.intt(cx[1, i], srQ[i]) for i in range(nq)])
+    LP = np_
+    c2q, c2p = oracle.decompose_and_split(levelQ, levelP, LP, 1, cxinv, Q, P)
+    st, ed = LP, min(2 * LP, nq)
+    expq = np.stack([cx[1, i] if st <= i < ed else oracle.ntt(c2q[i], srQ[i]) for i in range(nq)])
+    expp = np.stack([oracle.ntt(c2p[j], srP[j]) for j in range(np_)])
+    assert np.array_equal(dq.numpy()[1 * 2 + 1], expq) and np.array_equal(dp.numpy()[1 * 2 + 1], expp)
+    ev.close(); rq.close(); rp.close()
+
+
+@pytest.mark.parametrize("N,nq,np_,gal", [(64, 6, 2, 5), (4096, 5, 2, 3), (2048, 4, 2, 2 * 2048 - 1)])
+def test_automorphism_keyswitch_vs_oracle(rh, oracle, N, nq, np_, gal):
+    Q, P, rq, rp, beta, evkQ, evkP, c0, c1 = make_case(rh, N, nq, np_, 2, N + gal)
+    gct = rh.rlwe.GadgetCiphertext(rq, rp, evkQ, evkP)
+    ev = rh.rlwe.Evaluator(rq, rp, galois_keys={gal: gct})
+    levelQ, levelP = nq - 1, np_ - 1
+    ct = rh.Ciphertext([rh.DevicePoly.from_numpy(rq, c0), rh.DevicePoly.from_numpy(rq, c1)], is_ntt=True)
+    out = rh.Ciphertext([rq.NewPoly(2), rq.NewPoly(2)], is_ntt=True)
+    ev.Automorphism(ct, gal, out)
+    g0, g1 = out.Value[0].numpy(), out.Value[1].numpy()
+    OPS = rh.OPS
+    for k in range(2):
+        e0, e1 = oracle_gadget_product(oracle, rh, N, Q, P, levelQ, levelP, c1[k], evkQ, evkP)
+        for i, q in enumerate(Q):
+            s = oracle.vec_op(OPS["ADD"], e0[i], c0[k, i], e0[i], 0, 0, q)
+            assert np.array_equal(g0[k, i], oracle.automorphism_ntt(s, gal))
+            assert np.array_equal(g1[k, i], oracle.automorphism_ntt(e1[i], gal))
+    # hoisted form gives the same bits; inputs untouched
+    dq_dp = ev.DecomposeNTT(levelQ, levelP, ct.Value[1], True)
+    out2 = rh.Ciphertext([rq.NewPoly(2), rq.NewPoly(2)], is_ntt=True)
+    ev.AutomorphismHoisted(levelQ, ct, dq_dp, gal, out2)
+    assert np.array_equal(out2.Value[0].numpy(), g0) and np.array_equal(out2.Value[1].numpy(), g1)
+    assert np.array_equal(ct.Value[0].numpy(), c0) and np.array_equal(ct.Value[1].numpy(), c1)
+    # galEl == 1 is a copy (:20-25); a missing key is an error (:27-30); degree must be 1 (:16-18)
+    out3 = rh.Ciphertext([rq.NewPoly(2), rq.NewPoly(2)], is_ntt=True)
+    ev.Automorphism(ct, 1, out3)
+    assert np.array_equal(out3.Value[0].numpy(), c0) and np.array_equal(out3.Value[1].numpy(), c1)
+    with pytest.raises(rh.RingHipError):
+        ev.Automorphism(ct, gal + 2, out3)
+    with pytest.raises(rh.RingHipError):
+        ev.Automorphism(rh.Ciphertext([ct.Value[0]], is_ntt=True), gal, out3)
+    ev.close(); rq.close(); rp.close()
