@@ -169,7 +169,7 @@ def main():
         except Exception:
             traffic = None
     # what is actually launched inside the timed region (engine.hip: rh_std_ntt_launch)
-    chunk = args.chunk if args.chunk >= 0 else (128 if B >= 256 else 0)
+    chunk = args.chunk if args.chunk >= 0 else (max(1, 2048 // L) if B > max(1, 2048 // L) else 0)   # engine.hip auto rule
     special = args.cluster == 1 or args.persistent == 1
     if special:
         launches, kname = 1, "ntt_fwd_cluster / ntt_fwd_persistent (experimental single launch)"

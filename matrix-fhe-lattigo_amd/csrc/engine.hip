@@ -496,7 +496,10 @@ int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows,
     }
   }
   int chunk = r->chunk_polys;
-  if (chunk < 0) chunk = npoly >= 256 ? 128 : 0;    // auto: pipeline big batches in spans of 128 polys (measured optimum)
+  if (chunk < 0) {                                  // auto: pipeline batches of more than ~2048 limb rows in spans of ~2048 rows
+    const int c = r->auto_span_rows / (Lrows > 0 ? Lrows : 1) > 0 ? r->auto_span_rows / Lrows : 1;   // 128 polys at 16 limbs (measured optimum: 64..128)
+    chunk = npoly > c ? c : 0;
+  }
   const bool two_pass = r->logN > LT;
   if (chunk > 0 && two_pass && phase == 0 && !inverse && !lazy && npoly > chunk)
     return std_ntt_fwd_pipelined(r, in, out, npoly, Lrows, limb0, chunk);
@@ -581,6 +584,7 @@ extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
   if (!r || !key) return rh_fail(RH_ERR_ARG, "set_tuning: null argument");
   if (!strcmp(key, "chunk_polys")) { r->chunk_polys = (int)value; return RH_OK; }
   if (!strcmp(key, "asm_tile")) { r->asm_tile = value != 0; return RH_OK; }
+  if (!strcmp(key, "auto_span_rows")) { if (value < 1) return rh_fail(RH_ERR_ARG, "auto_span_rows must be >= 1"); r->auto_span_rows = (int)value; return RH_OK; }
   if (!strcmp(key, "asm_cols")) { r->asm_cols = (int)value; return RH_OK; }
   if (!strcmp(key, "prefetch")) { r->prefetch = (int)value; return RH_OK; }
   if (!strcmp(key, "order_mix")) { r->order_mix = (int)value; return RH_OK; }

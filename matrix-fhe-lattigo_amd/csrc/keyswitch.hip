@@ -45,6 +45,51 @@ int rh_gadget_mac(rh_ring* r, const u64* c2, const u64* e0, const u64* e1, u64* 
   return RH_OK;
 }
 
+// All digits in one pass (used when the whole decomposition is resident: the hoisted layout [digit][poly][limb][N]):
+// acc_c = sum_i MRedLazy(evk_c[i], c2[i]) with the reference's Reduce schedule (after every `overf` digits and at the end,
+// core/rlwe/evaluator_gadget_product.go:166-187) kept in registers -- the accumulators are written once instead of being
+// read and rewritten per digit.  poly is the fast block index, so the workgroups that share a key row run together.
+__global__ void __launch_bounds__(256)
+gadget_mac_all_kernel(const u64* c2, size_t digit_stride, const u64* __restrict__ evk, size_t evk_stride, int beta, int overf,
+                      u64* acc0, u64* acc1, unsigned n, const LimbConsts* __restrict__ consts, int L, int npoly) {
+  const u32 poly = blockIdx.x % (u32)npoly, limb = blockIdx.x / (u32)npoly;
+  const LimbConsts c = consts[limb];
+  const size_t ro = ((size_t)poly * L + limb) * n, eo = (size_t)limb * n;
+  const unsigned npairs = n >> 1;
+  for (unsigned i = blockIdx.y * blockDim.x + threadIdx.x; i < npairs; i += gridDim.y * blockDim.x) {
+    ulonglong2 a = {0, 0}, b = {0, 0};
+    int red = 0;
+    for (int d = 0; d < beta; ++d) {
+      const ulonglong2 x = *reinterpret_cast<const ulonglong2*>(c2 + (size_t)d * digit_stride + ro + 2 * (size_t)i);
+      const ulonglong2 k0 = *reinterpret_cast<const ulonglong2*>(evk + ((size_t)d * 2) * evk_stride + eo + 2 * (size_t)i);
+      const ulonglong2 k1 = *reinterpret_cast<const ulonglong2*>(evk + ((size_t)d * 2 + 1) * evk_stride + eo + 2 * (size_t)i);
+      a.x += mred_lazy(k0.x, x.x, c.q, c.qinv); a.y += mred_lazy(k0.y, x.y, c.q, c.qinv);
+      b.x += mred_lazy(k1.x, x.x, c.q, c.qinv); b.y += mred_lazy(k1.y, x.y, c.q, c.qinv);
+      if (red % overf == overf - 1) {
+        a.x = bred_add(a.x, c.q, c.bred0); a.y = bred_add(a.y, c.q, c.bred0);
+        b.x = bred_add(b.x, c.q, c.bred0); b.y = bred_add(b.y, c.q, c.bred0);
+      }
+      ++red;
+    }
+    if (red % overf != 0) {
+      a.x = bred_add(a.x, c.q, c.bred0); a.y = bred_add(a.y, c.q, c.bred0);
+      b.x = bred_add(b.x, c.q, c.bred0); b.y = bred_add(b.y, c.q, c.bred0);
+    }
+    *reinterpret_cast<ulonglong2*>(acc0 + ro + 2 * (size_t)i) = a;
+    *reinterpret_cast<ulonglong2*>(acc1 + ro + 2 * (size_t)i) = b;
+  }
+}
+
+static int mac_all(rh_ring* r, const u64* c2, size_t digit_stride, const u64* evk, int beta, int overf, u64* a0, u64* a1, int npoly, int L) {
+  const unsigned n = (unsigned)r->N;
+  unsigned chunks = (n / 2 + 1023) / 1024; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
+  gadget_mac_all_kernel<<<dim3((unsigned)npoly * L, chunks), 256, 0, r->stream>>>(c2, digit_stride, evk, (size_t)r->L * n, beta, overf, a0, a1, n,
+                                                                                 r->d_consts, L, npoly);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_mac_all_kernel launch failed: %s", hipGetErrorString(e));
+  return RH_OK;
+}
+
 int rh_overflow_margin(const std::vector<u64>& m, int level) {     // QiOverflowMargin / PiOverflowMargin, core/rlwe/params.go
   u64 mx = 0; for (int i = 0; i <= level; ++i) if (m[i] > mx) mx = m[i];
   return (int)(18446744073709551616.0 / (double)mx);
@@ -65,26 +110,10 @@ static int decompose_single_ntt(rh_bext* be, int levelQ, int levelP, int i, cons
 
 // the Reduce schedule of gadgetProductMultiplePLazy(Hoisted) (:166-187, :408-428)
 struct ReduceSchedule {
-  int reduce = 0, QiOverF, PiOverF;
+  int QiOverF, PiOverF;
   ReduceSchedule(rh_ring* RQ, int levelQ, rh_ring* RP, int levelP)
       : QiOverF(rh_overflow_margin(RQ->moduli, levelQ) >> 1), PiOverF(rh_overflow_margin(RP->moduli, levelP) >> 1) {}
 };
-static int reduce2(rh_ring* R, u64* a0, u64* a1, int npoly, int Lr) {
-  if (int rc = rh_vec_launch(R, RH_OP_REDUCE, a0, nullptr, a0, npoly, Lr, 0, nullptr, nullptr)) return rc;
-  return rh_vec_launch(R, RH_OP_REDUCE, a1, nullptr, a1, npoly, Lr, 0, nullptr, nullptr);
-}
-static int after_digit(ReduceSchedule& rs, rh_ring* RQ, rh_ring* RP, u64* ct0, u64* ct1, u64* aP0, u64* aP1, int npoly, int LQ, int LP) {
-  if (rs.reduce % rs.QiOverF == rs.QiOverF - 1) if (int rc = reduce2(RQ, ct0, ct1, npoly, LQ)) return rc;
-  if (rs.reduce % rs.PiOverF == rs.PiOverF - 1) if (int rc = reduce2(RP, aP0, aP1, npoly, LP)) return rc;
-  ++rs.reduce;
-  return RH_OK;
-}
-static int after_all(ReduceSchedule& rs, rh_ring* RQ, rh_ring* RP, u64* ct0, u64* ct1, u64* aP0, u64* aP1, int npoly, int LQ, int LP) {
-  if (rs.reduce % rs.QiOverF != 0) if (int rc = reduce2(RQ, ct0, ct1, npoly, LQ)) return rc;
-  if (rs.reduce % rs.PiOverF != 0) if (int rc = reduce2(RP, aP0, aP1, npoly, LP)) return rc;
-  return RH_OK;
-}
-
 static int ks_check(rh_bext* be, int levelQ, int levelP, int beta_key, const char* who, int* beta) {
   if (!be) return rh_fail(RH_ERR_ARG, "%s: null basis extender", who);
   rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
@@ -132,12 +161,8 @@ extern "C" int rh_bext_gadget_product_hoisted(rh_bext* be, int levelQ, int level
   if (int rc = rh_bext_scratch(be, 6, wp, &aP1)) return rc;
   const size_t evq_stride = (size_t)RQ->L * N, evp_stride = (size_t)RP->L * N;
   ReduceSchedule rs(RQ, levelQ, RP, levelP);
-  for (int i = 0; i < beta; ++i) {
-    if (int rc = rh_gadget_mac(RQ, decompQ + (size_t)i * wq, evkQ + ((size_t)i * 2) * evq_stride, evkQ + ((size_t)i * 2 + 1) * evq_stride, ct0, ct1, npoly, LQ, i == 0)) return rc;
-    if (int rc = rh_gadget_mac(RP, decompP + (size_t)i * wp, evkP + ((size_t)i * 2) * evp_stride, evkP + ((size_t)i * 2 + 1) * evp_stride, aP0, aP1, npoly, LP, i == 0)) return rc;
-    if (int rc = after_digit(rs, RQ, RP, ct0, ct1, aP0, aP1, npoly, LQ, LP)) return rc;
-  }
-  if (int rc = after_all(rs, RQ, RP, ct0, ct1, aP0, aP1, npoly, LQ, LP)) return rc;
+  if (int rc = mac_all(RQ, decompQ, wq, evkQ, beta, rs.QiOverF, ct0, ct1, npoly, LQ)) return rc;
+  if (int rc = mac_all(RP, decompP, wp, evkP, beta, rs.PiOverF, aP0, aP1, npoly, LP)) return rc;
   if (int rc = rh_bext_moddown_qp_to_q_ntt(be, levelQ, levelP, ct0, aP0, ct0, npoly)) return rc;
   return rh_bext_moddown_qp_to_q_ntt(be, levelQ, levelP, ct1, aP1, ct1, npoly);
 }
@@ -147,27 +172,15 @@ extern "C" int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const
   if (!cx || !evkQ || !evkP || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "gadget_product: null argument");
   int beta; if (int rc = ks_check(be, levelQ, levelP, beta_key, "gadget_product", &beta)) return rc;
   if (npoly <= 0) return RH_OK;
-  rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
+  rh_ring* RQ = rh_bext_ringQ(be);
   const int LQ = levelQ + 1, LP = levelP + 1, N = RQ->N;
   const size_t wq = (size_t)npoly * LQ * N, wp = (size_t)npoly * LP * N;
-  u64 *cxInv, *c2Q, *c2P, *aP0, *aP1;
-  if (int rc = rh_bext_scratch(be, 2, wq, &cxInv)) return rc;
-  if (int rc = rh_bext_scratch(be, 3, wq, &c2Q)) return rc;
-  if (int rc = rh_bext_scratch(be, 4, wp, &c2P)) return rc;
-  if (int rc = rh_bext_scratch(be, 5, wp, &aP0)) return rc;
-  if (int rc = rh_bext_scratch(be, 6, wp, &aP1)) return rc;
-  // ringQ.INTT(cxNTT, cxInvNTT)  (:138)
-  if (int rc = rh_std_ntt_launch(RQ, cx, cxInv, npoly, LQ, 0, true, false, 0)) return rc;
-  const size_t evq_stride = (size_t)RQ->L * N, evp_stride = (size_t)RP->L * N;     // one (digit, component) block
-  ReduceSchedule rs(RQ, levelQ, RP, levelP);
-  for (int i = 0; i < beta; ++i) {
-    if (int rc = decompose_single_ntt(be, levelQ, levelP, i, cx, cxInv, c2Q, c2P, npoly)) return rc;
-    if (int rc = rh_gadget_mac(RQ, c2Q, evkQ + ((size_t)i * 2) * evq_stride, evkQ + ((size_t)i * 2 + 1) * evq_stride, ct0, ct1, npoly, LQ, i == 0)) return rc;
-    if (int rc = rh_gadget_mac(RP, c2P, evkP + ((size_t)i * 2) * evp_stride, evkP + ((size_t)i * 2 + 1) * evp_stride, aP0, aP1, npoly, LP, i == 0)) return rc;
-    if (int rc = after_digit(rs, RQ, RP, ct0, ct1, aP0, aP1, npoly, LQ, LP)) return rc;
-  }
-  if (int rc = after_all(rs, RQ, RP, ct0, ct1, aP0, aP1, npoly, LQ, LP)) return rc;
-  // eval.ModDown, NTT -> NTT (:41-44)
-  if (int rc = rh_bext_moddown_qp_to_q_ntt(be, levelQ, levelP, ct0, aP0, ct0, npoly)) return rc;
-  return rh_bext_moddown_qp_to_q_ntt(be, levelQ, levelP, ct1, aP1, ct1, npoly);
+  // the whole decomposition stays resident (beta x the size of one digit) so that the key multiply-accumulate is ONE
+  // pass with the accumulators in registers: DecomposeNTT (:431-453) then the hoisted product (:373-429) -- the same
+  // arithmetic and Reduce schedule as gadgetProductMultiplePLazy (:122-188), digit by digit
+  u64 *decQ, *decP;
+  if (int rc = rh_bext_scratch(be, 3, (size_t)beta * wq, &decQ)) return rc;
+  if (int rc = rh_bext_scratch(be, 4, (size_t)beta * wp, &decP)) return rc;
+  if (int rc = rh_bext_decompose_ntt(be, levelQ, levelP, cx, 1, decQ, decP, npoly)) return rc;
+  return rh_bext_gadget_product_hoisted(be, levelQ, levelP, decQ, decP, evkQ, evkP, beta_key, ct0, ct1, npoly);
 }

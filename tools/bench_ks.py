@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Config-5 gadget product timing with the pipeline span as a parameter: bench_ks.py <auto_span_rows> [batch]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import matrix_fhe_lattigo_amd as rh
+from conftest import QI60, PI60
+span, B = int(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 64
+dev = torch.device("cuda", 0); stream = torch.cuda.current_stream()
+N = 1 << 16
+rq, rp = rh.Ring(N, QI60[:24]), rh.Ring(N, PI60[:6])
+for r in (rq, rp):
+    r.set_stream(stream.cuda_stream); r.set_tuning("auto_span_rows", span)
+be = rh.BasisExtender(rq, rp)
+def rb(n, mods):
+    qs = torch.tensor(mods, dtype=torch.int64, device=dev).view(1, len(mods), 1)
+    return torch.randint(0, 1 << 62, (n, len(mods), N), dtype=torch.int64, device=dev) % qs
+xq = rb(B, QI60[:24]); evq, evp = rb(8, QI60[:24]), rb(8, PI60[:6])
+c0, c1 = torch.zeros_like(xq), torch.zeros_like(xq)
+pq, p0, p1 = (rh.DevicePoly.from_torch(rq, t) for t in (xq, c0, c1))
+f = lambda: be.GadgetProduct(23, 5, pq, evq.data_ptr(), evp.data_ptr(), 4, p0, p1)
+f(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(stream)
+for _ in range(3): f()
+e1.record(stream); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 3
+print("span_rows", span, "batch", B, "ms", round(ms, 3), "keyswitch/s", round(B / ms * 1e3))
