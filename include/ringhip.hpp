@@ -155,8 +155,42 @@ class BasisExtender {
   void GadgetProduct(int lq, int lp, const Poly& cx, const Poly& evkQ, const Poly& evkP, int beta, Poly& ct0, Poly& ct1) const {
     check(rh_bext_gadget_product(h_.get(), lq, lp, cx.data(), evkQ.data(), evkP.data(), beta, ct0.data(), ct1.data(), cx.npoly()));
   }
+  // Evaluator.DecomposeNTT / GadgetProductHoisted (core/rlwe/evaluator_gadget_product.go:431-453, 326-429): decompQ / decompP
+  // hold beta * npoly polys (digit i of poly k = poly i*npoly + k)
+  void DecomposeNTT(int lq, int lp, const Poly& c2, bool c2IsNTT, Poly& decompQ, Poly& decompP) const {
+    check(rh_bext_decompose_ntt(h_.get(), lq, lp, c2.data(), c2IsNTT ? 1 : 0, decompQ.data(), decompP.data(), c2.npoly()));
+  }
+  void GadgetProductHoisted(int lq, int lp, const Poly& decompQ, const Poly& decompP, const Poly& evkQ, const Poly& evkP, int beta,
+                            Poly& ct0, Poly& ct1) const {
+    check(rh_bext_gadget_product_hoisted(h_.get(), lq, lp, decompQ.data(), decompP.data(), evkQ.data(), evkP.data(), beta, ct0.data(),
+                                         ct1.data(), ct0.npoly()));
+  }
  private:
   std::shared_ptr<rh_bext> h_;
+};
+
+// limb-sharded key switch (rh_kshard_*): this rank's limbs of the gadget product; the caller moves the
+// gathered source limbs (RCCL all-gather) between Digit / ModDown calls
+class KeySwitchShard {
+ public:
+  KeySwitchShard(const Ring& qLoc, const Ring* pLoc, const std::vector<uint64_t>& allQ, const std::vector<uint64_t>& allP,
+                 const std::vector<int>& ownQ, const std::vector<int>& ownP) {
+    rh_kshard* h = nullptr;
+    check(rh_kshard_create(&h, qLoc.handle(), pLoc ? pLoc->handle() : nullptr, allQ.data(), (int)allQ.size() - 1, allP.data(),
+                           (int)allP.size() - 1, ownQ.data(), (int)ownQ.size(), ownP.empty() ? ownQ.data() : ownP.data(), (int)ownP.size()));
+    h_.reset(h, rh_kshard_destroy);
+  }
+  int NumDigits() const { return rh_kshard_num_digits(h_.get()); }
+  std::pair<int, int> DigitRange(int digit) const { int st = 0, ed = 0; check(rh_kshard_digit_range(h_.get(), digit, &st, &ed)); return {st, ed}; }
+  void Digit(int digit, const uint64_t* srcGathered, const Poly& cxLoc, const uint64_t* evkQLoc, const uint64_t* evkPLoc, Poly& ct0, Poly& ct1,
+             uint64_t* accP0, uint64_t* accP1) const {
+    check(rh_kshard_digit(h_.get(), digit, srcGathered, cxLoc.data(), evkQLoc, evkPLoc, ct0.data(), ct1.data(), accP0, accP1, cxLoc.npoly()));
+  }
+  void ModDown(const uint64_t* srcPGathered, const Poly& ctIn, Poly& ctOut) const {
+    check(rh_kshard_moddown(h_.get(), srcPGathered, ctIn.data(), ctOut.data(), ctIn.npoly()));
+  }
+ private:
+  std::shared_ptr<rh_kshard> h_;
 };
 
 }  // namespace ringhip
