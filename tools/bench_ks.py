@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Config-5 gadget product timing with the pipeline span as a parameter: bench_ks.py <auto_span_rows> [batch]"""
+"""Config-5 gadget product timing: bench_ks.py <auto_span_rows> [batch] [graph]
+`graph`: also replay the call from a HIP graph captured through torch (latency of small batches)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -27,3 +28,22 @@ for _ in range(3): f()
 e1.record(stream); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 3
 print("span_rows", span, "batch", B, "ms", round(ms, 3), "keyswitch/s", round(B / ms * 1e3))
+if len(sys.argv) > 3:
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for r in (rq, rp):
+            r.set_stream(side.cuda_stream)
+        f(); side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            f()
+        g.replay(); side.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(side)
+        for _ in range(10): g.replay()
+        b.record(side); side.synchronize()
+        a2, b2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a2.record(side)
+        for _ in range(10): f()
+        b2.record(side); side.synchronize()
+        print("  graph replay ms", round(a.elapsed_time(b) / 10, 3), "| direct calls ms", round(a2.elapsed_time(b2) / 10, 3))
