@@ -21,6 +21,11 @@
 #include "bext_internal.hpp"
 #include "hostmath.hpp"
 
+// acc += a * b with the carry out of the 64-bit accumulator counted in cnt; b wave-uniform (a scalar-loaded constant)
+RH_DEV void mac_carry(u64& acc, u32& cnt, u32 a, u32 b) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(cnt) : "v"(a), "s"(b) : "vcc");
+}
+
 // NS: compile-time bound on the source-limb count (y_i live in registers, loops fully unrolled); EXACT: nsrc == NS.
 // NS == 0: generic fallback with the y_i in dynamic LDS ([limb][thread]).
 template <int NS, bool EXACT>
@@ -54,8 +59,7 @@ bext_kernel(const u64* in, int in_rows, int src_limb0, int nsrc, const BextSourc
     for (int i = 0; i < nsrc; ++i) ylds[i * 256 + tid] = source(i);
   }
   const u64 v = (u64)vi;
-#pragma unroll 2
-  for (int j = 0; j < ntgt_c; ++j) {                // branch-free body: two targets' constant loads and vt gathers overlap
+  auto one_target = [&](int j) {                    // branch-free body
     const BextTarget t = T[j];
     u64* outp = t.buf ? out1 : out0;
     const int rows = t.buf ? out1_rows : out0_rows;
@@ -63,18 +67,33 @@ bext_kernel(const u64* in, int in_rows, int src_limb0, int nsrc, const BextSourc
     const u64* cj = coef + (size_t)j * nsrc;
     u64 rlo, rhi;
     if constexpr (NS > 0) {
-      u128 acc = (u128)yr[0] * cj[0];
-      rlo = (u64)acc; rhi = (u64)(acc >> 64);
+      // multSum :612-649, the same 128-bit sum by columns: y = y1*2^32 + y0, c = c1*2^32 + c0 with y, c < 2^61, so
+      // y1, c1 < 2^29.  L = sum y0*c0 (carries counted in cL), M1 = sum y0*c1, M2 = sum y1*c0 (each term < 2^61: no
+      // overflow up to 8 terms, carries counted in cM beyond), H = sum y1*c1 (< 2^63 for 32 terms).  One multiply-add
+      // per partial product instead of a 128-bit add with compare-and-select carries per term.
+      u64 Lc = 0, M1 = 0, M2 = 0, H = 0;
+      u32 cL = 0, cM = 0;
 #pragma unroll
-      for (int i = 1; i < NS; ++i) {                                      // multSum :612-649
+      for (int i = 0; i < NS; ++i) {
         if (EXACT || i < nsrc) {
-          const u128 m = (u128)yr[i] * cj[i];
-          const u64 mlo = (u64)m, mhi = (u64)(m >> 64);
-          const u64 s = rlo + mlo;
-          rhi += mhi + (u64)(s < rlo);
-          rlo = s;
+          const u64 cw = cj[i];
+          const u32 c0 = (u32)cw, c1 = (u32)(cw >> 32);
+          const u32 y0 = (u32)yr[i], y1 = (u32)(yr[i] >> 32);
+          mac_carry(Lc, cL, y0, c0);
+          if constexpr (NS <= 8) {
+            M1 += (u64)y0 * c1;
+            M2 += (u64)y1 * c0;
+          } else {
+            mac_carry(M1, cM, y0, c1);
+            mac_carry(M2, cM, y1, c0);
+          }
+          H += (u64)y1 * c1;
         }
       }
+      const u64 mid = M1 + M2;
+      const u64 cm = (u64)(mid < M1) + cM;                                // weight 2^96
+      rlo = Lc + (mid << 32);
+      rhi = H + cL + (mid >> 32) + (u64)(rlo < Lc) + (cm << 32);
     } else {
       u128 acc = (u128)ylds[tid] * cj[0];
       rlo = (u64)acc; rhi = (u64)(acc >> 64);
@@ -94,7 +113,10 @@ bext_kernel(const u64* in, int in_rows, int src_limb0, int nsrc, const BextSourc
       r = mred(2 * t.p - y + r, t.md_scalar, t.p, t.pinv);                // SubThenMulScalarMontgomeryTwoModulus
     }
     if (live) outp[o] = r;
-  }
+  };
+  int j = 0;
+  for (; j + 1 < ntgt_c; j += 2) { one_target(j); one_target(j + 1); }   // two independent targets per trip: their constant loads,
+  if (j < ntgt_c) one_target(j);                                         // vt gathers and multiply-add chains interleave
   if (post >= 1 && live) {
     for (int j = ntgt_c; j < ntgt; ++j) {
       const BextTarget t = T[j];
