@@ -348,7 +348,9 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
       if (r->asm_tile && S1 > 0) ntt_inv_tile_asm<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly);
       else ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, (S1 == 0 && r->inv_scale) ? 1 : 0, npoly);
     }
-    if (S1 > 0 && phase != 2) launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, logN, r->inv_scale ? 1 : 0);
+    if (S1 == 4 && phase != 2 && r->asm_cols && r->asm_tile && r->inv_scale)
+      ntt_inv_cols16_asm<<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows);
+    else if (S1 > 0 && phase != 2) launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, logN, r->inv_scale ? 1 : 0);
   }
   return check_launch("ntt");
 }
@@ -424,8 +426,12 @@ template <int S1>
 static void launch_inv_fused(rh_ring* r, const u64* in1, u64* out1, unsigned n1, int npoly1, u64* data2, unsigned n2,
                              size_t toff, int limb0, const LimbConsts* c, int Lrows) {
   const unsigned grid = n1 > n2 ? n1 : n2;
-  ntt_inv_fused_asm<S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff,
-                                                     r->d_lastw + limb0, c, Lrows, r->logN);
+  if (S1 == 4 && r->asm_cols)
+    ntt_inv_fused_asm<S1, true><<<grid, 256, 0, r->stream>>>(in1, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff,
+                                                             r->d_lastw + limb0, c, Lrows, r->logN);
+  else
+    ntt_inv_fused_asm<S1, false><<<grid, 256, 0, r->stream>>>(in1, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff,
+                                                              r->d_lastw + limb0, c, Lrows, r->logN);
 }
 // Inverse transform of a large batch: launch j = tile stages of span j fused with column stages (+ N^-1) of span j-1.
 static int std_ntt_inv_pipelined(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, int chunk) {

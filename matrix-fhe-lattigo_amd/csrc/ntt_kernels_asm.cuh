@@ -186,6 +186,32 @@ RH_DEV void inv_tile_asm_body(u64* lds, const u32 b, const u64* in, u64* out, co
                  [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4)
                : NTT_TILE_ASM_CLOBBERS);
 }
+// inverse column stages with N^-1 folded in, N = 2^16 only (S1 = 4): same contract as inv_cols_body<4>(scale = 1)
+RH_DEV void inv_cols16_asm_body(const u32 b, u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
+                                const LimbConsts* __restrict__ consts, int L) {
+  const u32 limb = b % (u32)L;
+  const u32 r = b / (u32)L;
+  const size_t base = (((size_t)(r >> 4) * L + limb) << 16) + (r & 15) * 256;
+  const u64 pin = uni64((u64)(size_t)(data + base));
+  const u64 tw = uni64((u64)(size_t)(twn + ((size_t)limb << 16)));
+  const u64 q = uni64(consts[limb].q);
+  const u64 iw = uni64(consts[limb].ninv_w), ip = uni64(consts[limb].ninv_wp);
+  const u64 lw = uni64(lastw[limb].w), lp = uni64(lastw[limb].wp);
+  const u64 nq = (u64)0 - q, nq2 = (u64)0 - 2 * q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
+  const u32 tid = threadIdx.x;
+  asm volatile(NTT_COLS16_INV_ASM_BODY
+               :
+               : [tid] "v"(tid), [pin] "s"(pin), [tw] "s"(tw),
+                 [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4),
+                 [iw0] "s"((u32)iw), [iw1] "s"((u32)(iw >> 32)), [ip0] "s"((u32)ip), [ip1] "s"((u32)(ip >> 32)),
+                 [lw0] "s"((u32)lw), [lw1] "s"((u32)(lw >> 32)), [lp0] "s"((u32)lp), [lp1] "s"((u32)(lp >> 32))
+               : NTT_TILE_ASM_CLOBBERS);
+}
+__global__ void __launch_bounds__(256)
+ntt_inv_cols16_asm(u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw, const LimbConsts* __restrict__ consts, int L) {
+  inv_cols16_asm_body(blockIdx.x, data, twn, lastw, consts, L);
+}
+
 __global__ void __launch_bounds__(256)
 ntt_inv_tile_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts,
                  int L, int logN, int npoly) {
@@ -193,13 +219,16 @@ ntt_inv_tile_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const Lim
   inv_tile_asm_body(lds, blockIdx.x, in, out, twk, consts, L, logN, npoly);
 }
 // software-pipelined inverse: tile stages of span j (in -> out), then column stages + N^-1 of span j-1 (in place)
-template <int S1>
+template <int S1, bool ASMCOLS = false>
 __global__ void __launch_bounds__(256)
 ntt_inv_fused_asm(const u64* in1, u64* out1, unsigned n1, int npoly1, u64* data2, unsigned n2,
                   const tw2* __restrict__ twk, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
                   const LimbConsts* __restrict__ consts, int L, int logN) {
   __shared__ u64 lds[LDS_WORDS];
-  if (blockIdx.x < n2) inv_cols_body<S1>(blockIdx.x, data2, twn, lastw, consts, L, logN, 1);
+  if (blockIdx.x < n2) {
+    if constexpr (S1 == 4 && ASMCOLS) inv_cols16_asm_body(blockIdx.x, data2, twn, lastw, consts, L);
+    else inv_cols_body<S1>(blockIdx.x, data2, twn, lastw, consts, L, logN, 1);
+  }
   if (blockIdx.x < n1) inv_tile_asm_body(lds, blockIdx.x, in1, out1, twk, consts, L, logN, npoly1);
 }
 

@@ -289,3 +289,22 @@ def test_asm_column_stages_identical(rh, oracle, L, B):
     sr = oracle.SubRingConsts(N, mods[L - 1])
     assert np.array_equal(p.numpy()[B - 1, L - 1], oracle.ntt(a[B - 1, L - 1], sr))
     ring.close()
+
+
+@pytest.mark.parametrize("L,B", [(3, 2), (16, 5), (2, 300)])
+def test_asm_inverse_column_stages_identical(rh, oracle, L, B):
+    # N = 2^16: hand-scheduled inverse column stages with N^-1 folded in (standalone and fused launches) vs the C++ body
+    N, mods = 1 << 16, QI60[:L]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(L * 17 + B)
+    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    p = rh.DevicePoly.from_numpy(ring, a)
+    ref, o = ring.NewPoly(B), ring.NewPoly(B)
+    ring.set_tuning("asm_cols", 0); ring.INTT(p, ref)
+    ring.set_tuning("asm_cols", 1); ring.INTT(p, o); ring.sync()
+    assert np.array_equal(o.numpy(), ref.numpy())
+    sr = oracle.SubRingConsts(N, mods[L - 1])
+    assert np.array_equal(o.numpy()[B - 1, L - 1], oracle.intt(a[B - 1, L - 1], sr))
+    ring.INTT(p, p); ring.NTT(p, p); ring.sync()        # in place, and back
+    assert np.array_equal(p.numpy(), a)
+    ring.close()

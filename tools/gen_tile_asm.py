@@ -434,6 +434,103 @@ def gen_cols():
         emit("global_store_dwordx2 v%d, %s, %%[pout]" % (TW0 + k, pair(X(k))))
 
 
+def shoup_mul_steps(v, tw, t):
+    """v <- v * w in [0,4q) for the data pair v (any 64-bit value), tw = (w0, w1, p0, p1) operand names (SGPRs): the
+    multiplication half of inv_butterfly_steps.  11 slow + 1 fast."""
+    w0, w1, p0, p1 = tw
+    V = pair(v)
+    vl, vh = "v%d" % v, "v%d" % (v + 1)
+    Q, H, G, R, S = pair(t.Q), pair(t.H), pair(t.G), pair(t.R), pair(t.S)
+    ql, qh = "v%d" % t.Q, "v%d" % (t.Q + 1)
+    return [
+        "v_mul_hi_u32 v%d, %s, %s" % (t.H, vh, p0),
+        "v_mul_hi_u32 v%d, %s, %s" % (t.G, vl, p1),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (Q, DUMMY, vh, p1, H),
+        "v_mad_u64_u32 %s, %s, %s, %s, 0" % (R, DUMMY, vl, w1),
+        "v_lshl_add_u64 %s, %s, 0, %s" % (Q, Q, G),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (S, DUMMY, vh, w0, R),
+        "v_mad_u64_u32 %s, %s, %s, %%[nq1], %s" % (R, DUMMY, ql, S),
+        "v_mad_u64_u32 %s, %s, %s, %%[nq0], %s" % (S, DUMMY, qh, R),
+        "v_mad_u64_u32 %s, %s, %s, %s, 0" % (R, DUMMY, vl, w0),
+        "v_add_u32 v%d, v%d, v%d" % (t.R + 1, t.S, t.R + 1),
+        "v_mad_u64_u32 %s, %s, %s, %%[nq0], %s" % (V, DUMMY, ql, R),
+    ]
+
+
+def csub_steps(x, const_name, t):
+    """x <- x - bound if x >= bound (bound given as the SGPR pair holding -bound); 3 slow + 1 fast"""
+    return [
+        "v_lshl_add_u64 %s, %s, 0, %%[%s]" % (pair(t.T), pair(x), const_name),
+        "v_ashrrev_i32 v%d, 31, v%d" % (t.M, t.T + 1),
+        "v_bfi_b32 v%d, v%d, v%d, v%d" % (x, t.M, x, t.T),
+        "v_bfi_b32 v%d, v%d, v%d, v%d" % (x + 1, t.M, x + 1, t.T + 1),
+    ]
+
+
+def scaled_last_butterfly_steps(u, v, t):
+    """last inverse stage with N^-1 folded in (inv_cols_body, ntt_kernels.cuh): U, V < 4q ->
+    X = canon((U + V) * ninv) -> U,  Y = canon((U + 4q - V) * (psi * ninv)) -> V, both in [0, q)."""
+    U, V = pair(u), pair(v)
+    ul, uh, vl, vh = "v%d" % u, "v%d" % (u + 1), "v%d" % v, "v%d" % (v + 1)
+    ninv = ("%[iw0]", "%[iw1]", "%[ip0]", "%[ip1]")
+    last = ("%[lw0]", "%[lw1]", "%[lp0]", "%[lp1]")
+    steps = [
+        "v_lshl_add_u64 %s, %s, 0, %s" % (pair(t.T), U, V),          # T = U + V
+        "v_lshl_add_u64 %s, %s, 0, %%[q4]" % (U, U),                 # U = U + 4q
+        "v_sub_co_u32 %s, %s, %s, %s" % (vl, t.cc, ul, vl),          # V = U + 4q - V
+        "@CARRY",
+        "v_subb_co_u32 %s, %s, %s, %s, %s" % (vh, t.cc, uh, vh, t.cc),
+        "v_mov_b32 %s, v%d" % (ul, t.T),                             # U = T
+        "v_mov_b32 %s, v%d" % (uh, t.T + 1),
+    ]
+    steps += shoup_mul_steps(u, ninv, t) + csub_steps(u, "nq2", t) + csub_steps(u, "nq", t)
+    steps += shoup_mul_steps(v, last, t) + csub_steps(v, "nq2", t) + csub_steps(v, "nq", t)
+    return steps
+
+
+def gen_cols_inv():
+    """Inverse column stages for N = 2^16 (S1 = 4), scaled: stages with 8, 4, 2 blocks (twiddles tw[8..15], tw[4..7],
+    tw[2..3], wave-uniform), then the last stage with N^-1 folded into both multipliers; canonical outputs.  Same contract
+    as inv_cols_body<4>(scale = 1).  In place."""
+    if PRIO in (1, 2):
+        emit("s_setprio 3")
+    for t in (T0, T1):
+        emit("v_mov_b32 v%d, 0" % (t.H + 1))
+        emit("v_mov_b32 v%d, 0" % (t.G + 1))
+    for slot in range(1, 15):
+        emit("s_load_dwordx4 s[%d:%d], %%[tw], %d" % (36 + 4 * slot, 39 + 4 * slot, 16 * (slot + 1)))
+    emit("v_lshlrev_b32 v%d, 3, %%[tid]" % TW0)
+    for k in range(1, 16):
+        emit("v_add_u32 v%d, %d, v%d" % (TW0 + k, 32768 * k, TW0))
+    for k in range(16):
+        emit("global_load_dwordx2 %s, v%d, %%[pin]" % (pair(X(k)), TW0 + k))
+    emit("s_waitcnt lgkmcnt(0)")
+    if PRIO in (1, 2):
+        emit("s_setprio 0")
+    emit("s_waitcnt vmcnt(0)")
+    for u in (3, 2, 1):
+        h = 8 >> u
+        bfs = []
+        for g in range(1 << u):
+            slot = (1 << u) - 1 + g
+            sg = ("s%d" % (36 + 4 * slot), "s%d" % (37 + 4 * slot), "s%d" % (38 + 4 * slot), "s%d" % (39 + 4 * slot))
+            for e in range(h):
+                k = g * 2 * h + e
+                bfs.append((X(k), X(k + h), sg))
+        for i in range(0, len(bfs), 2):
+            a = inv_butterfly_steps(bfs[i][0], bfs[i][1], None, T0, bfs[i][2])
+            b = inv_butterfly_steps(bfs[i + 1][0], bfs[i + 1][1], None, T1, bfs[i + 1][2])
+            for ins in interleave(a, b):
+                emit(ins)
+    for e in range(0, 8, 2):
+        a = scaled_last_butterfly_steps(X(e), X(e + 8), T0)
+        b = scaled_last_butterfly_steps(X(e + 1), X(e + 9), T1)
+        for ins in interleave(a, b):
+            emit(ins)
+    for k in range(16):
+        emit("global_store_dwordx2 v%d, %s, %%[pin]" % (TW0 + k, pair(X(k))))
+
+
 def render(name, lines):
     body = "\n".join('  "%s\\n\\t"' % l for l in lines)
     return "#define %s \\\n%s\n" % (name, body.replace("\n", " \\\n"))
@@ -451,12 +548,15 @@ del out[:]
 gen_cols()
 cols = list(out)
 del out[:]
+gen_cols_inv()
+cols_inv = list(out)
+del out[:]
 gen_inverse()
 inv = list(out)
 clob_v = ", ".join('"v%d"' % i for i in range(NVGPR_USED))
 clob_s = ", ".join('"s%d"' % i for i in range(36, 100))
 text = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  forward: %d instructions, inverse: %d.\n" % (len(fwd), len(inv))
-text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_SC1_ASM_BODY", fwd_sc1) + render("NTT_TILE_PRE_ASM_BODY", fwd_pre) + render("NTT_COLS16_ASM_BODY", cols) + render("NTT_TILE_INV_ASM_BODY", inv)
+text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_SC1_ASM_BODY", fwd_sc1) + render("NTT_TILE_PRE_ASM_BODY", fwd_pre) + render("NTT_COLS16_ASM_BODY", cols) + render("NTT_COLS16_INV_ASM_BODY", cols_inv) + render("NTT_TILE_INV_ASM_BODY", inv)
 text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v, clob_s)
 clob_v_pre = ", ".join('"v%d"' % i for i in range(32, NVGPR_USED))     # v0..v31 are read-write operands there
 text += "#define NTT_TILE_PRE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v_pre, clob_s)
