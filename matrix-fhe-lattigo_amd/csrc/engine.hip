@@ -333,7 +333,9 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
       if (phase != 2) {
         if (lazy) launch_fwd_cols<MontPolicy>(S1, g1, st, in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN);
         else if (r->cols2) launch_fwd_cols2<ShoupPolicy>(S1, dim3(rows * 8), st, in, out, r->d_tw_fwd + toff, c, Lrows, logN);
-        else if (S1 == 4 && r->asm_cols && r->asm_tile) ntt_fwd_cols16_asm<<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows);
+        else if (S1 == 4 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<4><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows);
+        else if (S1 == 3 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<3><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows);
+        else if (S1 == 2 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<2><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows);
       else      launch_fwd_cols<ShoupPolicy>(S1, g1, st, in, out, r->d_tw_fwd + toff, c, Lrows, logN);
       }
       src = out;
@@ -348,8 +350,10 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
       if (r->asm_tile && S1 > 0) ntt_inv_tile_asm<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly);
       else ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, (S1 == 0 && r->inv_scale) ? 1 : 0, npoly);
     }
-    if (S1 == 4 && phase != 2 && r->asm_cols && r->asm_tile && r->inv_scale)
-      ntt_inv_cols16_asm<<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows);
+    const bool acols = phase != 2 && r->asm_cols && r->asm_tile && r->inv_scale;
+    if (S1 == 4 && acols) ntt_inv_cols_asm<4><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows);
+    else if (S1 == 3 && acols) ntt_inv_cols_asm<3><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows);
+    else if (S1 == 2 && acols) ntt_inv_cols_asm<2><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows);
     else if (S1 > 0 && phase != 2) launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, logN, r->inv_scale ? 1 : 0);
   }
   return check_launch("ntt");
@@ -361,7 +365,7 @@ static void launch_fused(rh_ring* r, const u64* in1, u64* out1, unsigned n1, u64
   const unsigned grid = n1 > n2 ? n1 : n2;
   if (r->asm_tile && r->prefetch)
     ntt_fwd_fused_pre<S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN);
-  else if (r->asm_tile && S1 == 4 && r->asm_cols)
+  else if (r->asm_tile && S1 >= 2 && S1 <= 4 && r->asm_cols)
     ntt_fwd_fused_asm<S1, true><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN, r->order_mix);
   else if (r->asm_tile)
     ntt_fwd_fused_asm<S1, false><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN, r->order_mix);
@@ -426,7 +430,7 @@ template <int S1>
 static void launch_inv_fused(rh_ring* r, const u64* in1, u64* out1, unsigned n1, int npoly1, u64* data2, unsigned n2,
                              size_t toff, int limb0, const LimbConsts* c, int Lrows) {
   const unsigned grid = n1 > n2 ? n1 : n2;
-  if (S1 == 4 && r->asm_cols)
+  if (S1 >= 2 && S1 <= 4 && r->asm_cols)
     ntt_inv_fused_asm<S1, true><<<grid, 256, 0, r->stream>>>(in1, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff,
                                                              r->d_lastw + limb0, c, Lrows, r->logN);
   else

@@ -44,34 +44,40 @@ RH_DEV void fwd_tile_asm_body(u64* lds, const u32 b, const u64* in, u64* out, co
                  : NTT_TILE_ASM_CLOBBERS);
 }
 
-// column stages, N = 2^16 only (S1 = 4): hand-scheduled radix-16 round with wave-uniform twiddles; same contract as
-// fwd_cols_body<ShoupPolicy, 4> (outputs < 8q, any representative: the tile stages that follow reduce canonically)
-RH_DEV void fwd_cols16_asm_body(const u32 b, const u64* in, u64* out, const tw2* __restrict__ twn,
-                                const LimbConsts* __restrict__ consts, int L) {
+// column stages for N = 2^14 .. 2^16 (S1 = 2..4): hand-scheduled radix-2^S1 register round with wave-uniform twiddles;
+// same contract as fwd_cols_body<ShoupPolicy, S1> (outputs < 8q, any representative: the tile stages reduce canonically)
+constexpr bool has_asm_cols(int S1) { return S1 >= 2 && S1 <= 4; }
+#define RH_COLS_FWD_ASM(BODY)                                                                                       \
+  asm volatile(BODY : : [tid] "v"(tid), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw), [nq0] "s"((u32)nq),        \
+               [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4) : NTT_TILE_ASM_CLOBBERS)
+template <int S1>
+RH_DEV void fwd_cols_asm_body(const u32 b, const u64* in, u64* out, const tw2* __restrict__ twn,
+                              const LimbConsts* __restrict__ consts, int L) {
+  static_assert(has_asm_cols(S1), "asm column stages exist for S1 = 2..4");
+  constexpr int logN = LT + S1;
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
-  const size_t base = (((size_t)(r >> 4) * L + limb) << 16) + (r & 15) * 256;
+  const size_t base = (((size_t)(r >> 4) * L + limb) << logN) + (r & 15) * 256;
   const u64 pin = uni64((u64)(size_t)(in + base));
   const u64 pout = uni64((u64)(size_t)(out + base));
-  const u64 tw = uni64((u64)(size_t)(twn + ((size_t)limb << 16)));
+  const u64 tw = uni64((u64)(size_t)(twn + ((size_t)limb << logN)));
   const u64 q = uni64(consts[limb].q);
   const u64 nq = (u64)0 - q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
   const u32 tid = threadIdx.x;
-  asm volatile(NTT_COLS16_ASM_BODY
-               :
-               : [tid] "v"(tid), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw),
-                 [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4)
-               : NTT_TILE_ASM_CLOBBERS);
+  if constexpr (S1 == 4) RH_COLS_FWD_ASM(NTT_COLS16_ASM_BODY);
+  else if constexpr (S1 == 3) RH_COLS_FWD_ASM(NTT_COLS8_ASM_BODY);
+  else RH_COLS_FWD_ASM(NTT_COLS4_ASM_BODY);
 }
 template <int S1, bool ASMCOLS>
 RH_DEV void fwd_cols_best(const u32 b, const u64* in, u64* out, const tw2* __restrict__ twn,
                           const LimbConsts* __restrict__ consts, int L, int logN) {
-  if constexpr (S1 == 4 && ASMCOLS) fwd_cols16_asm_body(b, in, out, twn, consts, L);
+  if constexpr (has_asm_cols(S1) && ASMCOLS) fwd_cols_asm_body<S1>(b, in, out, twn, consts, L);
   else fwd_cols_body<ShoupPolicy, S1>(b, in, out, twn, consts, L, logN);
 }
+template <int S1>
 __global__ void __launch_bounds__(256)
-ntt_fwd_cols16_asm(const u64* in, u64* out, const tw2* __restrict__ twn, const LimbConsts* __restrict__ consts, int L) {
-  fwd_cols16_asm_body(blockIdx.x, in, out, twn, consts, L);
+ntt_fwd_cols_asm(const u64* in, u64* out, const tw2* __restrict__ twn, const LimbConsts* __restrict__ consts, int L) {
+  fwd_cols_asm_body<S1>(blockIdx.x, in, out, twn, consts, L);
 }
 
 __global__ void __launch_bounds__(256)
@@ -186,30 +192,35 @@ RH_DEV void inv_tile_asm_body(u64* lds, const u32 b, const u64* in, u64* out, co
                  [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4)
                : NTT_TILE_ASM_CLOBBERS);
 }
-// inverse column stages with N^-1 folded in, N = 2^16 only (S1 = 4): same contract as inv_cols_body<4>(scale = 1)
-RH_DEV void inv_cols16_asm_body(const u32 b, u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
-                                const LimbConsts* __restrict__ consts, int L) {
+// inverse column stages with N^-1 folded in, S1 = 2..4: same contract as inv_cols_body<S1>(scale = 1)
+#define RH_COLS_INV_ASM(BODY)                                                                                                     \
+  asm volatile(BODY : : [tid] "v"(tid), [pin] "s"(pin), [tw] "s"(tw), [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)),            \
+               [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4), [iw0] "s"((u32)iw), [iw1] "s"((u32)(iw >> 32)),       \
+               [ip0] "s"((u32)ip), [ip1] "s"((u32)(ip >> 32)), [lw0] "s"((u32)lw), [lw1] "s"((u32)(lw >> 32)),                   \
+               [lp0] "s"((u32)lp), [lp1] "s"((u32)(lp >> 32)) : NTT_TILE_ASM_CLOBBERS)
+template <int S1>
+RH_DEV void inv_cols_asm_body(const u32 b, u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
+                              const LimbConsts* __restrict__ consts, int L) {
+  static_assert(has_asm_cols(S1), "asm column stages exist for S1 = 2..4");
+  constexpr int logN = LT + S1;
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
-  const size_t base = (((size_t)(r >> 4) * L + limb) << 16) + (r & 15) * 256;
+  const size_t base = (((size_t)(r >> 4) * L + limb) << logN) + (r & 15) * 256;
   const u64 pin = uni64((u64)(size_t)(data + base));
-  const u64 tw = uni64((u64)(size_t)(twn + ((size_t)limb << 16)));
+  const u64 tw = uni64((u64)(size_t)(twn + ((size_t)limb << logN)));
   const u64 q = uni64(consts[limb].q);
   const u64 iw = uni64(consts[limb].ninv_w), ip = uni64(consts[limb].ninv_wp);
   const u64 lw = uni64(lastw[limb].w), lp = uni64(lastw[limb].wp);
   const u64 nq = (u64)0 - q, nq2 = (u64)0 - 2 * q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
   const u32 tid = threadIdx.x;
-  asm volatile(NTT_COLS16_INV_ASM_BODY
-               :
-               : [tid] "v"(tid), [pin] "s"(pin), [tw] "s"(tw),
-                 [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4),
-                 [iw0] "s"((u32)iw), [iw1] "s"((u32)(iw >> 32)), [ip0] "s"((u32)ip), [ip1] "s"((u32)(ip >> 32)),
-                 [lw0] "s"((u32)lw), [lw1] "s"((u32)(lw >> 32)), [lp0] "s"((u32)lp), [lp1] "s"((u32)(lp >> 32))
-               : NTT_TILE_ASM_CLOBBERS);
+  if constexpr (S1 == 4) RH_COLS_INV_ASM(NTT_COLS16_INV_ASM_BODY);
+  else if constexpr (S1 == 3) RH_COLS_INV_ASM(NTT_COLS8_INV_ASM_BODY);
+  else RH_COLS_INV_ASM(NTT_COLS4_INV_ASM_BODY);
 }
+template <int S1>
 __global__ void __launch_bounds__(256)
-ntt_inv_cols16_asm(u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw, const LimbConsts* __restrict__ consts, int L) {
-  inv_cols16_asm_body(blockIdx.x, data, twn, lastw, consts, L);
+ntt_inv_cols_asm(u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw, const LimbConsts* __restrict__ consts, int L) {
+  inv_cols_asm_body<S1>(blockIdx.x, data, twn, lastw, consts, L);
 }
 
 __global__ void __launch_bounds__(256)
@@ -226,7 +237,7 @@ ntt_inv_fused_asm(const u64* in1, u64* out1, unsigned n1, int npoly1, u64* data2
                   const LimbConsts* __restrict__ consts, int L, int logN) {
   __shared__ u64 lds[LDS_WORDS];
   if (blockIdx.x < n2) {
-    if constexpr (S1 == 4 && ASMCOLS) inv_cols16_asm_body(blockIdx.x, data2, twn, lastw, consts, L);
+    if constexpr (has_asm_cols(S1) && ASMCOLS) inv_cols_asm_body<S1>(blockIdx.x, data2, twn, lastw, consts, L);
     else inv_cols_body<S1>(blockIdx.x, data2, twn, lastw, consts, L, logN, 1);
   }
   if (blockIdx.x < n1) inv_tile_asm_body(lds, blockIdx.x, in1, out1, twk, consts, L, logN, npoly1);

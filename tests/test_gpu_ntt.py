@@ -272,10 +272,10 @@ def test_fused_prefetch_identical(rh, oracle, logN, L, B):
     ring.close()
 
 
-@pytest.mark.parametrize("L,B", [(3, 2), (16, 5), (2, 300)])
-def test_asm_column_stages_identical(rh, oracle, L, B):
-    # N = 2^16: hand-scheduled column stages (standalone launch for small batches, fused launch for B >= 256) vs the C++ body
-    N, mods = 1 << 16, QI60[:L]
+@pytest.mark.parametrize("logN,L,B", [(16, 3, 2), (16, 16, 5), (16, 2, 1100), (15, 3, 3), (15, 2, 1100), (14, 5, 2), (14, 2, 1100)])
+def test_asm_column_stages_identical(rh, oracle, logN, L, B):
+    # N = 2^14..2^16: hand-scheduled column stages (standalone launch for small batches, fused launches for big ones) vs the C++ body
+    N, mods = 1 << logN, QI60[:L]
     ring = rh.Ring(N, mods)
     rng = np.random.default_rng(L * 31 + B)
     a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
@@ -291,10 +291,10 @@ def test_asm_column_stages_identical(rh, oracle, L, B):
     ring.close()
 
 
-@pytest.mark.parametrize("L,B", [(3, 2), (16, 5), (2, 300)])
-def test_asm_inverse_column_stages_identical(rh, oracle, L, B):
-    # N = 2^16: hand-scheduled inverse column stages with N^-1 folded in (standalone and fused launches) vs the C++ body
-    N, mods = 1 << 16, QI60[:L]
+@pytest.mark.parametrize("logN,L,B", [(16, 3, 2), (16, 16, 5), (16, 2, 1100), (15, 3, 3), (15, 2, 1100), (14, 5, 2), (14, 2, 1100)])
+def test_asm_inverse_column_stages_identical(rh, oracle, logN, L, B):
+    # N = 2^14..2^16: hand-scheduled inverse column stages with N^-1 folded in (standalone and fused launches) vs the C++ body
+    N, mods = 1 << logN, QI60[:L]
     ring = rh.Ring(N, mods)
     rng = np.random.default_rng(L * 17 + B)
     a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])

@@ -266,11 +266,11 @@ def gen_inverse():
     emit("s_waitcnt vmcnt(0)")
 
 
-def round16(tw_of_slot, stage_hook=None, pair_hook=None):
-    """4 stages over x[0..15]; tw_of_slot(slot) -> (vgpr_quad_index or None, sgpr tuple or None).
-    stage_hook(u) / pair_hook(u, i) emit waits just before the first consumer (guide G15: waits at the first consumer)"""
-    for u in range(4):
-        h = 8 >> u
+def round16(tw_of_slot, stage_hook=None, pair_hook=None, stages=4):
+    """`stages` stages over x[0 .. 2^stages - 1] (4 -> the radix-16 round); tw_of_slot(slot) -> (vgpr_quad_index or None,
+    sgpr tuple or None).  stage_hook(u) / pair_hook(u, i) emit waits just before the first consumer (guide G15)"""
+    for u in range(stages):
+        h = (1 << (stages - 1)) >> u
         if stage_hook:
             stage_hook(u)
         bfs = []
@@ -402,24 +402,24 @@ def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True):
 
 
 
-def gen_cols():
-    """Column stages for N = 2^16 (S1 = 4): x[k] = in[c + 4096 k], k < 16, one radix-16 round with the wave-uniform
-    twiddles tw[1..15] (natural order: stage s, group g -> tw[2^s + g] = slot 2^s - 1 + g), outputs < 8q stored back.
-    Same contract as fwd_cols_body<ShoupPolicy, 4> (ntt_kernels.cuh); operands: tid, pin, pout (row base + 256*cb
-    columns, bytes), tw (limb's natural-order table), nq0, nq1, nq4, q4."""
-    A0 = ADDR
+def gen_cols(S1=4):
+    """Column stages for N = 2^(12+S1), S1 = 2..4: x[k] = in[c + 4096 k], k < R = 2^S1, one radix-R register round with the
+    wave-uniform twiddles tw[1..R-1] (natural order: stage s, group g -> tw[2^s + g] = slot 2^s - 1 + g), outputs < 8q
+    stored back.  Same contract as fwd_cols_body<ShoupPolicy, S1> (ntt_kernels.cuh); operands: tid, pin, pout (row base +
+    256*cb columns, bytes), tw (limb's natural-order table), nq0, nq1, nq4, q4."""
+    R = 1 << S1
     if PRIO in (1, 2):
         emit("s_setprio 3")
     for t in (T0, T1):
         emit("v_mov_b32 v%d, 0" % (t.H + 1))
         emit("v_mov_b32 v%d, 0" % (t.G + 1))
-    for slot in range(15):
+    for slot in range(R - 1):
         emit("s_load_dwordx4 s[%d:%d], %%[tw], %d" % (36 + 4 * slot, 39 + 4 * slot, 16 * (slot + 1)))
     emit("v_lshlrev_b32 v%d, 3, %%[tid]" % TW0)                # byte offset of column c; element k adds 32768*k
-    for k in range(1, 16):
+    for k in range(1, R):
         emit("v_add_u32 v%d, %d, v%d" % (TW0 + k, 32768 * k, TW0))
-    for kk in range(16):
-        k = (kk >> 1) + 8 * (kk & 1)
+    for kk in range(R):
+        k = (kk >> 1) + (R >> 1) * (kk & 1)
         emit("global_load_dwordx2 %s, v%d, %%[pin]" % (pair(X(k)), TW0 + k))
     emit("s_waitcnt lgkmcnt(0)")
     if PRIO in (1, 2):
@@ -427,10 +427,10 @@ def gen_cols():
 
     def pair_hook(u, i):
         if u == 0:
-            emit("s_waitcnt vmcnt(%d)" % (16 - (2 * i + 4)))
+            emit("s_waitcnt vmcnt(%d)" % (R - (2 * i + 4)))
     round16(lambda slot: (None, ("s%d" % (36 + 4 * slot), "s%d" % (37 + 4 * slot), "s%d" % (38 + 4 * slot), "s%d" % (39 + 4 * slot))),
-            pair_hook=pair_hook)
-    for k in range(16):
+            pair_hook=pair_hook, stages=S1)
+    for k in range(R):
         emit("global_store_dwordx2 v%d, %s, %%[pout]" % (TW0 + k, pair(X(k))))
 
 
@@ -488,28 +488,29 @@ def scaled_last_butterfly_steps(u, v, t):
     return steps
 
 
-def gen_cols_inv():
-    """Inverse column stages for N = 2^16 (S1 = 4), scaled: stages with 8, 4, 2 blocks (twiddles tw[8..15], tw[4..7],
-    tw[2..3], wave-uniform), then the last stage with N^-1 folded into both multipliers; canonical outputs.  Same contract
-    as inv_cols_body<4>(scale = 1).  In place."""
+def gen_cols_inv(S1=4):
+    """Inverse column stages for N = 2^(12+S1), S1 = 2..4, scaled: the stages with 2^(S1-1) .. 2 blocks (wave-uniform
+    twiddles tw[2^u + g]), then the last stage with N^-1 folded into both multipliers; canonical outputs.  Same contract as
+    inv_cols_body<S1>(scale = 1).  In place."""
+    R = 1 << S1
     if PRIO in (1, 2):
         emit("s_setprio 3")
     for t in (T0, T1):
         emit("v_mov_b32 v%d, 0" % (t.H + 1))
         emit("v_mov_b32 v%d, 0" % (t.G + 1))
-    for slot in range(1, 15):
+    for slot in range(1, R - 1):
         emit("s_load_dwordx4 s[%d:%d], %%[tw], %d" % (36 + 4 * slot, 39 + 4 * slot, 16 * (slot + 1)))
     emit("v_lshlrev_b32 v%d, 3, %%[tid]" % TW0)
-    for k in range(1, 16):
+    for k in range(1, R):
         emit("v_add_u32 v%d, %d, v%d" % (TW0 + k, 32768 * k, TW0))
-    for k in range(16):
+    for k in range(R):
         emit("global_load_dwordx2 %s, v%d, %%[pin]" % (pair(X(k)), TW0 + k))
     emit("s_waitcnt lgkmcnt(0)")
     if PRIO in (1, 2):
         emit("s_setprio 0")
     emit("s_waitcnt vmcnt(0)")
-    for u in (3, 2, 1):
-        h = 8 >> u
+    for u in range(S1 - 1, 0, -1):
+        h = (R >> 1) >> u
         bfs = []
         for g in range(1 << u):
             slot = (1 << u) - 1 + g
@@ -522,12 +523,12 @@ def gen_cols_inv():
             b = inv_butterfly_steps(bfs[i + 1][0], bfs[i + 1][1], None, T1, bfs[i + 1][2])
             for ins in interleave(a, b):
                 emit(ins)
-    for e in range(0, 8, 2):
-        a = scaled_last_butterfly_steps(X(e), X(e + 8), T0)
-        b = scaled_last_butterfly_steps(X(e + 1), X(e + 9), T1)
+    for e in range(0, R >> 1, 2):
+        a = scaled_last_butterfly_steps(X(e), X(e + (R >> 1)), T0)
+        b = scaled_last_butterfly_steps(X(e + 1), X(e + 1 + (R >> 1)), T1)
         for ins in interleave(a, b):
             emit(ins)
-    for k in range(16):
+    for k in range(R):
         emit("global_store_dwordx2 v%d, %s, %%[pin]" % (TW0 + k, pair(X(k))))
 
 
@@ -545,18 +546,20 @@ del out[:]
 gen(preloaded=True, tail_wait=False)   # fused launch: the caller issued the data loads ahead of its column stages
 fwd_pre = list(out)
 del out[:]
-gen_cols()
-cols = list(out)
-del out[:]
-gen_cols_inv()
-cols_inv = list(out)
-del out[:]
+cols, cols_inv = {}, {}
+for s1 in (2, 3, 4):
+    gen_cols(s1)
+    cols[s1] = list(out)
+    del out[:]
+    gen_cols_inv(s1)
+    cols_inv[s1] = list(out)
+    del out[:]
 gen_inverse()
 inv = list(out)
 clob_v = ", ".join('"v%d"' % i for i in range(NVGPR_USED))
 clob_s = ", ".join('"s%d"' % i for i in range(36, 100))
 text = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  forward: %d instructions, inverse: %d.\n" % (len(fwd), len(inv))
-text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_SC1_ASM_BODY", fwd_sc1) + render("NTT_TILE_PRE_ASM_BODY", fwd_pre) + render("NTT_COLS16_ASM_BODY", cols) + render("NTT_COLS16_INV_ASM_BODY", cols_inv) + render("NTT_TILE_INV_ASM_BODY", inv)
+text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_SC1_ASM_BODY", fwd_sc1) + render("NTT_TILE_PRE_ASM_BODY", fwd_pre) + "".join(render("NTT_COLS%d_ASM_BODY" % (1 << k), cols[k]) + render("NTT_COLS%d_INV_ASM_BODY" % (1 << k), cols_inv[k]) for k in (2, 3, 4)) + render("NTT_TILE_INV_ASM_BODY", inv)
 text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v, clob_s)
 clob_v_pre = ", ".join('"v%d"' % i for i in range(32, NVGPR_USED))     # v0..v31 are read-write operands there
 text += "#define NTT_TILE_PRE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v_pre, clob_s)
