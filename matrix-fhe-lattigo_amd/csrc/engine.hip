@@ -595,6 +595,7 @@ extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
   if (!strcmp(key, "chunk_polys")) { r->chunk_polys = (int)value; return RH_OK; }
   if (!strcmp(key, "asm_tile")) { r->asm_tile = value != 0; return RH_OK; }
   if (!strcmp(key, "auto_span_rows")) { if (value < 1) return rh_fail(RH_ERR_ARG, "auto_span_rows must be >= 1"); r->auto_span_rows = (int)value; return RH_OK; }
+  if (!strcmp(key, "fuse3n")) { r->fuse3n = (int)value; return RH_OK; }
   if (!strcmp(key, "asm_cols")) { r->asm_cols = (int)value; return RH_OK; }
   if (!strcmp(key, "prefetch")) { r->prefetch = (int)value; return RH_OK; }
   if (!strcmp(key, "order_mix")) { r->order_mix = (int)value; return RH_OK; }

@@ -150,6 +150,47 @@ ntt3n_perm_inv(const u64* in, u64* out, int N, int nb, int log_n2, const int* __
   }
 }
 
+// the b = 1 butterflies on the six coefficients {i + k*N/6}: split + radix-3 layer (forward) and their inverses
+RH_DEV void pre_b1(u64 (&x)[6], const LimbConsts& c, const Limb3N& k, const tw2* __restrict__ t, u64 q4) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const u64 tt = shoup_mul(x[j + 3], k.zeta.w, k.zeta.wp, c.nq);
+    const u64 lo = add4(x[j], tt, q4), hi = sub4(add4(x[j], x[j + 3], q4), tt, q4);
+    x[j] = lo; x[j + 3] = hi;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const tw2 z1 = t[2 * h], z2 = t[2 * h + 1];
+    const u64 b0 = x[3 * h], b1 = x[3 * h + 1], b2 = x[3 * h + 2];
+    const u64 t1 = shoup_mul(b1, z1.w, z1.wp, c.nq), t2 = shoup_mul(b2, z2.w, z2.wp, c.nq);
+    const u64 t3 = shoup_mul(t1 + q4 - t2, k.w3.w, k.w3.wp, c.nq);
+    x[3 * h] = add4(add4(b0, t1, q4), t2, q4);
+    x[3 * h + 1] = add4(sub4(b0, t2, q4), t3, q4);
+    x[3 * h + 2] = sub4(sub4(b0, t1, q4), t3, q4);
+  }
+}
+RH_DEV void post_b1(u64 (&x)[6], const LimbConsts& c, const Limb3N& k, const tw2* __restrict__ t, u64 q4) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const tw2 z1 = t[2 * h], z2 = t[2 * h + 1];
+    const u64 B0 = x[3 * h], B1 = x[3 * h + 1], B2 = x[3 * h + 2];
+    const u64 tt = shoup_mul(B1 + q4 - B2, k.w3.w, k.w3.wp, c.nq);
+    const u64 s1 = sub4(sub4(B0, B1, q4), tt, q4), s2 = add4(sub4(B0, B2, q4), tt, q4);
+    x[3 * h] = add4(add4(B0, B1, q4), B2, q4);
+    x[3 * h + 1] = shoup_mul(s1, z1.w, z1.wp, c.nq);
+    x[3 * h + 2] = shoup_mul(s2, z2.w, z2.wp, c.nq);
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const u64 lo = x[j], hi = x[j + 3];
+    const u64 d = hi + q4 - lo;
+    const u64 b1 = shoup_mul(d, k.inv_b1.w, k.inv_b1.wp, c.nq);
+    const u64 zb1 = shoup_mul(d, k.inv_b0z.w, k.inv_b0z.wp, c.nq);
+    const u64 los = shoup_mul(lo, k.inv_s.w, k.inv_s.wp, c.nq);
+    x[j] = canon8(los + q4 - zb1, c.q); x[j + 3] = canon4(b1, c.q);
+  }
+}
+
 // ---- b = 1 fast path: split + the single radix-3 layer fused, 6 coefficients {i + k*N/6} per thread (one pass) -------
 __global__ void __launch_bounds__(256)
 ntt3n_pre_b1_fwd(const u64* in, u64* out, int N, const tw2* __restrict__ r3, int r3_stride,
@@ -164,22 +205,7 @@ ntt3n_pre_b1_fwd(const u64* in, u64* out, int N, const tw2* __restrict__ r3, int
     u64 x[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) x[j] = csub(in[base + i + (size_t)j * s], q4);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {                          // split: pairs (j, j+3) are N/2 apart
-      const u64 tt = shoup_mul(x[j + 3], k.zeta.w, k.zeta.wp, c.nq);
-      const u64 lo = add4(x[j], tt, q4), hi = sub4(add4(x[j], x[j + 3], q4), tt, q4);
-      x[j] = lo; x[j + 3] = hi;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {                          // radix-3 on each half
-      const tw2 z1 = t[2 * h], z2 = t[2 * h + 1];
-      const u64 b0 = x[3 * h], b1 = x[3 * h + 1], b2 = x[3 * h + 2];
-      const u64 t1 = shoup_mul(b1, z1.w, z1.wp, c.nq), t2 = shoup_mul(b2, z2.w, z2.wp, c.nq);
-      const u64 t3 = shoup_mul(t1 + q4 - t2, k.w3.w, k.w3.wp, c.nq);
-      x[3 * h] = add4(add4(b0, t1, q4), t2, q4);
-      x[3 * h + 1] = add4(sub4(b0, t2, q4), t3, q4);
-      x[3 * h + 2] = sub4(sub4(b0, t1, q4), t3, q4);
-    }
+    pre_b1(x, c, k, t, q4);
 #pragma unroll
     for (int j = 0; j < 6; ++j) out[base + i + (size_t)j * s] = x[j];
   }
@@ -197,27 +223,106 @@ ntt3n_post_b1_inv(const u64* in, u64* out, int N, const tw2* __restrict__ r3, in
     u64 x[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) x[j] = in[base + i + (size_t)j * s];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const tw2 z1 = t[2 * h], z2 = t[2 * h + 1];
-      const u64 B0 = x[3 * h], B1 = x[3 * h + 1], B2 = x[3 * h + 2];
-      const u64 tt = shoup_mul(B1 + q4 - B2, k.w3.w, k.w3.wp, c.nq);
-      const u64 s1 = sub4(sub4(B0, B1, q4), tt, q4), s2 = add4(sub4(B0, B2, q4), tt, q4);
-      x[3 * h] = add4(add4(B0, B1, q4), B2, q4);
-      x[3 * h + 1] = shoup_mul(s1, z1.w, z1.wp, c.nq);
-      x[3 * h + 2] = shoup_mul(s2, z2.w, z2.wp, c.nq);
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const u64 lo = x[j], hi = x[j + 3];
-      const u64 d = hi + q4 - lo;
-      const u64 b1 = shoup_mul(d, k.inv_b1.w, k.inv_b1.wp, c.nq);
-      const u64 zb1 = shoup_mul(d, k.inv_b0z.w, k.inv_b0z.wp, c.nq);
-      const u64 los = shoup_mul(lo, k.inv_s.w, k.inv_s.wp, c.nq);
-      x[j] = canon8(los + q4 - zb1, c.q); x[j + 3] = canon4(b1, c.q);
-    }
+    post_b1(x, c, k, t, q4);
 #pragma unroll
     for (int j = 0; j < 6; ++j) out[base + i + (size_t)j * s] = x[j];
+  }
+}
+
+// ---- b = 1, n2 >= 8192: the split + radix-3 layer fused with the COLUMN stages of the radix-2 sub-transforms (one pass
+// instead of two).  A thread owns R = 2^S1 local positions p_k = col + 4096 k of all six blocks: 6R coefficients in
+// registers.  After the pre-butterflies, block j's R values are exactly what ntt_fwd_cols would load for that block, so
+// the first S1 stages run in place on them with block j's twiddles (virtual limb limb*6 + j of the sub-ring) and the
+// sub-ring only runs its tile kernel afterwards.  Same arithmetic as ntt3n_pre_b1_fwd followed by fwd_cols_body.
+template <int S1>
+__global__ void __launch_bounds__(256)
+ntt3n_pre_cols_fwd(const u64* in, u64* out, int N, const tw2* __restrict__ r3, int r3_stride, const Limb3N* __restrict__ l3,
+                   const LimbConsts* __restrict__ consts, int L, const tw2* __restrict__ sub_tw, int log_n2) {
+  constexpr int R = 1 << S1;
+  const u32 limb = blockIdx.x % (u32)L, rr = blockIdx.x / (u32)L;
+  const u32 col = (rr & 15) * 256 + threadIdx.x;
+  const size_t base = ((size_t)(rr >> 4) * L + limb) * N;
+  const LimbConsts c = consts[limb]; const Limb3N k3 = l3[limb];
+  const tw2* t = r3 + (size_t)limb * r3_stride;
+  const u64 q4 = 4 * c.q;
+  const size_t s = (size_t)1 << log_n2;                    // = N / 6
+  u64 x[6][R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    u64 v[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v[j] = csub(in[base + col + ((size_t)k << 12) + j * s], q4);
+    pre_b1(v, c, k3, t, q4);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) x[j][k] = v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const tw2* tw = sub_tw + ((size_t)(limb * 6 + j) << log_n2);
+#pragma unroll
+    for (int st = 0; st < S1; ++st) {
+      const int h = R >> (st + 1);
+#pragma unroll
+      for (int g = 0; g < (1 << st); ++g) {
+        const tw2 w = tw[(1 << st) + g];
+#pragma unroll
+        for (int e = 0; e < h; ++e) {                      // ShoupPolicy::fwd (ntt_kernels.cuh)
+          u64& U = x[j][g * 2 * h + e]; u64& V = x[j][g * 2 * h + e + h];
+          const u64 u = csub(U, q4);
+          const u64 X = shoup_mul_acc(V, w.w, w.wp, c.nq, u);
+          V = ((u << 1) + q4) - X;
+          U = X;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) out[base + j * s + col + ((size_t)k << 12)] = x[j][k];
+  }
+}
+
+// inverse mirror: the sub-transforms' column stages (unscaled, values < 4q) fused with the radix-3 layer + split
+template <int S1>
+__global__ void __launch_bounds__(256)
+ntt3n_cols_post_inv(const u64* in, u64* out, int N, const tw2* __restrict__ r3, int r3_stride, const Limb3N* __restrict__ l3,
+                    const LimbConsts* __restrict__ consts, int L, const tw2* __restrict__ sub_tw, int log_n2) {
+  constexpr int R = 1 << S1;
+  const u32 limb = blockIdx.x % (u32)L, rr = blockIdx.x / (u32)L;
+  const u32 col = (rr & 15) * 256 + threadIdx.x;
+  const size_t base = ((size_t)(rr >> 4) * L + limb) * N;
+  const LimbConsts c = consts[limb]; const Limb3N k3 = l3[limb];
+  const tw2* t = r3 + (size_t)limb * r3_stride;
+  const u64 q4 = 4 * c.q;
+  const size_t s = (size_t)1 << log_n2;
+  u64 x[6][R];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) x[j][k] = in[base + j * s + col + ((size_t)k << 12)];
+    const tw2* tw = sub_tw + ((size_t)(limb * 6 + j) << log_n2);
+#pragma unroll
+    for (int st = S1 - 1; st >= 0; --st) {                 // inv_cols_body(scale = 0): stages with 2^st blocks, the last one plain
+      const int h = R >> (st + 1);
+#pragma unroll
+      for (int g = 0; g < (1 << st); ++g) {
+        const tw2 w = tw[(1 << st) + g];
+#pragma unroll
+        for (int e = 0; e < h; ++e) {                      // ShoupPolicy::inv
+          u64& U = x[j][g * 2 * h + e]; u64& V = x[j][g * 2 * h + e + h];
+          const u64 d = U + q4 - V;
+          U = csub(U + V, q4);
+          V = shoup_mul(d, w.w, w.wp, c.nq);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    u64 v[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v[j] = x[j][k];
+    post_b1(v, c, k3, t, q4);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) out[base + col + ((size_t)k << 12) + j * s] = v[j];
   }
 }
 
@@ -412,7 +517,16 @@ int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
   const size_t perm_lds = (size_t)32 * (32 * nb + 1) * 8;
   const dim3 pgrid(rows, 1u << (s->log_n2 >= 2 * PT ? s->log_n2 - 2 * PT : 0));
   if (!inverse) {
-    if (s->b == 1) {
+    const int S1sub = s->sub ? s->log_n2 - 12 : 0;
+    const bool fuse = s->b == 1 && s->sub && r->fuse3n && S1sub >= 1 && S1sub <= 3;    // 6 * 2^S1 coefficients per thread
+    if (fuse) {
+      const tw2* stw = s->sub->d_tw_fwd + ((size_t)limb0 * nb << s->log_n2);
+      const dim3 g(rows * 16);
+      if (S1sub == 1) ntt3n_pre_cols_fwd<1><<<g, 256, 0, st>>>(in, tmp, N, r3f + s->r3_off[1], s->r3_stride, l3, c, Lrows, stw, s->log_n2);
+      else if (S1sub == 2) ntt3n_pre_cols_fwd<2><<<g, 256, 0, st>>>(in, tmp, N, r3f + s->r3_off[1], s->r3_stride, l3, c, Lrows, stw, s->log_n2);
+      else ntt3n_pre_cols_fwd<3><<<g, 256, 0, st>>>(in, tmp, N, r3f + s->r3_off[1], s->r3_stride, l3, c, Lrows, stw, s->log_n2);
+      if (int rc = rh_std_ntt_launch(s->sub, tmp, tmp, npoly, Lrows * nb, limb0 * nb, false, false, 2)) return rc;   // tile stages only
+    } else if (s->b == 1) {
       ntt3n_pre_b1_fwd<<<dim3(rows, chunks(N / 6)), 256, 0, st>>>(in, tmp, N, r3f + s->r3_off[1], s->r3_stride, l3, c, Lrows);
     } else {
       ntt3n_split_fwd<<<dim3(rows, chunks(N / 2)), 256, 0, st>>>(in, tmp, N, l3, c, Lrows);
@@ -420,7 +534,7 @@ int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
       for (int l = 1; l <= s->b; ++l, cnt *= 3, step /= 3)
         ntt3n_radix3_fwd<<<dim3(rows, chunks(cnt * step)), 256, 0, st>>>(tmp, N, step, cnt, r3f + s->r3_off[l], s->r3_stride, l3, c, Lrows);
     }
-    if (s->sub) {
+    if (s->sub && !fuse) {
       // (poly, limb, block) rows of length n2: limb-major virtual limb index = limb*nb + c
       if (int rc = rh_std_ntt_launch(s->sub, tmp, tmp, npoly, Lrows * nb, limb0 * nb, false, false, 0)) return rc;
     }
@@ -429,10 +543,18 @@ int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
   } else {
     if (tiled) ntt3n_perm_tiled<false><<<pgrid, 256, perm_lds, st>>>(in, tmp, N, nb, s->log_n2, s->d_rank);
     else ntt3n_perm_inv<<<dim3(rows, chunks(N)), 256, 0, st>>>(in, tmp, N, nb, s->log_n2, s->d_block_of_rank);
+    const int S1sub = s->sub ? s->log_n2 - 12 : 0;
+    const bool fuse = s->b == 1 && s->sub && r->fuse3n && S1sub >= 1 && S1sub <= 3;
     if (s->sub) {
-      if (int rc = rh_std_ntt_launch(s->sub, tmp, tmp, npoly, Lrows * nb, limb0 * nb, true, false, 0)) return rc;
+      if (int rc = rh_std_ntt_launch(s->sub, tmp, tmp, npoly, Lrows * nb, limb0 * nb, true, false, fuse ? 2 : 0)) return rc;   // fused: tile stages only
     }
-    if (s->b == 1) {
+    if (fuse) {
+      const tw2* stw = s->sub->d_tw_inv + ((size_t)limb0 * nb << s->log_n2);
+      const dim3 g(rows * 16);
+      if (S1sub == 1) ntt3n_cols_post_inv<1><<<g, 256, 0, st>>>(tmp, out, N, r3i + s->r3_off[1], s->r3_stride, l3, c, Lrows, stw, s->log_n2);
+      else if (S1sub == 2) ntt3n_cols_post_inv<2><<<g, 256, 0, st>>>(tmp, out, N, r3i + s->r3_off[1], s->r3_stride, l3, c, Lrows, stw, s->log_n2);
+      else ntt3n_cols_post_inv<3><<<g, 256, 0, st>>>(tmp, out, N, r3i + s->r3_off[1], s->r3_stride, l3, c, Lrows, stw, s->log_n2);
+    } else if (s->b == 1) {
       ntt3n_post_b1_inv<<<dim3(rows, chunks(N / 6)), 256, 0, st>>>(tmp, out, N, r3i + s->r3_off[1], s->r3_stride, l3, c, Lrows);
     } else {
       int cnt = nb / 3, step = s->n2;

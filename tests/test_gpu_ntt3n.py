@@ -117,3 +117,30 @@ def test_3n_errors(rh):
         rh.Ring(24, [0x1fffffffffe00001 - 0], kind=rh.Matrix3N) if (0x1fffffffffe00001 - 1) % 72 else (_ for _ in ()).throw(rh.RingHipError("skip"))
     with pytest.raises(rh.RingHipError):
         rh.Ring(20, [65537], kind=rh.Matrix3N)   # N not of the form 2^a 3^b
+
+
+@pytest.mark.parametrize("logn2", [13, 14, 15])
+def test_fused_pre_and_column_stages_identical(rh, oracle, logn2):
+    # b = 1 rings with n2 = 2^13..2^15: split + radix-3 layer fused with the sub-transforms' column stages (default) vs the
+    # separate passes; forward and inverse, batch of 3 with 2 limbs, one limb against the oracle
+    N = 6 << logn2
+    mods = []
+    q = find_prime_3n(N, 60)
+    while len(mods) < 2:
+        if oracle.lib().orc_is_prime(q):
+            mods.append(q)
+        q += 3 * N
+    ring = rh.Ring(N, mods, kind=rh.Matrix3N, omega3n=[omega_for(m, N) for m in mods])
+    rng = np.random.default_rng(logn2)
+    a = np.stack([np.stack([rng.integers(0, 1 << 62, size=N, dtype=np.uint64) % np.uint64(m) for m in mods]) for _ in range(3)])
+    p = rh.DevicePoly.from_numpy(ring, a)
+    f0, f1, b0, b1 = (ring.NewPoly(3) for _ in range(4))
+    ring.set_tuning("fuse3n", 0); ring.NTT(p, f0); ring.INTT(f0, b0)
+    ring.set_tuning("fuse3n", 1); ring.NTT(p, f1); ring.INTT(f1, b1)
+    assert np.array_equal(f1.numpy(), f0.numpy())
+    assert np.array_equal(b1.numpy(), a) and np.array_equal(b0.numpy(), a)
+    if logn2 == 13:
+        assert np.array_equal(f1.numpy()[2, 1], oracle.ntt3n_forward(a[2, 1], mods[1], omega_for(mods[1], N)))
+    ring.NTT(p, p); ring.INTT(p, p)                     # in place
+    assert np.array_equal(p.numpy(), a)
+    ring.close()
