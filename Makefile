@@ -14,7 +14,7 @@ $(CSRC)/ntt_tile_asm.inc: tools/gen_tile_asm.py
 
 $(LIB): $(SRCS) $(HDRS) $(CSRC)/ntt_tile_asm.inc
 	@mkdir -p $(PKG)/lib
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Iinclude $(SRCS) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -mllvm -pragma-unroll-threshold=131072 -fPIC -shared -Iinclude $(SRCS) -o $@
 
 tests/cpp/test_ring_cpp: tests/cpp/test_ring_cpp.cpp include/ringhip.hpp include/ringhip.h $(LIB)
 	g++ -O2 -std=c++17 -Iinclude $< -L$(PKG)/lib -lringhip -Wl,-rpath,'$$ORIGIN/../../$(PKG)/lib' -o $@
