@@ -347,10 +347,12 @@ extern "C" int rh_bext_moddown_qp_to_q_ntt(rh_bext* be, int levelQ, int levelP, 
   if (int rc = launch_plan(be, *p, buffP, levelP + 1, 0, buffQ, levelQ + 1, nullptr, 0, nullptr, 0, npoly, BEXT_ADD_CRED)) return rc;
   // ringQ.NTTLazy(buffQ, buffQ): the following MRed yields the canonical residue for any representative (< 8q) of the
   // NTT values, so the canonical forward transform is used.
-  if (int rc = rh_std_ntt_launch(be->Q, buffQ, buffQ, npoly, levelQ + 1, 0, false, false, 0)) return rc;
   std::vector<u64> sc(levelQ + 1);
   std::vector<u64> Ps(be->P->moduli.begin(), be->P->moduli.begin() + levelP + 1);
   for (int i = 0; i <= levelQ; ++i) sc[i] = be->Q->moduli[i] - moddown_const(Ps, be->Q->moduli[i]);
+  if (rh_can_fuse_submul(be->Q))                 // the subtract-multiply rides in the forward tile kernel's epilogue
+    return rh_std_ntt_submul_launch(be->Q, buffQ, npoly, levelQ + 1, 0, p1Q, levelQ + 1, p2Q, levelQ + 1, sc.data());
+  if (int rc = rh_std_ntt_launch(be->Q, buffQ, buffQ, npoly, levelQ + 1, 0, false, false, 0)) return rc;
   return rh_vec_launch(be->Q, RH_OP_SUB_THEN_MUL_SCALAR_MONT_TWO_MODULUS, buffQ, p1Q, p2Q, npoly, levelQ + 1, 0, sc.data(), nullptr);
 }
 

@@ -518,6 +518,25 @@ int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows,
   return std_ntt_launch_span(r, in, out, npoly, Lrows, limb0, inverse, lazy, phase);
 }
 
+bool rh_can_fuse_submul(const rh_ring* r) { return r->kind == RH_RING_STANDARD && r->logN >= LT && r->fuse_submul; }
+// Forward canonical transform of `buf` (in place up to its tile stages) fused with out = MRed(2q - y + NTT(buf), s_limb):
+// column stages as usual, then ntt_fwd_tile_submul.  y / out: (poly, limb) blocks with y_rows / out_rows limbs per poly.
+int rh_std_ntt_submul_launch(rh_ring* r, u64* buf, int npoly, int Lrows, int limb0, const u64* y, int y_rows, u64* out, int out_rows,
+                             const u64* scalars_host) {
+  static_assert(RH_MAX_LIMBS_K == RH_MAX_LIMBS, "limb bound mismatch");
+  if (!rh_can_fuse_submul(r)) return rh_fail(RH_ERR_UNSUPPORTED, "fused subtract-multiply needs a standard ring with N >= 4096");
+  const unsigned rows = (unsigned)npoly * (unsigned)Lrows;
+  if (rows == 0) return RH_OK;
+  const int S1 = r->logN - LT;
+  if (S1 > 0) if (int rc = rh_std_ntt_launch(r, buf, buf, npoly, Lrows, limb0, false, false, 1)) return rc;   // column stages only
+  (void)hipGetLastError();
+  LimbScalars sc; memset(&sc, 0, sizeof(sc)); memcpy(sc.s, scalars_host, (size_t)Lrows * 8);
+  const size_t toff = (size_t)limb0 * r->N;
+  ntt_fwd_tile_submul<<<rows << S1, 256, 0, r->stream>>>(buf, r->d_twk_fwd + toff, r->d_consts + limb0, Lrows, r->logN, npoly, y, y_rows,
+                                                         out, out_rows, sc);
+  return check_launch("ntt_fwd_tile_submul");
+}
+
 // ---- conjugate-invariant ring Z[X+X^-1]/(X^2N+1) (ring/ntt.go:716-1311): the negacyclic kernels on the re-indexed
 // 4N-th-root table, plus the fold with F = roots[1] before (forward :761-768) / after (inverse :1149-1156) them.
 __global__ void __launch_bounds__(256)
@@ -595,6 +614,7 @@ extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
   if (!strcmp(key, "chunk_polys")) { r->chunk_polys = (int)value; return RH_OK; }
   if (!strcmp(key, "asm_tile")) { r->asm_tile = value != 0; return RH_OK; }
   if (!strcmp(key, "auto_span_rows")) { if (value < 1) return rh_fail(RH_ERR_ARG, "auto_span_rows must be >= 1"); r->auto_span_rows = (int)value; return RH_OK; }
+  if (!strcmp(key, "fuse_submul")) { r->fuse_submul = (int)value; return RH_OK; }
   if (!strcmp(key, "fuse3n")) { r->fuse3n = (int)value; return RH_OK; }
   if (!strcmp(key, "asm_cols")) { r->asm_cols = (int)value; return RH_OK; }
   if (!strcmp(key, "prefetch")) { r->prefetch = (int)value; return RH_OK; }

@@ -43,6 +43,7 @@ struct rh_ring {
   int persist_grid = 0;           // resident workgroups (0 = query)
   unsigned* d_rowcnt = nullptr; size_t rowcnt_words = 0, err_index = 0;
   int cols2 = 0;                  // column kernel: two adjacent columns per thread (16 B per lane)
+  int fuse_submul = 1;            // ModDown / rescale: subtract-multiply fused into the forward tile kernel's epilogue
   int fuse3n = 1;                 // 3N rings, b = 1: split + radix-3 layer fused with the sub-transforms' column stages
   int asm_cols = 1;               // N = 2^16: hand-scheduled column stages (fwd_cols16_asm_body) in place of the C++ body
   int prefetch = 0;               // fused forward launch: issue the tile loads ahead of the column stages (ntt_fwd_fused_pre); measured: no gain
@@ -54,6 +55,9 @@ struct rh_ring {
 };
 
 int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase = 0);
+bool rh_can_fuse_submul(const rh_ring* r);
+int rh_std_ntt_submul_launch(rh_ring* r, u64* buf, int npoly, int Lrows, int limb0, const u64* y, int y_rows, u64* out, int out_rows,
+                             const u64* scalars_host);
 int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3, int npoly, int Lrows, int limb0,
                   const u64* s0, const u64* s1);
 int rh_std_upload_tables(rh_ring* r, const std::vector<tw2>& fs, const std::vector<tw2>& is, const std::vector<u64>* mont,

@@ -202,6 +202,7 @@ extern "C" int rh_kshard_moddown(rh_kshard* ks, const uint64_t* srcP, const uint
   u64* buffQ;
   if (int rc = ks_buf(ks, 2, (size_t)npoly * nQ * N, &buffQ)) return rc;
   if (int rc = rh_bext_launch_raw(RQ->stream, N, ks->md_plan, srcP, LP, 0, buffQ, nQ, nullptr, 0, nullptr, 0, npoly, BEXT_ADD_CRED)) return rc;
+  if (rh_can_fuse_submul(RQ)) return rh_std_ntt_submul_launch(RQ, buffQ, npoly, nQ, 0, ctQ_in, nQ, ctQ_out, nQ, ks->md_scalars.data());
   if (int rc = rh_std_ntt_launch(RQ, buffQ, buffQ, npoly, nQ, 0, false, false, 0)) return rc;
   return rh_vec_launch(RQ, RH_OP_SUB_THEN_MUL_SCALAR_MONT_TWO_MODULUS, buffQ, ctQ_in, ctQ_out, npoly, nQ, 0, ks->md_scalars.data(), nullptr);
 }

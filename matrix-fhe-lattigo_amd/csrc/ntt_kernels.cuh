@@ -165,6 +165,56 @@ ntt_fwd_tile(const u64* in, u64* out, const typename P::tw_t* __restrict__ twk,
   fwd_tile_body<P>(lds, blockIdx.x, in, out, twk, consts, L, logN, canonical, npoly);
 }
 
+// Forward tile stages with a fused epilogue: out = MRed(2q - y + NTT(in), s_limb) -- the subtract-multiply that follows a
+// forward transform in ModDownQPtoQNTT (ring/basis_extension.go:255-257, SubThenMulScalarMontgomeryTwoModulus) and in
+// DivRoundByLastModulusNTT (ring/scaling.go:120-124).  The canonical NTT values never go to memory: the element-wise
+// pass (24 B per coefficient) disappears.  y and out are (poly, limb) blocks with their own row counts.
+struct LimbScalars { u64 s[RH_MAX_LIMBS_K]; };
+__global__ void __launch_bounds__(256)
+ntt_fwd_tile_submul(const u64* in, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts, int L, int logN, int npoly,
+                    const u64* y, int y_rows, u64* out, int out_rows, LimbScalars sc) {
+  __shared__ u64 lds[LDS_WORDS];
+  const int tid = threadIdx.x;
+  const u32 b = blockIdx.x;
+  const u32 limb = b % (u32)L;
+  const u32 r = b / (u32)L;
+  const int S1 = logN - LT;
+  const u32 poly = r % (u32)npoly;
+  const u32 tile = r / (u32)npoly;
+  const size_t base = (((size_t)poly * L + limb) << logN) + ((size_t)tile << LT);
+  const tw2* tw = twk + ((size_t)limb << logN) + ((size_t)tile << LT);
+  const LimbConsts c = consts[limb];
+  ShoupPolicy p; p.init(c);
+  u64 x[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = in[base + tid + 256 * k];
+  round16_fwd(p, x, [&](int slot) { return tw[slot]; }, S1, logN);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[LDS_PAD(tid + 256 * k)] = x[k];
+  __syncthreads();
+  const int hi4 = tid >> 4, lo4 = tid & 15;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = lds[LDS_PAD((hi4 << 8) | (k << 4) | lo4)];
+  round16_fwd(p, x, [&](int slot) { return tw[16 + slot * 16 + hi4]; }, S1 + 4, logN);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[LDS_PAD((hi4 << 8) | (k << 4) | lo4)] = x[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = lds[LDS_PAD(tid * 16 + k)];
+  round16_fwd(p, x, [&](int slot) { return tw[256 + slot * 256 + tid]; }, S1 + 8, logN);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[LDS_PAD(tid * 16 + k)] = p.fwd_final(x[k], true);
+  __syncthreads();
+  const size_t yb = (((size_t)poly * y_rows + limb) << logN) + ((size_t)tile << LT);
+  const size_t ob = (((size_t)poly * out_rows + limb) << logN) + ((size_t)tile << LT);
+  const u64 sl = sc.s[limb], q2 = 2 * c.q;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const u64 v = lds[LDS_PAD(tid + 256 * k)];
+    out[ob + tid + 256 * k] = mred(q2 - y[yb + tid + 256 * k] + v, sl, c.q, c.qinv);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // K2 inverse: first 12 stages (t = 1..2048) on a 4096-tile.  If `last` (logN == 12) the N^-1 scaling and the
 // canonical reduction happen here, else values leave < 4q for K1 inverse.

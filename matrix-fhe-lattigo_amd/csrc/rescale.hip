@@ -161,6 +161,11 @@ extern "C" int rh_ring_div_by_last_modulus_many_ntt(rh_ring* r, int round, int l
     gather_limb_kernel<<<grid, 256, 0, r->stream>>>(p0, level + 1, level, tmp, N);
     if (int rc = rh_std_ntt_launch(r, tmp, tmp, npoly, 1, level, true, true, 0)) return rc;
     rescale_expand_kernel<<<grid, 256, 0, r->stream>>>(round ? 1 : 0, tmp, buff, level, level, N, r->moduli[level], T);
+    if (level > 0 && rh_can_fuse_submul(r)) {          // p1 = MRed(2q - p0 + NTT(buff), c_i) in the tile kernel's epilogue (:120-124)
+      std::vector<u64> sc(level);
+      for (int i = 0; i < level; ++i) sc[i] = rh::mform(r->moduli[i] - rh::invmod_prime(r->moduli[level] % r->moduli[i], r->moduli[i]), r->moduli[i]);
+      return rh_std_ntt_submul_launch(r, buff, npoly, level, 0, p0, level + 1, p1, p1_rows, sc.data());
+    }
     if (level > 0) if (int rc = rh_std_ntt_launch(r, buff, buff, npoly, level, 0, false, false, 0)) return rc;
     rescale_finish_kernel<<<grid, 256, 0, r->stream>>>(buff, level, p0, level + 1, p1, p1_rows, level, N, T);
     return launched("rescale (NTT domain)");

@@ -2,6 +2,7 @@
 #pragma once
 #include "modarith.cuh"
 
+#define RH_MAX_LIMBS_K 64        // = RH_MAX_LIMBS (engine_internal.hpp): per-limb scalars passed to kernels by value
 struct LimbConsts {
   u64 q, qinv, bred0, bred1;   // Modulus, MRedConstant, BRedConstant[0], [1]
   u64 nq;                      // 2^64 - q
