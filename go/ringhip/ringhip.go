@@ -163,3 +163,72 @@ func (d *DeviceRing) must(rc C.int) {
 		panic(fmt.Sprintf("ringhip: %s", C.GoString(C.rh_last_error())))
 	}
 }
+
+// ---- element-wise ops by opcode (one RH_OP_* per ring/vec_ops.go function) and the callers built on the ring ----------
+
+// VecOp runs any of the 38 element-wise kernels; s0/s1 are per-limb scalars (nil when the op takes none).
+func (d *DeviceRing) VecOp(op C.int, p1, p2, p3 *DevPoly, s0, s1 []uint64) {
+	var a, b, x, y *C.uint64_t
+	if p1 != nil {
+		a = p1.ptr
+	}
+	if p2 != nil {
+		b = p2.ptr
+	}
+	if len(s0) > 0 {
+		x = (*C.uint64_t)(unsafe.Pointer(&s0[0]))
+	}
+	if len(s1) > 0 {
+		y = (*C.uint64_t)(unsafe.Pointer(&s1[0]))
+	}
+	d.must(C.rh_ring_vec_op(d.h, op, a, b, p3.ptr, C.int(p3.npoly), C.int(p3.limbs-1), x, y))
+}
+
+// DivRoundByLastModulusManyNTT mirrors ring.Ring.DivRoundByLastModulusManyNTT (ring/scaling.go:130-156).
+func (d *DeviceRing) DivRoundByLastModulusManyNTT(nbRescales int, p0, p1 *DevPoly) {
+	d.must(C.rh_ring_div_by_last_modulus_many_ntt(d.h, 1 /* round */, C.int(p0.limbs-1), C.int(nbRescales), p0.ptr, p1.ptr, C.int(p1.limbs), C.int(p0.npoly)))
+}
+
+// AutomorphismNTT mirrors ring.Ring.AutomorphismNTT (ring/automorphism.go:52-73).
+func (d *DeviceRing) AutomorphismNTT(in *DevPoly, galEl uint64, out *DevPoly) {
+	d.must(C.rh_ring_automorphism_ntt(d.h, C.int(in.limbs-1), in.ptr, C.uint64_t(galEl), out.ptr, C.int(in.npoly), 0))
+}
+
+// KeySwitcher pairs the Q and P device rings (ring.BasisExtender + the gadget product of rlwe.Evaluator).
+type KeySwitcher struct {
+	be   *C.rh_bext
+	q, p *DeviceRing
+}
+
+func NewKeySwitcher(q, p *DeviceRing) (*KeySwitcher, error) {
+	k := &KeySwitcher{q: q, p: p}
+	if rc := C.rh_bext_create(&k.be, q.h, p.h); rc != 0 {
+		return nil, fmt.Errorf("ringhip: %s", C.GoString(C.rh_last_error()))
+	}
+	return k, nil
+}
+
+// GadgetProduct mirrors rlwe.Evaluator.GadgetProduct for NTT-domain cx and levelP >= 1
+// (core/rlwe/evaluator_gadget_product.go:16-30).  evkQ / evkP hold GadgetCiphertext.Value[i][0][c].Q / .P as
+// blocks of beta*2 polys ([digit][component][limb][N]).
+func (k *KeySwitcher) GadgetProduct(levelQ, levelP int, cx, evkQ, evkP *DevPoly, beta int, ct0, ct1 *DevPoly) {
+	k.q.must(C.rh_bext_gadget_product(k.be, C.int(levelQ), C.int(levelP), cx.ptr, evkQ.ptr, evkP.ptr, C.int(beta), ct0.ptr, ct1.ptr, C.int(cx.npoly)))
+}
+
+// DecomposeNTT / GadgetProductHoisted mirror the hoisted pair (:431-453, :326-349): one decomposition, many rotations.
+func (k *KeySwitcher) DecomposeNTT(levelQ, levelP int, c2 *DevPoly, c2IsNTT bool, decompQ, decompP *DevPoly) {
+	isNTT := C.int(0)
+	if c2IsNTT {
+		isNTT = 1
+	}
+	k.q.must(C.rh_bext_decompose_ntt(k.be, C.int(levelQ), C.int(levelP), c2.ptr, isNTT, decompQ.ptr, decompP.ptr, C.int(c2.npoly)))
+}
+func (k *KeySwitcher) GadgetProductHoisted(levelQ, levelP int, decompQ, decompP, evkQ, evkP *DevPoly, beta int, ct0, ct1 *DevPoly) {
+	k.q.must(C.rh_bext_gadget_product_hoisted(k.be, C.int(levelQ), C.int(levelP), decompQ.ptr, decompP.ptr, evkQ.ptr, evkP.ptr, C.int(beta),
+		ct0.ptr, ct1.ptr, C.int(ct0.npoly)))
+}
+
+// ModDownQPtoQNTT mirrors ring.BasisExtender.ModDownQPtoQNTT (ring/basis_extension.go:241-258).
+func (k *KeySwitcher) ModDownQPtoQNTT(levelQ, levelP int, p1Q, p1P, p2Q *DevPoly) {
+	k.q.must(C.rh_bext_moddown_qp_to_q_ntt(k.be, C.int(levelQ), C.int(levelP), p1Q.ptr, p1P.ptr, p2Q.ptr, C.int(p1Q.npoly)))
+}
