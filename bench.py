@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--cluster-wgs", type=int, default=-1)
     ap.add_argument("--unsafe", type=int, default=0)
     ap.add_argument("--order-mix", type=int, default=-1)
+    ap.add_argument("--lds-pad", type=int, default=0, help="experiment: extra dynamic LDS bytes per workgroup of the fused launch (occupancy sensitivity)")
     ap.add_argument("--asm-cols", type=int, default=-1, help="hand-scheduled column stages at N=2^16 (default on)")
     ap.add_argument("--prefetch", type=int, default=-1, help="fused launch with tile loads ahead of the column stages (default off: measured no gain)")
     ap.add_argument("--cols2", type=int, default=-1)
@@ -86,6 +87,8 @@ def main():
         ring.set_tuning("persistent", args.persistent)
     if args.cols2 >= 0:
         ring.set_tuning("cols2", args.cols2)
+    if args.lds_pad > 0:
+        ring.set_tuning("dbg_lds_pad", args.lds_pad)
     if args.asm_cols >= 0:
         ring.set_tuning("asm_cols", args.asm_cols)
     if args.prefetch >= 0:

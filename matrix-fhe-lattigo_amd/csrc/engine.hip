@@ -366,7 +366,7 @@ static void launch_fused(rh_ring* r, const u64* in1, u64* out1, unsigned n1, u64
   if (r->asm_tile && r->prefetch)
     ntt_fwd_fused_pre<S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN);
   else if (r->asm_tile && S1 >= 2 && S1 <= 4 && r->asm_cols)
-    ntt_fwd_fused_asm<S1, true><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN, r->order_mix);
+    ntt_fwd_fused_asm<S1, true><<<grid, 256, (size_t)r->dbg_lds_pad, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN, r->order_mix);
   else if (r->asm_tile)
     ntt_fwd_fused_asm<S1, false><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN, r->order_mix);
   else
@@ -614,6 +614,7 @@ extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
   if (!strcmp(key, "chunk_polys")) { r->chunk_polys = (int)value; return RH_OK; }
   if (!strcmp(key, "asm_tile")) { r->asm_tile = value != 0; return RH_OK; }
   if (!strcmp(key, "auto_span_rows")) { if (value < 1) return rh_fail(RH_ERR_ARG, "auto_span_rows must be >= 1"); r->auto_span_rows = (int)value; return RH_OK; }
+  if (!strcmp(key, "dbg_lds_pad")) { r->dbg_lds_pad = (int)value; return RH_OK; }    // occupancy experiments: extra dynamic LDS per workgroup
   if (!strcmp(key, "fuse_submul")) { r->fuse_submul = (int)value; return RH_OK; }
   if (!strcmp(key, "fuse3n")) { r->fuse3n = (int)value; return RH_OK; }
   if (!strcmp(key, "asm_cols")) { r->asm_cols = (int)value; return RH_OK; }
