@@ -593,21 +593,6 @@ extern "C" int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in, uint64_t* out, 
   if (phase < 0 || phase > 2) return rh_fail(RH_ERR_ARG, "phase must be 0, 1 or 2");
   return ntt_batch(r, in, out, npoly, level, inverse != 0, false, phase);
 }
-// debugging aid (not part of the documented ABI surface): dry run of the single-pass ticket schedule
-extern "C" int rh_debug_cluster_dryrun(rh_ring* r, int npoly, int Lrows, unsigned* out_host, unsigned cap) {
-  if (!r || !out_host) return rh_fail(RH_ERR_ARG, "null");
-  (void)hipSetDevice(r->device);
-  unsigned *d_head = nullptr, *d_dbg = nullptr;
-  const size_t words = 8 + 8 * (size_t)cap;
-  if (hipMalloc((void**)&d_head, 64) != hipSuccess || hipMalloc((void**)&d_dbg, words * 4) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc");
-  (void)hipMemset(d_head, 0, 64); (void)hipMemset(d_dbg, 0, words * 4);
-  ntt_cluster_dryrun<<<1024, 256, 0, r->stream>>>((unsigned)npoly * Lrows, Lrows, d_head, d_dbg, cap);
-  hipError_t e = hipStreamSynchronize(r->stream);
-  if (e == hipSuccess) e = hipMemcpy(out_host, d_dbg, words * 4, hipMemcpyDeviceToHost);
-  (void)hipFree(d_head); (void)hipFree(d_dbg);
-  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "dryrun: %s", hipGetErrorString(e));
-  return RH_OK;
-}
 
 extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
   if (!r || !key) return rh_fail(RH_ERR_ARG, "set_tuning: null argument");

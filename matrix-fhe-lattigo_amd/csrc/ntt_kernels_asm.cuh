@@ -372,30 +372,3 @@ ntt_fwd_cluster(const u64* in, u64* out, unsigned nrows, const tw2* __restrict__
   }
 }
 
-// debugging aid for ntt_fwd_cluster: walks the same ticket schedule but touches no data; records per-ticket facts
-// (xcc, ticket, row, unit, poly, limb) into dbg so that the addressing can be audited on the host.
-__global__ void __launch_bounds__(256)
-ntt_cluster_dryrun(unsigned nrows, int L, unsigned* head, unsigned* dbg, unsigned dbg_cap) {
-  __shared__ unsigned s_ticket;
-  unsigned xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  const unsigned raw = xcc;
-  xcc &= 7u;
-  const unsigned nx = nrows > xcc ? (nrows - xcc + 7) / 8 : 0;
-  const unsigned ntick = nx * 16;
-  for (int guard = 0; guard < 100000; ++guard) {
-    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&head[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const unsigned t = s_ticket;
-    __syncthreads();
-    if (t >= ntick) break;
-    const unsigned row = xcc + 8 * (t >> 4), unit = t & 15;
-    if (threadIdx.x == 0) {
-      const unsigned slot = __hip_atomic_fetch_add(&dbg[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (slot < dbg_cap) {
-        unsigned* d = dbg + 8 + 8 * slot;
-        d[0] = raw; d[1] = t; d[2] = row; d[3] = unit; d[4] = row / (unsigned)L; d[5] = row % (unsigned)L; d[6] = blockIdx.x; d[7] = ntick;
-      }
-    }
-  }
-}
