@@ -5,6 +5,7 @@ the HIP library; no key generation, no encoders (those stay with the reference).
   GadgetProduct          core/rlwe/evaluator_gadget_product.go:16-30
   DecomposeNTT           :431-453        GadgetProductHoisted   :326-349
   Automorphism           core/rlwe/evaluator_automorphism.go:14-60      AutomorphismHoisted  :62-105
+  ApplyEvaluationKey     core/rlwe/evaluator_evaluationkey.go:37-123 (same ring degree)   Relinearize  :125-153
 
 Restrictions (the reference's other branches are not built): ciphertexts in the NTT domain, levelP >= 1
 (gadgetProductMultiplePLazy; the single-P / bit-decomposition branch :190-324 is out of scope), BaseTwoDecomposition 0."""
@@ -72,6 +73,40 @@ class Evaluator:
         npoly = ct.Value[0].npoly
         _check(lib().rh_bext_gadget_product_hoisted(self.be._h, levelQ, gadgetCt.LevelP(), dq.ptr, dp.ptr, gadgetCt.Q.ptr,
                                                     gadgetCt.P.ptr, gadgetCt.digits, ct.Value[0].ptr, ct.Value[1].ptr, npoly))
+
+    # ---- core/rlwe/evaluator_evaluationkey.go ---------------------------------------------------------------
+    def ApplyEvaluationKey(self, ctIn, evk, opOut):
+        """(:37-123), same ring degree on both sides (:97-99 -> applyEvaluationKey :105-112):
+        opOut = (ctIn[0] + KS(ctIn[1])_0, KS(ctIn[1])_1).  The ring-degree switching branches are not built."""
+        if ctIn.Degree() != 1 or opOut.Degree() != 1:
+            raise RingHipError("cannot ApplyEvaluationKey: input and output Ciphertext must be of degree 1")
+        if not ctIn.IsNTT:
+            raise RingHipError("ApplyEvaluationKey: coefficient-domain ciphertexts are not supported by the device path")
+        level = min(ctIn.Level(), opOut.Level())
+        ringQ = self.ringQ.AtLevel(level)
+        npoly = ctIn.Value[1].npoly
+        tmp = Ciphertext([DevicePoly(ringQ, npoly, level + 1), opOut.Value[1]], is_ntt=True)   # component 1 lands in opOut directly
+        self.GadgetProduct(level, ctIn.Value[1], evk, tmp)
+        ringQ.Add(ctIn.Value[0], tmp.Value[0], opOut.Value[0])
+        opOut.IsNTT = True
+
+    def Relinearize(self, ctIn, opOut, rlk=None):
+        """(:125-153): degree 2 -> degree 1 with the relinearisation key (galois_keys["rlk"] or the argument)"""
+        if ctIn.Degree() != 2:
+            raise RingHipError("cannot relinearize: ctIn.Degree() should be 2 but is %d" % ctIn.Degree())
+        rlk = rlk or self.galois_keys.get("rlk")
+        if rlk is None:
+            raise RingHipError("cannot relinearize: relinearization key is missing")
+        if not ctIn.IsNTT:
+            raise RingHipError("Relinearize: coefficient-domain ciphertexts are not supported by the device path")
+        level = min(ctIn.Level(), opOut.Level())
+        ringQ = self.ringQ.AtLevel(level)
+        npoly = ctIn.Value[2].npoly
+        tmp = Ciphertext([DevicePoly(ringQ, npoly, level + 1), DevicePoly(ringQ, npoly, level + 1)], is_ntt=True)
+        self.GadgetProduct(level, ctIn.Value[2], rlk, tmp)
+        ringQ.Add(ctIn.Value[0], tmp.Value[0], opOut.Value[0])
+        ringQ.Add(ctIn.Value[1], tmp.Value[1], opOut.Value[1])
+        opOut.IsNTT = True
 
     # ---- core/rlwe/evaluator_automorphism.go -----------------------------------------------------------------
     def _galois_key(self, galEl):

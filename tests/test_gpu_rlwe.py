@@ -88,3 +88,33 @@ def test_automorphism_keyswitch_vs_oracle(rh, oracle, N, nq, np_, gal):
     with pytest.raises(rh.RingHipError):
         ev.Automorphism(rh.Ciphertext([ct.Value[0]], is_ntt=True), gal, out3)
     ev.close(); rq.close(); rp.close()
+
+
+def test_relinearize_and_apply_evaluation_key(rh, oracle):
+    # Relinearize (evaluator_evaluationkey.go:125-153) and ApplyEvaluationKey, same ring degree (:97-112)
+    N, nq, np_ = 4096, 5, 2
+    Q, P, rq, rp, beta, evkQ, evkP, c0, c1 = make_case(rh, N, nq, np_, 2, 77)
+    rng = np.random.default_rng(5)
+    c2 = np.stack([np.stack([uniform_mod(rng, q, N) for q in Q]) for _ in range(2)])
+    gct = rh.rlwe.GadgetCiphertext(rq, rp, evkQ, evkP)
+    ev = rh.rlwe.Evaluator(rq, rp, galois_keys={"rlk": gct})
+    dp = lambda a: rh.DevicePoly.from_numpy(rq, a)
+    ct2 = rh.Ciphertext([dp(c0), dp(c1), dp(c2)], is_ntt=True)
+    out = rh.Ciphertext([rq.NewPoly(2), rq.NewPoly(2)], is_ntt=True)
+    ev.Relinearize(ct2, out)
+    ct1 = rh.Ciphertext([dp(c0), dp(c2)], is_ntt=True)
+    out2 = rh.Ciphertext([rq.NewPoly(2), rq.NewPoly(2)], is_ntt=True)
+    ev.ApplyEvaluationKey(ct1, gct, out2)
+    OPS = rh.OPS
+    for k in range(2):
+        e0, e1 = oracle_gadget_product(oracle, rh, N, Q, P, nq - 1, np_ - 1, c2[k], evkQ, evkP)
+        for i, q in enumerate(Q):
+            assert np.array_equal(out.Value[0].numpy()[k, i], oracle.vec_op(OPS["ADD"], c0[k, i], e0[i], e0[i], 0, 0, q))
+            assert np.array_equal(out.Value[1].numpy()[k, i], oracle.vec_op(OPS["ADD"], c1[k, i], e1[i], e1[i], 0, 0, q))
+            assert np.array_equal(out2.Value[0].numpy()[k, i], oracle.vec_op(OPS["ADD"], c0[k, i], e0[i], e0[i], 0, 0, q))
+            assert np.array_equal(out2.Value[1].numpy()[k, i], e1[i])
+    with pytest.raises(rh.RingHipError):
+        ev.Relinearize(ct1, out)                       # degree must be 2
+    with pytest.raises(rh.RingHipError):
+        rh.rlwe.Evaluator(rq, rp).Relinearize(ct2, out)   # key missing
+    ev.close(); rq.close(); rp.close()
