@@ -347,7 +347,9 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
     }
   } else {
     if (phase != 1) {
-      if (r->asm_tile && S1 > 0) ntt_inv_tile_asm<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly);
+      // the hand-scheduled body leaves values < 4q unscaled: right whenever column stages follow, and for N = 4096
+      // sub-rings of the 3N transform (inv_scale = false), which scale in their own last layer
+      if (r->asm_tile && (S1 > 0 || !r->inv_scale)) ntt_inv_tile_asm<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly);
       else ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, (S1 == 0 && r->inv_scale) ? 1 : 0, npoly);
     }
     const bool acols = phase != 2 && r->asm_cols && r->asm_tile && r->inv_scale;
