@@ -45,6 +45,7 @@ struct rh_ring {
   int cols2 = 0;                  // column kernel: two adjacent columns per thread (16 B per lane)
   int dbg_lds_pad = 0;            // experiments: extra dynamic LDS of the fused forward launch (lowers workgroups per CU)
   int fuse_submul = 1;            // ModDown / rescale: subtract-multiply fused into the forward tile kernel's epilogue
+  int perm_inv_shape = 64;        // 3N inverse permutation tile: words per block-order run (32 / 64 / 128)
   int fuse3n = 1;                 // 3N rings, b = 1: split + radix-3 layer fused with the sub-transforms' column stages
   int asm_cols = 1;               // N = 2^16: hand-scheduled column stages (fwd_cols16_asm_body) in place of the C++ body
   int prefetch = 0;               // fused forward launch: issue the tile loads ahead of the column stages (ntt_fwd_fused_pre); measured: no gain

@@ -330,41 +330,45 @@ ntt3n_cols_post_inv(const u64* in, u64* out, int N, const tw2* __restrict__ r3, 
 // ---- tiled permutation (log_n2 >= 10): a tile is {j_low: 32} x {j_high: 32} x {nb blocks} for one j_mid.
 // Reads are 256 B runs (32 consecutive j), writes are nb*256 B runs (32 consecutive bitrev(j) x nb ranks).
 #define PT 5
-template <bool FWD>
+// A = low bits of j (contiguous run on the block-order side), B = high bits (contiguous, bit-reversed, on the rank-order
+// side): a tile is {jlow: 2^A} x {jhigh: 2^B} x {nb blocks} for one jmid.  Block-order runs are 2^A words, rank-order runs
+// nb * 2^B words.  Forward uses (5, 5); the inverse WRITES the block-order side, where longer runs pay: (6, 4).
+template <bool FWD, int A, int B>
 __global__ void __launch_bounds__(256)
 ntt3n_perm_tiled(const u64* in, u64* out, int N, int nb, int log_n2, const int* __restrict__ rank_of_block) {
-  extern __shared__ u64 tile[];                           // [32 j_low][32*nb + 1]
-  const int m = log_n2, midbits = m - 2 * PT;
+  extern __shared__ u64 tile[];                           // [2^A j_low][2^B * nb + 1]
+  const int m = log_n2, midbits = m - A - B;
   const u32 jmid = blockIdx.y;                            // 0 .. 2^midbits - 1
   const size_t base = (size_t)blockIdx.x * N;
-  const int rowlen = 32 * nb + 1;
+  const int nhi = 1 << B, nlo = 1 << A;
+  const int rowlen = nhi * nb + 1;
   const u32 jbmid = midbits ? (__brev(jmid) >> (32 - midbits)) : 0u;
-  // global "block order" side: element (c, jhigh, jlow) at c*n2 + (jhigh << (m-PT)) | (jmid << PT) | jlow
-  // global "rank order" side:  element at nb * ((brev5(jlow) << (m-PT)) | (jbmid << PT) | brev5(jhigh)) + rank[c]
-  const int nseg = nb * 32;                               // (c, jhigh) pairs
+  // global "block order" side: element (c, jhigh, jlow) at c*n2 + (jhigh << (m-B)) | (jmid << A) | jlow
+  // global "rank order" side:  element at nb * ((brevA(jlow) << (m-A)) | (jbmid << B) | brevB(jhigh)) + rank[c]
+  const int nseg = nb * nhi;                              // (c, jhigh) pairs
   if (FWD) {
-    for (int e = threadIdx.x; e < nseg * 32; e += 256) {
-      const int seg = e >> 5, jl = e & 31, c = seg >> 5, jh = seg & 31;
-      const u64 v = in[base + ((size_t)c << m) + ((size_t)jh << (m - PT)) + ((size_t)jmid << PT) + jl];
-      tile[jl * rowlen + (int)(__brev((u32)jh) >> 27) * nb + rank_of_block[c]] = v;
+    for (int e = threadIdx.x; e < nseg * nlo; e += 256) {
+      const int seg = e >> A, jl = e & (nlo - 1), c = seg >> B, jh = seg & (nhi - 1);
+      const u64 v = in[base + ((size_t)c << m) + ((size_t)jh << (m - B)) + ((size_t)jmid << A) + jl];
+      tile[jl * rowlen + (int)(__brev((u32)jh) >> (32 - B)) * nb + rank_of_block[c]] = v;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 32 * nseg; e += 256) {
+    for (int e = threadIdx.x; e < nlo * nseg; e += 256) {
       const int jl = e / nseg, w = e - jl * nseg;
-      const size_t jbhi = (size_t)(__brev((u32)jl) >> 27);
-      out[base + (size_t)nb * ((jbhi << (m - PT)) + ((size_t)jbmid << PT)) + w] = tile[jl * rowlen + w];
+      const size_t jbhi = (size_t)(__brev((u32)jl) >> (32 - A));
+      out[base + (size_t)nb * ((jbhi << (m - A)) + ((size_t)jbmid << B)) + w] = tile[jl * rowlen + w];
     }
   } else {
-    for (int e = threadIdx.x; e < 32 * nseg; e += 256) {
+    for (int e = threadIdx.x; e < nlo * nseg; e += 256) {
       const int jl = e / nseg, w = e - jl * nseg;
-      const size_t jbhi = (size_t)(__brev((u32)jl) >> 27);
-      tile[jl * rowlen + w] = in[base + (size_t)nb * ((jbhi << (m - PT)) + ((size_t)jbmid << PT)) + w];
+      const size_t jbhi = (size_t)(__brev((u32)jl) >> (32 - A));
+      tile[jl * rowlen + w] = in[base + (size_t)nb * ((jbhi << (m - A)) + ((size_t)jbmid << B)) + w];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < nseg * 32; e += 256) {
-      const int seg = e >> 5, jl = e & 31, c = seg >> 5, jh = seg & 31;
-      out[base + ((size_t)c << m) + ((size_t)jh << (m - PT)) + ((size_t)jmid << PT) + jl] =
-          tile[jl * rowlen + (int)(__brev((u32)jh) >> 27) * nb + rank_of_block[c]];
+    for (int e = threadIdx.x; e < nseg * nlo; e += 256) {
+      const int seg = e >> A, jl = e & (nlo - 1), c = seg >> B, jh = seg & (nhi - 1);
+      out[base + ((size_t)c << m) + ((size_t)jh << (m - B)) + ((size_t)jmid << A) + jl] =
+          tile[jl * rowlen + (int)(__brev((u32)jh) >> (32 - B)) * nb + rank_of_block[c]];
     }
   }
 }
@@ -517,6 +521,7 @@ int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
   const bool tiled = s->log_n2 >= 2 * PT && nb <= 6;     // LDS: 32*(32*nb+1)*8 bytes = 48 KiB at nb = 6
   const size_t perm_lds = (size_t)32 * (32 * nb + 1) * 8;
   const dim3 pgrid(rows, 1u << (s->log_n2 >= 2 * PT ? s->log_n2 - 2 * PT : 0));
+  const size_t perm_lds_inv = (size_t)64 * (16 * nb + 1) * 8;      // (A, B) = (6, 4): same mid-bit count, 512-byte write runs
   if (!inverse) {
     const int S1sub = s->sub ? s->log_n2 - 12 : 0;
     const bool fuse = s->b == 1 && s->sub && r->fuse3n && S1sub >= 1 && S1sub <= 3;    // 6 * 2^S1 coefficients per thread
@@ -539,10 +544,12 @@ int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
       // (poly, limb, block) rows of length n2: limb-major virtual limb index = limb*nb + c
       if (int rc = rh_std_ntt_launch(s->sub, tmp, tmp, npoly, Lrows * nb, limb0 * nb, false, false, 0)) return rc;
     }
-    if (tiled) ntt3n_perm_tiled<true><<<pgrid, 256, perm_lds, st>>>(tmp, out, N, nb, s->log_n2, s->d_rank);
+    if (tiled) ntt3n_perm_tiled<true, 5, 5><<<pgrid, 256, perm_lds, st>>>(tmp, out, N, nb, s->log_n2, s->d_rank);
     else ntt3n_perm_fwd<<<dim3(rows, chunks(N)), 256, 0, st>>>(tmp, out, N, nb, s->log_n2, s->d_block_of_rank, c, Lrows, s->sub ? 0 : 1);
   } else {
-    if (tiled) ntt3n_perm_tiled<false><<<pgrid, 256, perm_lds, st>>>(in, tmp, N, nb, s->log_n2, s->d_rank);
+    if (tiled && r->perm_inv_shape == 64) ntt3n_perm_tiled<false, 6, 4><<<pgrid, 256, perm_lds_inv, st>>>(in, tmp, N, nb, s->log_n2, s->d_rank);
+    else if (tiled && r->perm_inv_shape == 128) ntt3n_perm_tiled<false, 7, 3><<<pgrid, 256, (size_t)128 * (8 * nb + 1) * 8, st>>>(in, tmp, N, nb, s->log_n2, s->d_rank);
+    else if (tiled) ntt3n_perm_tiled<false, 5, 5><<<pgrid, 256, perm_lds, st>>>(in, tmp, N, nb, s->log_n2, s->d_rank);
     else ntt3n_perm_inv<<<dim3(rows, chunks(N)), 256, 0, st>>>(in, tmp, N, nb, s->log_n2, s->d_block_of_rank);
     const int S1sub = s->sub ? s->log_n2 - 12 : 0;
     const bool fuse = s->b == 1 && s->sub && r->fuse3n && S1sub >= 1 && S1sub <= 3;
