@@ -158,7 +158,7 @@ RH_DEV void fwd_tile_body(u64* lds, const u32 b, const u64* in, u64* out, const 
   for (int k = 0; k < 16; ++k) out[base + tid + 256 * k] = lds[LDS_PAD(tid + 256 * k)];
 }
 template <class P>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // LDS allows 4 workgroups per CU: keep the registers within that
 ntt_fwd_tile(const u64* in, u64* out, const typename P::tw_t* __restrict__ twk,
              const LimbConsts* __restrict__ consts, int L, int logN, int canonical, int npoly) {
   __shared__ u64 lds[LDS_WORDS];
@@ -170,7 +170,7 @@ ntt_fwd_tile(const u64* in, u64* out, const typename P::tw_t* __restrict__ twk,
 // DivRoundByLastModulusNTT (ring/scaling.go:120-124).  The canonical NTT values never go to memory: the element-wise
 // pass (24 B per coefficient) disappears.  y and out are (poly, limb) blocks with their own row counts.
 struct LimbScalars { u64 s[RH_MAX_LIMBS_K]; };
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // <= 128 VGPRs: 4 workgroups per CU like the asm body
 ntt_fwd_tile_submul(const u64* in, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts, int L, int logN, int npoly,
                     const u64* y, int y_rows, u64* out, int out_rows, LimbScalars sc) {
   __shared__ u64 lds[LDS_WORDS];
@@ -219,7 +219,7 @@ ntt_fwd_tile_submul(const u64* in, const tw2* __restrict__ twk, const LimbConsts
 // K2 inverse: first 12 stages (t = 1..2048) on a 4096-tile.  If `last` (logN == 12) the N^-1 scaling and the
 // canonical reduction happen here, else values leave < 4q for K1 inverse.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 ntt_inv_tile(const u64* in, u64* out, const tw2* __restrict__ twk,
              const LimbConsts* __restrict__ consts, int L, int logN, int last, int npoly) {
   __shared__ u64 lds[LDS_WORDS];
