@@ -280,18 +280,18 @@ static void launch_fwd_cols2(int S1, dim3 grid, hipStream_t st, const u64* in, u
     case 2: ntt_fwd_cols2<P, 2><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
     case 3: ntt_fwd_cols2<P, 3><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
     case 4: ntt_fwd_cols2<P, 4><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
-    case 5: ntt_fwd_cols<P, 5><<<dim3(grid.x * 2), 256, 0, st>>>(in, out, tw, c, L, logN); break;   // 64 coefficients/thread: keep one column
+    case 5: ntt_fwd_cols<P, 5><<<dim3(grid.x * 2), 256, 0, st>>>(in, out, tw, c, L, logN, 0); break;   // 64 coefficients/thread: keep one column
   }
 }
 template <class P>
 static void launch_fwd_cols(int S1, dim3 grid, hipStream_t st, const u64* in, u64* out, const typename P::tw_t* tw,
-                            const LimbConsts* c, int L, int logN) {
+                            const LimbConsts* c, int L, int logN, int Ls = 0) {
   switch (S1) {
-    case 1: ntt_fwd_cols<P, 1><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
-    case 2: ntt_fwd_cols<P, 2><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
-    case 3: ntt_fwd_cols<P, 3><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
-    case 4: ntt_fwd_cols<P, 4><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
-    case 5: ntt_fwd_cols<P, 5><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
+    case 1: ntt_fwd_cols<P, 1><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN, Ls); break;
+    case 2: ntt_fwd_cols<P, 2><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN, Ls); break;
+    case 3: ntt_fwd_cols<P, 3><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN, Ls); break;
+    case 4: ntt_fwd_cols<P, 4><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN, Ls); break;
+    case 5: ntt_fwd_cols<P, 5><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN, Ls); break;
   }
 }
 static void launch_inv_cols(int S1, dim3 grid, hipStream_t st, u64* data, const tw2* tw, const tw2* lastw,
@@ -307,7 +307,8 @@ static void launch_inv_cols(int S1, dim3 grid, hipStream_t st, u64* data, const 
 
 // limb0: first limb of the table set to use (host-pointer single-limb path); rows = npoly * Lrows.
 // phase: 0 = whole transform, 1 = column kernel only, 2 = tile kernel only (profiling aid, rh_ring_ntt_phase).
-static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase) {
+static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase,
+                               int Ls = 0) {          // Ls: rows per poly of the block when > Lrows (forward, N >= 4096 only)
   (void)hipGetLastError();                       // drop any stale error of an unrelated earlier call
   const int logN = r->logN, N = r->N;
   const size_t toff = (size_t)limb0 * N;
@@ -331,19 +332,20 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
     if (S1 > 0) {
       dim3 g1(rows * 16);
       if (phase != 2) {
-        if (lazy) launch_fwd_cols<MontPolicy>(S1, g1, st, in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN);
+        if (lazy) launch_fwd_cols<MontPolicy>(S1, g1, st, in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN, Ls);
         else if (r->cols2) launch_fwd_cols2<ShoupPolicy>(S1, dim3(rows * 8), st, in, out, r->d_tw_fwd + toff, c, Lrows, logN);
-        else if (S1 == 4 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<4><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows);
-        else if (S1 == 3 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<3><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows);
-        else if (S1 == 2 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<2><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows);
-      else      launch_fwd_cols<ShoupPolicy>(S1, g1, st, in, out, r->d_tw_fwd + toff, c, Lrows, logN);
+        else if (S1 == 4 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<4><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
+        else if (S1 == 3 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<3><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
+        else if (S1 == 2 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<2><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
+      else      launch_fwd_cols<ShoupPolicy>(S1, g1, st, in, out, r->d_tw_fwd + toff, c, Lrows, logN, Ls);
       }
       src = out;
     }
     if (phase != 1) {
-      if (lazy) ntt_fwd_tile<MontPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd_mont + toff, c, Lrows, logN, 0, npoly);
-      else if (r->asm_tile) ntt_fwd_tile_asm<<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, npoly);
-      else      ntt_fwd_tile<ShoupPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, 1, npoly);
+      const int ls = Ls ? Ls : Lrows;
+      if (lazy) ntt_fwd_tile<MontPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd_mont + toff, c, Lrows, logN, 0, npoly, ls);
+      else if (r->asm_tile) ntt_fwd_tile_asm<<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, npoly, ls);
+      else      ntt_fwd_tile<ShoupPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, 1, npoly, ls);
     }
   } else {
     if (phase != 1) {
@@ -518,6 +520,18 @@ int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows,
   if (chunk > 0 && two_pass && phase == 0 && inverse && r->asm_tile && r->inv_scale && npoly > chunk)
     return std_ntt_inv_pipelined(r, in, out, npoly, Lrows, limb0, chunk);
   return std_ntt_launch_span(r, in, out, npoly, Lrows, limb0, inverse, lazy, phase);
+}
+
+// Forward canonical transform, in place, of limbs [limb0, limb0 + Lrows) of each poly of a block that has Ls >= Lrows
+// rows per poly (`data` points at row limb0 of poly 0): lets a caller skip rows it will overwrite anyway (the digit's own
+// limbs in DecomposeSingleNTT).  N >= 4096 standard rings; cols2 / cluster / pipeline variants are not involved.
+int rh_std_ntt_fwd_strided(rh_ring* r, u64* data, int npoly, int Lrows, int limb0, int Ls) {
+  if (r->logN < LT || Ls < Lrows) return rh_fail(RH_ERR_ARG, "strided transform needs N >= 4096 and a row stride >= the row count");
+  if (Lrows <= 0 || npoly <= 0) return RH_OK;
+  const int saved = r->cols2; r->cols2 = 0;
+  const int rc = std_ntt_launch_span(r, data, data, npoly, Lrows, limb0, false, false, 0, Ls);
+  r->cols2 = saved;
+  return rc;
 }
 
 bool rh_can_fuse_submul(const rh_ring* r) { return r->kind == RH_RING_STANDARD && r->logN >= LT && r->fuse_submul; }

@@ -101,8 +101,11 @@ static int decompose_single_ntt(rh_bext* be, int levelQ, int levelP, int i, cons
   rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
   const int LQ = levelQ + 1, LP = levelP + 1, N = RQ->N;
   if (int rc = rh_bext_decompose_and_split(be, levelQ, levelP, LP, i, cxInv, c2Q, c2P, npoly)) return rc;
-  if (int rc = rh_std_ntt_launch(RQ, c2Q, c2Q, npoly, LQ, 0, false, false, 0)) return rc;
   const int st = i * LP; int ed = st + LP; if (ed > LQ) ed = LQ;
+  if (RQ->logN >= 12) {          // the digit's own limbs are overwritten below: transform only the limbs around them
+    if (int rc = rh_std_ntt_fwd_strided(RQ, c2Q, npoly, st, 0, LQ)) return rc;
+    if (int rc = rh_std_ntt_fwd_strided(RQ, c2Q + (size_t)ed * N, npoly, LQ - ed, ed, LQ)) return rc;
+  } else if (int rc = rh_std_ntt_launch(RQ, c2Q, c2Q, npoly, LQ, 0, false, false, 0)) return rc;
   if (hipMemcpy2DAsync(c2Q + (size_t)st * N, (size_t)LQ * N * 8, cx + (size_t)st * N, (size_t)LQ * N * 8, (size_t)(ed - st) * N * 8, npoly,
                        hipMemcpyDeviceToDevice, RQ->stream) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_product: digit copy failed");
   return rh_std_ntt_launch(RP, c2P, c2P, npoly, LP, 0, false, false, 0);

@@ -118,7 +118,7 @@ RH_DEV void round16_inv(const P& p, u64 (&x)[16], TWF TW) {
 // ---------------------------------------------------------------------------------------------------------------
 template <class P>
 RH_DEV void fwd_tile_body(u64* lds, const u32 b, const u64* in, u64* out, const typename P::tw_t* __restrict__ twk,
-                          const LimbConsts* __restrict__ consts, int L, int logN, int canonical, int npoly) {
+                          const LimbConsts* __restrict__ consts, int L, int logN, int canonical, int npoly, int Ls) {
   const int tid = threadIdx.x;
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
@@ -127,7 +127,7 @@ RH_DEV void fwd_tile_body(u64* lds, const u32 b, const u64* in, u64* out, const 
   // tile's twiddles (64 KiB per limb) are served by the XCD's L2 instead of being re-fetched per poly
   const u32 poly = r % (u32)npoly;
   const u32 tile = r / (u32)npoly;
-  const size_t base = (((size_t)poly * L + limb) << logN) + ((size_t)tile << LT);
+  const size_t base = (((size_t)poly * Ls + limb) << logN) + ((size_t)tile << LT);   // Ls = rows per poly of the block (>= L)
   const typename P::tw_t* tw = twk + ((size_t)limb << logN) + ((size_t)tile << LT);
   P p; p.init(consts[limb]);
 
@@ -160,9 +160,9 @@ RH_DEV void fwd_tile_body(u64* lds, const u32 b, const u64* in, u64* out, const 
 template <class P>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // LDS allows 4 workgroups per CU: keep the registers within that
 ntt_fwd_tile(const u64* in, u64* out, const typename P::tw_t* __restrict__ twk,
-             const LimbConsts* __restrict__ consts, int L, int logN, int canonical, int npoly) {
+             const LimbConsts* __restrict__ consts, int L, int logN, int canonical, int npoly, int Ls) {
   __shared__ u64 lds[LDS_WORDS];
-  fwd_tile_body<P>(lds, blockIdx.x, in, out, twk, consts, L, logN, canonical, npoly);
+  fwd_tile_body<P>(lds, blockIdx.x, in, out, twk, consts, L, logN, canonical, npoly, Ls);
 }
 
 // Forward tile stages with a fused epilogue: out = MRed(2q - y + NTT(in), s_limb) -- the subtract-multiply that follows a
@@ -272,13 +272,14 @@ ntt_inv_tile(const u64* in, u64* out, const tw2* __restrict__ twk,
 // WT: write-through (sc1) stores, for the in-launch hand-off of the persistent pipeline (ntt_kernels_asm.cuh)
 template <class P, int S1, bool WT = false>
 RH_DEV void fwd_cols_body(const u32 b, const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
-                          const LimbConsts* __restrict__ consts, int L, int logN) {
+                          const LimbConsts* __restrict__ consts, int L, int logN, int Ls = 0) {
+  if (Ls == 0) Ls = L;                     // rows per poly of the block (>= L)
   constexpr int R = 1 << S1;
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
   const u32 cb = r & 15;            // 16 blocks of 256 columns per limb
   const u32 poly = r >> 4;
-  const size_t base = (((size_t)poly * L + limb) << logN) + cb * 256 + threadIdx.x;
+  const size_t base = (((size_t)poly * Ls + limb) << logN) + cb * 256 + threadIdx.x;
   const typename P::tw_t* tw = twn + ((size_t)limb << logN);
   P p; p.init(consts[limb]);
   u64 x[R];
@@ -304,8 +305,8 @@ RH_DEV void fwd_cols_body(const u32 b, const u64* in, u64* out, const typename P
 template <class P, int S1>
 __global__ void __launch_bounds__(256)
 ntt_fwd_cols(const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
-             const LimbConsts* __restrict__ consts, int L, int logN) {
-  fwd_cols_body<P, S1>(blockIdx.x, in, out, twn, consts, L, logN);
+             const LimbConsts* __restrict__ consts, int L, int logN, int Ls) {
+  fwd_cols_body<P, S1>(blockIdx.x, in, out, twn, consts, L, logN, Ls);
 }
 // two adjacent columns per thread: every global access is 16 B per lane (1 KiB per wave instruction)
 template <class P, int S1>
@@ -361,7 +362,7 @@ ntt_fwd_fused(const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n2, i
               const LimbConsts* __restrict__ consts, int L, int logN, int canonical) {
   __shared__ u64 lds[LDS_WORDS];
   if (blockIdx.x < n1) fwd_cols_body<P, S1>(blockIdx.x, in1, out1, twn, consts, L, logN);
-  if (blockIdx.x < n2) fwd_tile_body<P>(lds, blockIdx.x, data2, data2, twk, consts, L, logN, canonical, npoly2);
+  if (blockIdx.x < n2) fwd_tile_body<P>(lds, blockIdx.x, data2, data2, twk, consts, L, logN, canonical, npoly2, L);
 }
 
 // K1 inverse: last S1 stages (t = 4096 .. N/2), in natural-order RootsBackward indexing, then N^-1 and canonical

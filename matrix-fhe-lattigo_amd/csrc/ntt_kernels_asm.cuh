@@ -15,12 +15,13 @@ RH_DEV u64 uni64(u64 x) { return ((u64)uni32((u32)(x >> 32)) << 32) | uni32((u32
 
 template <bool SC1 = false>
 RH_DEV void fwd_tile_asm_body(u64* lds, const u32 b, const u64* in, u64* out, const tw2* __restrict__ twk,
-                              const LimbConsts* __restrict__ consts, int L, int logN, int npoly) {
+                              const LimbConsts* __restrict__ consts, int L, int logN, int npoly, int Ls = 0) {
+  if (Ls == 0) Ls = L;                     // rows per poly of the block (>= L)
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
   const u32 poly = r % (u32)npoly;
   const u32 tile = r / (u32)npoly;
-  const size_t base = (((size_t)poly * L + limb) << logN) + ((size_t)tile << LT);
+  const size_t base = (((size_t)poly * Ls + limb) << logN) + ((size_t)tile << LT);
   const u64 pin = uni64((u64)(size_t)(in + base));
   const u64 pout = uni64((u64)(size_t)(out + base));
   const u64 tw = uni64((u64)(size_t)(twk + ((size_t)limb << logN) + ((size_t)tile << LT)));
@@ -52,12 +53,13 @@ constexpr bool has_asm_cols(int S1) { return S1 >= 2 && S1 <= 4; }
                [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4) : NTT_TILE_ASM_CLOBBERS)
 template <int S1>
 RH_DEV void fwd_cols_asm_body(const u32 b, const u64* in, u64* out, const tw2* __restrict__ twn,
-                              const LimbConsts* __restrict__ consts, int L) {
+                              const LimbConsts* __restrict__ consts, int L, int Ls = 0) {
+  if (Ls == 0) Ls = L;                     // rows per poly of the block (>= L)
   static_assert(has_asm_cols(S1), "asm column stages exist for S1 = 2..4");
   constexpr int logN = LT + S1;
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
-  const size_t base = (((size_t)(r >> 4) * L + limb) << logN) + (r & 15) * 256;
+  const size_t base = (((size_t)(r >> 4) * Ls + limb) << logN) + (r & 15) * 256;
   const u64 pin = uni64((u64)(size_t)(in + base));
   const u64 pout = uni64((u64)(size_t)(out + base));
   const u64 tw = uni64((u64)(size_t)(twn + ((size_t)limb << logN)));
@@ -76,15 +78,15 @@ RH_DEV void fwd_cols_best(const u32 b, const u64* in, u64* out, const tw2* __res
 }
 template <int S1>
 __global__ void __launch_bounds__(256)
-ntt_fwd_cols_asm(const u64* in, u64* out, const tw2* __restrict__ twn, const LimbConsts* __restrict__ consts, int L) {
-  fwd_cols_asm_body<S1>(blockIdx.x, in, out, twn, consts, L);
+ntt_fwd_cols_asm(const u64* in, u64* out, const tw2* __restrict__ twn, const LimbConsts* __restrict__ consts, int L, int Ls) {
+  fwd_cols_asm_body<S1>(blockIdx.x, in, out, twn, consts, L, Ls);
 }
 
 __global__ void __launch_bounds__(256)
 ntt_fwd_tile_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts,
-                 int L, int logN, int npoly) {
+                 int L, int logN, int npoly, int Ls) {
   __shared__ u64 lds[LDS_WORDS];
-  fwd_tile_asm_body(lds, blockIdx.x, in, out, twk, consts, L, logN, npoly);
+  fwd_tile_asm_body(lds, blockIdx.x, in, out, twk, consts, L, logN, npoly, Ls);
 }
 
 // software-pipelined launch (see ntt_fwd_fused): column stages of span j (C++ body), then the asm tile body of span j-1
