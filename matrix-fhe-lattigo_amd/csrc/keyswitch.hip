@@ -51,7 +51,8 @@ int rh_gadget_mac(rh_ring* r, const u64* c2, const u64* e0, const u64* e1, u64* 
 // read and rewritten per digit.  poly is the fast block index, so the workgroups that share a key row run together.
 __global__ void __launch_bounds__(256)
 gadget_mac_all_kernel(const u64* c2, size_t digit_stride, const u64* __restrict__ evk, size_t evk_stride, int beta, int overf,
-                      u64* acc0, u64* acc1, unsigned n, const LimbConsts* __restrict__ consts, int L, int npoly) {
+                      u64* acc0, u64* acc1, unsigned n, const LimbConsts* __restrict__ consts, int L, int npoly,
+                      const u64* cx, int digit_limbs) {   // cx != null: limb l of digit l / digit_limbs is read from cx (:467-468), not from c2
   const u32 poly = blockIdx.x % (u32)npoly, limb = blockIdx.x / (u32)npoly;
   const LimbConsts c = consts[limb];
   const size_t ro = ((size_t)poly * L + limb) * n, eo = (size_t)limb * n;
@@ -60,7 +61,8 @@ gadget_mac_all_kernel(const u64* c2, size_t digit_stride, const u64* __restrict_
     ulonglong2 a = {0, 0}, b = {0, 0};
     int red = 0;
     for (int d = 0; d < beta; ++d) {
-      const ulonglong2 x = *reinterpret_cast<const ulonglong2*>(c2 + (size_t)d * digit_stride + ro + 2 * (size_t)i);
+      const u64* src = (cx && (int)limb / digit_limbs == d) ? cx + ro : c2 + (size_t)d * digit_stride + ro;
+      const ulonglong2 x = *reinterpret_cast<const ulonglong2*>(src + 2 * (size_t)i);
       const ulonglong2 k0 = *reinterpret_cast<const ulonglong2*>(evk + ((size_t)d * 2) * evk_stride + eo + 2 * (size_t)i);
       const ulonglong2 k1 = *reinterpret_cast<const ulonglong2*>(evk + ((size_t)d * 2 + 1) * evk_stride + eo + 2 * (size_t)i);
       a.x += mred_lazy(k0.x, x.x, c.q, c.qinv); a.y += mred_lazy(k0.y, x.y, c.q, c.qinv);
@@ -80,11 +82,12 @@ gadget_mac_all_kernel(const u64* c2, size_t digit_stride, const u64* __restrict_
   }
 }
 
-static int mac_all(rh_ring* r, const u64* c2, size_t digit_stride, const u64* evk, int beta, int overf, u64* a0, u64* a1, int npoly, int L) {
+static int mac_all(rh_ring* r, const u64* c2, size_t digit_stride, const u64* evk, int beta, int overf, u64* a0, u64* a1, int npoly, int L,
+                   const u64* cx = nullptr, int digit_limbs = 1) {
   const unsigned n = (unsigned)r->N;
   unsigned chunks = (n / 2 + 1023) / 1024; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
   gadget_mac_all_kernel<<<dim3((unsigned)npoly * L, chunks), 256, 0, r->stream>>>(c2, digit_stride, evk, (size_t)r->L * n, beta, overf, a0, a1, n,
-                                                                                 r->d_consts, L, npoly);
+                                                                                 r->d_consts, L, npoly, cx, digit_limbs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_mac_all_kernel launch failed: %s", hipGetErrorString(e));
   return RH_OK;
@@ -97,7 +100,8 @@ int rh_overflow_margin(const std::vector<u64>& m, int level) {     // QiOverflow
 
 // DecomposeSingleNTT (:455-478): digit i of cx -> c2Q (levelQ+1 limbs), c2P (levelP+1 limbs), NTT domain.
 // cx: NTT-domain input (its digit limbs are copied as they are, :467-468), cxInv: its inverse transform.
-static int decompose_single_ntt(rh_bext* be, int levelQ, int levelP, int i, const u64* cx, const u64* cxInv, u64* c2Q, u64* c2P, int npoly) {
+static int decompose_single_ntt(rh_bext* be, int levelQ, int levelP, int i, const u64* cx, const u64* cxInv, u64* c2Q, u64* c2P, int npoly,
+                                bool copy_digit = true) {   // false: the consumer reads the digit's own limbs from cx itself
   rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
   const int LQ = levelQ + 1, LP = levelP + 1, N = RQ->N;
   if (int rc = rh_bext_decompose_and_split(be, levelQ, levelP, LP, i, cxInv, c2Q, c2P, npoly)) return rc;
@@ -106,8 +110,8 @@ static int decompose_single_ntt(rh_bext* be, int levelQ, int levelP, int i, cons
     if (int rc = rh_std_ntt_fwd_strided(RQ, c2Q, npoly, st, 0, LQ)) return rc;
     if (int rc = rh_std_ntt_fwd_strided(RQ, c2Q + (size_t)ed * N, npoly, LQ - ed, ed, LQ)) return rc;
   } else if (int rc = rh_std_ntt_launch(RQ, c2Q, c2Q, npoly, LQ, 0, false, false, 0)) return rc;
-  if (hipMemcpy2DAsync(c2Q + (size_t)st * N, (size_t)LQ * N * 8, cx + (size_t)st * N, (size_t)LQ * N * 8, (size_t)(ed - st) * N * 8, npoly,
-                       hipMemcpyDeviceToDevice, RQ->stream) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_product: digit copy failed");
+  if (copy_digit && hipMemcpy2DAsync(c2Q + (size_t)st * N, (size_t)LQ * N * 8, cx + (size_t)st * N, (size_t)LQ * N * 8, (size_t)(ed - st) * N * 8, npoly,
+                                     hipMemcpyDeviceToDevice, RQ->stream) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_product: digit copy failed");
   return rh_std_ntt_launch(RP, c2P, c2P, npoly, LP, 0, false, false, 0);
 }
 
@@ -150,9 +154,10 @@ extern "C" int rh_bext_decompose_ntt(rh_bext* be, int levelQ, int levelP, const 
   return RH_OK;
 }
 
-// Evaluator.GadgetProductHoisted (:326-349) = gadgetProductMultiplePLazyHoisted (:373-429) + ModDown NTT->NTT (:33-46)
-extern "C" int rh_bext_gadget_product_hoisted(rh_bext* be, int levelQ, int levelP, const uint64_t* decompQ, const uint64_t* decompP,
-                                              const uint64_t* evkQ, const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly) {
+// Evaluator.GadgetProductHoisted (:326-349) = gadgetProductMultiplePLazyHoisted (:373-429) + ModDown NTT->NTT (:33-46).
+// cx != null (internal, direct product): the digits' own limbs of decompQ were not filled; the multiply-accumulate reads them from cx.
+static int hoisted_tail(rh_bext* be, int levelQ, int levelP, const uint64_t* decompQ, const uint64_t* decompP, const uint64_t* evkQ,
+                        const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly, const uint64_t* cx) {
   if (!decompQ || !decompP || !evkQ || !evkP || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "gadget_product_hoisted: null argument");
   int beta; if (int rc = ks_check(be, levelQ, levelP, beta_key, "gadget_product_hoisted", &beta)) return rc;
   if (npoly <= 0) return RH_OK;
@@ -164,10 +169,14 @@ extern "C" int rh_bext_gadget_product_hoisted(rh_bext* be, int levelQ, int level
   if (int rc = rh_bext_scratch(be, 6, wp, &aP1)) return rc;
   const size_t evq_stride = (size_t)RQ->L * N, evp_stride = (size_t)RP->L * N;
   ReduceSchedule rs(RQ, levelQ, RP, levelP);
-  if (int rc = mac_all(RQ, decompQ, wq, evkQ, beta, rs.QiOverF, ct0, ct1, npoly, LQ)) return rc;
+  if (int rc = mac_all(RQ, decompQ, wq, evkQ, beta, rs.QiOverF, ct0, ct1, npoly, LQ, cx, LP)) return rc;
   if (int rc = mac_all(RP, decompP, wp, evkP, beta, rs.PiOverF, aP0, aP1, npoly, LP)) return rc;
   if (int rc = rh_bext_moddown_qp_to_q_ntt(be, levelQ, levelP, ct0, aP0, ct0, npoly)) return rc;
   return rh_bext_moddown_qp_to_q_ntt(be, levelQ, levelP, ct1, aP1, ct1, npoly);
+}
+extern "C" int rh_bext_gadget_product_hoisted(rh_bext* be, int levelQ, int levelP, const uint64_t* decompQ, const uint64_t* decompP,
+                                              const uint64_t* evkQ, const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly) {
+  return hoisted_tail(be, levelQ, levelP, decompQ, decompP, evkQ, evkP, beta_key, ct0, ct1, npoly, nullptr);
 }
 
 extern "C" int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, const uint64_t* evkQ,
@@ -184,6 +193,10 @@ extern "C" int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const
   u64 *decQ, *decP;
   if (int rc = rh_bext_scratch(be, 3, (size_t)beta * wq, &decQ)) return rc;
   if (int rc = rh_bext_scratch(be, 4, (size_t)beta * wp, &decP)) return rc;
-  if (int rc = rh_bext_decompose_ntt(be, levelQ, levelP, cx, 1, decQ, decP, npoly)) return rc;
-  return rh_bext_gadget_product_hoisted(be, levelQ, levelP, decQ, decP, evkQ, evkP, beta_key, ct0, ct1, npoly);
+  u64* cxInv;
+  if (int rc = rh_bext_scratch(be, 2, wq, &cxInv)) return rc;
+  if (int rc = rh_std_ntt_launch(RQ, cx, cxInv, npoly, LQ, 0, true, false, 0)) return rc;                  // ringQ.INTT(cxNTT, cxInvNTT) (:138)
+  for (int i = 0; i < beta; ++i)
+    if (int rc = decompose_single_ntt(be, levelQ, levelP, i, cx, cxInv, decQ + (size_t)i * wq, decP + (size_t)i * wp, npoly, false)) return rc;
+  return hoisted_tail(be, levelQ, levelP, decQ, decP, evkQ, evkP, beta_key, ct0, ct1, npoly, cx);
 }
