@@ -85,3 +85,33 @@ def test_small_moduli_and_mixed_sizes(rh, oracle):
     ring.NTT(p, o); ring.INTT(o, o)
     assert np.array_equal(o.numpy(), a)
     ring.close()
+
+
+def test_thirty_two_limbs_and_widest_basis_extension(rh, oracle):
+    # the reference's largest basis: 32 source limbs (stack arrays of reconstructRNS, ring/basis_extension.go:285); all 32 Qi60
+    # primes in one ring: NTT round trip + one limb vs the oracle, ModUpQtoP from 32 limbs (the bounded-unroll kernel variant)
+    # and ModUpPtoQ to 32 limbs against the oracle, unreduced values bit for bit
+    from conftest import QI60, PI60
+    N, B = 1 << 13, 2
+    Q, P = QI60[:32], PI60[:3]
+    rq, rp = rh.Ring(N, Q), rh.Ring(N, P)
+    rng = np.random.default_rng(32)
+    a = np.stack([np.stack([rng.integers(0, 1 << 62, size=N, dtype=np.uint64) % np.uint64(q) for q in Q]) for _ in range(B)])
+    p = rh.DevicePoly.from_numpy(rq, a)
+    f = rq.NewPoly(B)
+    rq.NTT(p, f)
+    sr = oracle.SubRingConsts(N, Q[31])
+    assert np.array_equal(f.numpy()[1, 31], oracle.ntt(a[1, 31], sr))
+    rq.INTT(f, f)
+    assert np.array_equal(f.numpy(), a)
+    be = rh.BasisExtender(rq, rp)
+    outp = rp.NewPoly(B)
+    be.ModUpQtoP(31, 2, p, outp)
+    for k in range(B):
+        assert np.array_equal(outp.numpy()[k], oracle.modup_centered(a[k], Q, P))
+    b = np.stack([np.stack([rng.integers(0, 1 << 62, size=N, dtype=np.uint64) % np.uint64(m) for m in P]) for _ in range(B)])
+    outq = rq.NewPoly(B)
+    be.ModUpPtoQ(2, 31, rh.DevicePoly.from_numpy(rp, b), outq)
+    for k in range(B):
+        assert np.array_equal(outq.numpy()[k], oracle.modup_centered(b[k], P, Q))
+    be.close(); rq.close(); rp.close()
