@@ -114,4 +114,9 @@ def test_thirty_two_limbs_and_widest_basis_extension(rh, oracle):
     be.ModUpPtoQ(2, 31, rh.DevicePoly.from_numpy(rp, b), outq)
     for k in range(B):
         assert np.array_equal(outq.numpy()[k], oracle.modup_centered(b[k], P, Q))
+    # 12 source limbs: the 16-bounded kernel variant (levels below the top, polys allocated at that level)
+    p12 = rh.DevicePoly.from_numpy(rq.AtLevel(11), np.ascontiguousarray(a[:, :12]))
+    be.ModUpQtoP(11, 2, p12, outp)
+    for k in range(B):
+        assert np.array_equal(outp.numpy()[k], oracle.modup_centered(a[k, :12], Q[:12], P))
     be.close(); rq.close(); rp.close()
