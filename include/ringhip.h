@@ -92,7 +92,16 @@ int rh_ring_intt(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npol
 
 /* profiling aid: phase 0 = whole transform, 1 = column kernel only, 2 = tile kernel only (N >= 8192) */
 int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int inverse, int phase);
-/* tuning knobs (performance only, never results): "chunk_polys" = polys per span of the fused (column+tile) forward pipeline: -1 auto, 0 = whole batch in two launches; "asm_tile", "persistent", "group_polys": see DESIGN.md */
+/* Tuning knobs: performance only, never results (each non-default setting is covered by a parity test).  Unknown keys
+ * return RH_ERR_ARG.  Defaults are the measured optimum on MI355X.
+ *   chunk_polys     polys per span of the fused (column + tile) pipeline: -1 auto (auto_span_rows), 0 = two launches per batch
+ *   auto_span_rows  span size of the auto rule in (poly, limb) rows (2048)
+ *   asm_tile / asm_cols   1: generated hand-scheduled bodies (default), 0: the C++ kernels
+ *   fuse_submul     1: ModDown / rescale subtract-multiply in the forward tile kernel's epilogue (default)
+ *   fuse3n          1: 3N rings, split + radix-3 layer fused with the sub-transforms' column stages (default)
+ *   perm_inv_shape  3N inverse permutation tile: 32 / 64 (default) / 128 words per block-order run
+ *   experiments, off by default: cluster, cluster_wgs_per_cu, cluster_dbg, persistent, group_polys, persist_grid,
+ *   persist_unsafe_timing, prefetch, order_mix, cols2, dbg_lds_pad (what did not work) */
 int rh_ring_set_tuning(rh_ring* r, const char* key, long value);
 
 /* ---- element-wise family (ring/vec_ops.go via ring/operations.go loops): p3 = op(p1, p2 [, p3]) on npoly polys of
