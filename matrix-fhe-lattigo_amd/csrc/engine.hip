@@ -537,14 +537,33 @@ int rh_std_ntt_fwd_strided(rh_ring* r, u64* data, int npoly, int Lrows, int limb
 bool rh_can_fuse_submul(const rh_ring* r) { return r->kind == RH_RING_STANDARD && r->logN >= LT && r->fuse_submul; }
 // Forward canonical transform of `buf` (in place up to its tile stages) fused with out = MRed(2q - y + NTT(buf), s_limb):
 // column stages as usual, then ntt_fwd_tile_submul.  y / out: (poly, limb) blocks with y_rows / out_rows limbs per poly.
+// rescale: column stages of limbs 0..Lrows-1 fed by the re-expansion of the coefficient-domain last limb `tmp` (N >= 8192)
+int rh_std_ntt_expand_cols_launch(rh_ring* r, const u64* tmp, u64* buf, int npoly, int Lrows, const void* table_dev, int mode, u64 qL) {
+  const int S1 = r->logN - LT;
+  if (S1 < 1 || S1 > 5) return rh_fail(RH_ERR_UNSUPPORTED, "expand + column stages need 8192 <= N <= 2^17");
+  const unsigned rows = (unsigned)npoly * (unsigned)Lrows;
+  if (rows == 0) return RH_OK;
+  (void)hipGetLastError();
+  const RescaleLimb* T = (const RescaleLimb*)table_dev;
+  const dim3 g(rows * 16);
+  switch (S1) {
+    case 1: ntt_fwd_cols_expand<1><<<g, 256, 0, r->stream>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;
+    case 2: ntt_fwd_cols_expand<2><<<g, 256, 0, r->stream>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;
+    case 3: ntt_fwd_cols_expand<3><<<g, 256, 0, r->stream>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;
+    case 4: ntt_fwd_cols_expand<4><<<g, 256, 0, r->stream>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;
+    case 5: ntt_fwd_cols_expand<5><<<dim3(rows * 16), 256, 0, r->stream>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;
+  }
+  return check_launch("ntt_fwd_cols_expand");
+}
+
 int rh_std_ntt_submul_launch(rh_ring* r, u64* buf, int npoly, int Lrows, int limb0, const u64* y, int y_rows, u64* out, int out_rows,
-                             const u64* scalars_host) {
+                             const u64* scalars_host, bool cols_done) {
   static_assert(RH_MAX_LIMBS_K == RH_MAX_LIMBS, "limb bound mismatch");
   if (!rh_can_fuse_submul(r)) return rh_fail(RH_ERR_UNSUPPORTED, "fused subtract-multiply needs a standard ring with N >= 4096");
   const unsigned rows = (unsigned)npoly * (unsigned)Lrows;
   if (rows == 0) return RH_OK;
   const int S1 = r->logN - LT;
-  if (S1 > 0) if (int rc = rh_std_ntt_launch(r, buf, buf, npoly, Lrows, limb0, false, false, 1)) return rc;   // column stages only
+  if (S1 > 0 && !cols_done) if (int rc = rh_std_ntt_launch(r, buf, buf, npoly, Lrows, limb0, false, false, 1)) return rc;   // column stages only
   (void)hipGetLastError();
   LimbScalars sc; memset(&sc, 0, sizeof(sc)); memcpy(sc.s, scalars_host, (size_t)Lrows * 8);
   const size_t toff = (size_t)limb0 * r->N;

@@ -60,7 +60,8 @@ int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows,
 int rh_std_ntt_fwd_strided(rh_ring* r, u64* data, int npoly, int Lrows, int limb0, int Ls);
 bool rh_can_fuse_submul(const rh_ring* r);
 int rh_std_ntt_submul_launch(rh_ring* r, u64* buf, int npoly, int Lrows, int limb0, const u64* y, int y_rows, u64* out, int out_rows,
-                             const u64* scalars_host);
+                             const u64* scalars_host, bool cols_done = false);
+int rh_std_ntt_expand_cols_launch(rh_ring* r, const u64* tmp, u64* buf, int npoly, int Lrows, const void* table_dev, int mode, u64 qL);
 int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3, int npoly, int Lrows, int limb0,
                   const u64* s0, const u64* s1);
 int rh_std_upload_tables(rh_ring* r, const std::vector<tw2>& fs, const std::vector<tw2>& is, const std::vector<u64>* mont,

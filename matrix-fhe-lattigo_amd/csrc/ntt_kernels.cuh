@@ -308,6 +308,45 @@ ntt_fwd_cols(const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
              const LimbConsts* __restrict__ consts, int L, int logN, int Ls) {
   fwd_cols_body<P, S1>(blockIdx.x, in, out, twn, consts, L, logN, Ls);
 }
+// Column stages fed by the re-expansion of a rescale step (ring/scaling.go:97-118): x = (t [+ h, recentred]) mod q_limb is
+// computed on the fly from the coefficient-domain last limb t (one row per poly, L2-resident across the limbs) instead of
+// being written to a buffer and read back.  Same arithmetic as rescale_expand_kernel followed by fwd_cols_body.
+template <int S1>
+__global__ void __launch_bounds__(256)
+ntt_fwd_cols_expand(const u64* tmp, u64* out, const tw2* __restrict__ twn, const LimbConsts* __restrict__ consts,
+                    const RescaleLimb* __restrict__ T, int L, int logN, int mode, u64 qL) {
+  constexpr int R = 1 << S1;
+  const u32 b = blockIdx.x;
+  const u32 limb = b % (u32)L;
+  const u32 r = b / (u32)L;
+  const u32 cb = r & 15;
+  const u32 poly = r >> 4;
+  const size_t col = cb * 256 + threadIdx.x;
+  const size_t base = (((size_t)poly * L + limb) << logN) + col;
+  const tw2* tw = twn + ((size_t)limb << logN);
+  const RescaleLimb l = T[limb];
+  ShoupPolicy p; p.init(consts[limb]);
+  u64 x[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    u64 t = tmp[((size_t)poly << logN) + col + ((size_t)k << LT)];
+    if (mode == 1) t = cred(t + ((qL - 1) >> 1), qL) + l.s;              // AddScalarLazy (:104)
+    x[k] = bred_add(t, l.q, l.bred0);
+  }
+#pragma unroll
+  for (int s = 0; s < S1; ++s) {
+    const int h = R >> (s + 1);
+#pragma unroll
+    for (int g = 0; g < (1 << s); ++g) {
+      tw2 w = tw[(1 << s) + g];
+#pragma unroll
+      for (int e = 0; e < h; ++e) p.fwd(x[g * 2 * h + e], x[g * 2 * h + e + h], w, false);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) out[base + ((size_t)k << LT)] = x[k];
+}
+
 // two adjacent columns per thread: every global access is 16 B per lane (1 KiB per wave instruction)
 template <class P, int S1>
 RH_DEV void fwd_cols2_body(const u32 b, const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,

@@ -11,7 +11,6 @@
 #include "engine_internal.hpp"
 #include "hostmath.hpp"
 
-struct RescaleLimb { u64 q, qinv, bred0, c /* MForm(q - qL^-1) */, s /* q - (h mod q) */; };
 
 // mode 0 = floor, 1 = round.  p0: rows0 limbs per poly (limbs 0..level), p1: rows1 limbs per poly (limbs 0..level-1).
 __global__ void __launch_bounds__(256)
@@ -160,12 +159,15 @@ extern "C" int rh_ring_div_by_last_modulus_many_ntt(rh_ring* r, int round, int l
     u64* tmp = r->d_rs[0]; u64* buff = r->d_rs[1];
     gather_limb_kernel<<<grid, 256, 0, r->stream>>>(p0, level + 1, level, tmp, N);
     if (int rc = rh_std_ntt_launch(r, tmp, tmp, npoly, 1, level, true, true, 0)) return rc;
-    rescale_expand_kernel<<<grid, 256, 0, r->stream>>>(round ? 1 : 0, tmp, buff, level, level, N, r->moduli[level], T);
     if (level > 0 && rh_can_fuse_submul(r)) {          // p1 = MRed(2q - p0 + NTT(buff), c_i) in the tile kernel's epilogue (:120-124)
       std::vector<u64> sc(level);
       for (int i = 0; i < level; ++i) sc[i] = rh::mform(r->moduli[i] - rh::invmod_prime(r->moduli[level] % r->moduli[i], r->moduli[i]), r->moduli[i]);
-      return rh_std_ntt_submul_launch(r, buff, npoly, level, 0, p0, level + 1, p1, p1_rows, sc.data());
+      const bool fuse_expand = r->logN > 12 && r->logN <= 17;       // the re-expansion feeds the column stages directly
+      if (fuse_expand) { if (int rc = rh_std_ntt_expand_cols_launch(r, tmp, buff, npoly, level, T, round ? 1 : 0, r->moduli[level])) return rc; }
+      else rescale_expand_kernel<<<grid, 256, 0, r->stream>>>(round ? 1 : 0, tmp, buff, level, level, N, r->moduli[level], T);
+      return rh_std_ntt_submul_launch(r, buff, npoly, level, 0, p0, level + 1, p1, p1_rows, sc.data(), fuse_expand);
     }
+    rescale_expand_kernel<<<grid, 256, 0, r->stream>>>(round ? 1 : 0, tmp, buff, level, level, N, r->moduli[level], T);
     if (level > 0) if (int rc = rh_std_ntt_launch(r, buff, buff, npoly, level, 0, false, false, 0)) return rc;
     rescale_finish_kernel<<<grid, 256, 0, r->stream>>>(buff, level, p0, level + 1, p1, p1_rows, level, N, T);
     return launched("rescale (NTT domain)");

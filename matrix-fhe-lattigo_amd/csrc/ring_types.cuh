@@ -16,3 +16,6 @@ struct tw2 { u64 w, wp; };     // Shoup pair: root in standard form, floor(root*
 #define TILE (1 << LT)
 #define LDS_PAD(j) ((j) + ((j) >> 4))
 #define LDS_WORDS (TILE + (TILE >> 4))
+
+// per-limb constants of one rescale step at a given level (rescale.hip; also read by ntt_fwd_cols_expand)
+struct RescaleLimb { u64 q, qinv, bred0, c /* MForm(q - qL^-1) */, s /* q - (h mod q) */; };

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("round_", [0, 1])
-@pytest.mark.parametrize("N,L,nb", [(64, 4, 3), (4096, 6, 1), (8192, 6, 5), (64, 2, 1), (1 << 15, 8, 2)])
+@pytest.mark.parametrize("N,L,nb", [(64, 4, 3), (4096, 6, 1), (8192, 6, 5), (64, 2, 1), (1 << 15, 8, 2), (8192, 5, 1), (1 << 16, 4, 1), (1 << 14, 2, 1)])
 def test_div_many_coefficient_and_ntt_domain(rh, oracle, N, L, nb, round_):
     Q = QI60[:L]
     ring = rh.Ring(N, Q)
