@@ -16,6 +16,7 @@ class Evaluator:
     def __init__(self, ringQ, ringP=None, rlk=None, levels_consumed_per_rescaling=1):
         self.ringQ, self.ringP, self.rlk = ringQ, ringP, rlk
         self.nb_rescales = int(levels_consumed_per_rescaling)
+        self.fused_tensor = True          # regular ct x ct case: rh_ring_tensor_degree1 instead of six element-wise launches (same bits)
         self.ks = rlwe.Evaluator(ringQ, ringP) if ringP is not None else None
 
     def close(self):
@@ -47,13 +48,16 @@ class Evaluator:
             c0, c1 = opOut.Value[0], opOut.Value[1]
             c2 = new() if relin else opOut.Value[2]
             tmp0, tmp1 = (op1, op0) if op1 is opOut else (op0, op1)        # avoid overwriting when the second input is the output
-            rq.MForm(tmp0.Value[0], c00)
-            rq.MForm(tmp0.Value[1], c01)
+            if op0 is op1 or not self.fused_tensor:
+                rq.MForm(tmp0.Value[0], c00)
+                rq.MForm(tmp0.Value[1], c01)
             if op0 is op1:                                                  # squaring
                 rq.MulCoeffsMontgomery(c00, tmp1.Value[0], c0)
                 rq.MulCoeffsMontgomery(c01, tmp1.Value[1], c2)
                 rq.MulCoeffsMontgomery(c00, tmp1.Value[1], c1)
                 rq.Add(c1, c1, c1)
+            elif self.fused_tensor:                                         # the same six ring calls as one kernel
+                rq.TensorDegree1(tmp0.Value[0], tmp0.Value[1], tmp1.Value[0], tmp1.Value[1], c0, c1, c2)
             else:
                 rq.MulCoeffsMontgomery(c00, tmp1.Value[0], c0)
                 rq.MulCoeffsMontgomery(c01, tmp1.Value[1], c2)

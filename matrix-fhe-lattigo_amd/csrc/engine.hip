@@ -726,6 +726,48 @@ int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3,
   return check_launch("vec_op");
 }
 
+// Degree-1 x degree-1 tensoring of ckks mulRelin (schemes/ckks/evaluator.go:821-834) in one pass: the six ring calls
+//   c00 = MForm(a0); c01 = MForm(a1); c0 = MulCoeffsMontgomery(c00, b0); c2 = MulCoeffsMontgomery(c01, b1);
+//   c1 = MulCoeffsMontgomery(c00, b1); c1 = MulCoeffsMontgomeryThenAdd(c01, b0, c1)
+// with the same formulas element by element (7 operands of traffic instead of 23).  Outputs may alias inputs element-wise.
+__global__ void __launch_bounds__(256)
+tensor_degree1_kernel(const u64* a0, const u64* a1, const u64* b0, const u64* b1, u64* c0, u64* c1, u64* c2, unsigned n,
+                      const LimbConsts* __restrict__ consts, int L) {
+  const u32 row = blockIdx.x, limb = row % (u32)L;
+  const LimbConsts c = consts[limb];
+  const size_t ro = (size_t)row * n;
+  for (unsigned i = blockIdx.y * blockDim.x + threadIdx.x; i < (n >> 1); i += gridDim.y * blockDim.x) {
+    const size_t o = ro + 2 * (size_t)i;
+    const ulonglong2 x0 = *reinterpret_cast<const ulonglong2*>(a0 + o), x1 = *reinterpret_cast<const ulonglong2*>(a1 + o);
+    const ulonglong2 y0 = *reinterpret_cast<const ulonglong2*>(b0 + o), y1 = *reinterpret_cast<const ulonglong2*>(b1 + o);
+    ulonglong2 r0, r1, r2;
+    {
+      const u64 m0 = mform(x0.x, c.q, c.bred0, c.bred1), m1 = mform(x1.x, c.q, c.bred0, c.bred1);
+      r0.x = mred(m0, y0.x, c.q, c.qinv); r2.x = mred(m1, y1.x, c.q, c.qinv);
+      r1.x = cred(mred(m0, y1.x, c.q, c.qinv) + mred(m1, y0.x, c.q, c.qinv), c.q);
+    }
+    {
+      const u64 m0 = mform(x0.y, c.q, c.bred0, c.bred1), m1 = mform(x1.y, c.q, c.bred0, c.bred1);
+      r0.y = mred(m0, y0.y, c.q, c.qinv); r2.y = mred(m1, y1.y, c.q, c.qinv);
+      r1.y = cred(mred(m0, y1.y, c.q, c.qinv) + mred(m1, y0.y, c.q, c.qinv), c.q);
+    }
+    *reinterpret_cast<ulonglong2*>(c0 + o) = r0; *reinterpret_cast<ulonglong2*>(c1 + o) = r1; *reinterpret_cast<ulonglong2*>(c2 + o) = r2;
+  }
+}
+extern "C" int rh_ring_tensor_degree1(rh_ring* r, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0, const uint64_t* b1,
+                                      uint64_t* c0, uint64_t* c1, uint64_t* c2, int npoly, int level) {
+  if (!r || !a0 || !a1 || !b0 || !b1 || !c0 || !c1 || !c2) return rh_fail(RH_ERR_ARG, "tensor_degree1: null argument");
+  if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "tensor_degree1: level %d out of range [0,%d)", level, r->L);
+  if (npoly < 0) return rh_fail(RH_ERR_ARG, "tensor_degree1: npoly < 0");
+  const unsigned rows = (unsigned)npoly * (unsigned)(level + 1), n = (unsigned)r->N;
+  if (rows == 0) return RH_OK;
+  (void)hipSetDevice(r->device);
+  (void)hipGetLastError();
+  unsigned chunks = (n / 2 + 1023) / 1024; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
+  tensor_degree1_kernel<<<dim3(rows, chunks), 256, 0, r->stream>>>(a0, a1, b0, b1, c0, c1, c2, n, r->d_consts, level + 1);
+  return check_launch("tensor_degree1");
+}
+
 extern "C" int rh_ring_vec_op(rh_ring* r, int opcode, const uint64_t* p1, const uint64_t* p2, uint64_t* p3, int npoly, int level,
                               const uint64_t* s0, const uint64_t* s1) {
   if (!r || !p3) return rh_fail(RH_ERR_ARG, "vec_op: null argument");

@@ -52,6 +52,12 @@ def test_mul_relin_rescale_chain(rh, oracle, N, nq, np_):
     for k in range(B):
         for c in range(3):
             assert np.array_equal(got2[c][k], exp[k][c])
+    ev.fused_tensor = False                                       # the six separate ring calls give the same bits
+    out2b = rh.Ciphertext([rq.NewPoly(B) for _ in range(3)], is_ntt=True)
+    ev.MulRelin(ct0, ct1, out2b, relin=False)
+    for c in range(3):
+        assert np.array_equal(out2b.Value[c].numpy(), got2[c])
+    ev.fused_tensor = True
     # with relinearisation, then rescale
     out = rh.Ciphertext([rq.NewPoly(B), rq.NewPoly(B)], is_ntt=True)
     ev.MulRelin(ct0, ct1, out, relin=True)

@@ -92,6 +92,24 @@ e = entry("config5 GadgetProduct N=2^16 Q=24 P=6 beta=4 (per ciphertext componen
           16.0 * N * limb_ntts * B + 2.0 * beta * 30 * 8 * N, B, "keyswitch")
 e["limb_ntt_equivalents_per_keyswitch"] = limb_ntts
 res.append(e)
+# CKKS ct x ct multiply with relinearisation, then rescale (schemes/ckks/evaluator.go:786-881, 500-535) at the config 5 parameters
+gct = rh.rlwe.GadgetCiphertext.__new__(rh.rlwe.GadgetCiphertext)
+gct.digits, gct.levelQ, gct.levelP = beta, 23, 5
+gct.Q, gct.P = rh.DevicePoly.from_torch(rq, evq), rh.DevicePoly.from_torch(rp, evp)
+cev = rh.ckks.Evaluator(rq, rp, rlk=gct)
+mk = lambda: rh.DevicePoly.from_torch(rq, rand_block(B, QI60[:24], N))
+ctA, ctB = rh.Ciphertext([mk(), mk()], is_ntt=True), rh.Ciphertext([mk(), mk()], is_ntt=True)
+ctO, ctR = rh.Ciphertext([mk(), mk()], is_ntt=True), rh.Ciphertext([mk(), mk()], is_ntt=True)
+def mulrelin_rescale():
+    cev.MulRelin(ctA, ctB, ctO, relin=True)
+    cev.Rescale(ctO, ctR)
+ms = timed(mulrelin_rescale, reps=3, warm=1)
+e = entry("CKKS MulRelin + Rescale N=2^16 Q=24 P=6 (tensor, key switch, 2 adds, rescale of both components; batch %d)" % B, ms,
+          0.0, B, "ctmul")
+e.pop("algorithmic_GBps"); e.pop("frac_of_8TBps")
+res.append(e)
+del ctA, ctB, ctO, ctR, gct
+cev.close()
 del pq, pp, poq, pop, xq, xp, oq, op_, p0, p1, c0, c1, evq, evp
 be.close(); rq.close(); rp.close(); torch.cuda.empty_cache()
 
