@@ -220,6 +220,20 @@ func (k *KeySwitcher) GadgetProduct(levelQ, levelP int, cx, evkQ, evkP *DevPoly,
 	k.q.must(C.rh_bext_gadget_product(k.be, C.int(levelQ), C.int(levelP), cx.ptr, evkQ.ptr, evkP.ptr, C.int(beta), ct0.ptr, ct1.ptr, C.int(cx.npoly)))
 }
 
+// GadgetProductThenAdd: ct_c = add_c + GadgetProduct(cx)_c, the ring.Add of Relinearize / mulRelin / Automorphism folded
+// into ModDown's epilogue (add0 / add1 may be nil and may be ct0 / ct1 themselves).
+func (k *KeySwitcher) GadgetProductThenAdd(levelQ, levelP int, cx, evkQ, evkP *DevPoly, beta int, add0, add1, ct0, ct1 *DevPoly) {
+	var a0, a1 *C.uint64_t
+	if add0 != nil {
+		a0 = add0.ptr
+	}
+	if add1 != nil {
+		a1 = add1.ptr
+	}
+	k.q.must(C.rh_bext_gadget_product_then_add(k.be, C.int(levelQ), C.int(levelP), cx.ptr, evkQ.ptr, evkP.ptr, C.int(beta), a0, a1,
+		ct0.ptr, ct1.ptr, C.int(cx.npoly)))
+}
+
 // DecomposeNTT / GadgetProductHoisted mirror the hoisted pair (:431-453, :326-349): one decomposition, many rotations.
 func (k *KeySwitcher) DecomposeNTT(levelQ, levelP int, c2 *DevPoly, c2IsNTT bool, decompQ, decompP *DevPoly) {
 	isNTT := C.int(0)

@@ -159,6 +159,13 @@ int rh_bext_decompose_and_split(rh_bext* be, int levelQ, int levelP, int nbPi, i
 int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const uint64_t* cx_dev, const uint64_t* evkQ_dev,
                            const uint64_t* evkP_dev, int beta_key, uint64_t* ct0_dev, uint64_t* ct1_dev, int npoly);
 
+/* The same with the ring.Add that follows it in Relinearize (core/rlwe/evaluator_evaluationkey.go:144-146), mulRelin
+ * (schemes/ckks/evaluator.go:850-852), applyEvaluationKey (:105-112) and Automorphism (evaluator_automorphism.go:42-44):
+ * ct_c = add_c + product_c, canonical.  add0 / add1 may be NULL and may alias ct0 / ct1. */
+int rh_bext_gadget_product_then_add(rh_bext* be, int levelQ, int levelP, const uint64_t* cx_dev, const uint64_t* evkQ_dev,
+                                    const uint64_t* evkP_dev, int beta_key, const uint64_t* add0_dev, const uint64_t* add1_dev,
+                                    uint64_t* ct0_dev, uint64_t* ct1_dev, int npoly);
+
 /* Hoisted form (rotations of one ciphertext share the decomposition).  Evaluator.DecomposeNTT
  * (core/rlwe/evaluator_gadget_product.go:431-453): c2 (levelQ+1 limbs, NTT or coefficient domain per c2_is_ntt) ->
  * decompQ [beta][npoly][levelQ+1][N], decompP [beta][npoly][levelP+1][N], NTT domain, beta = BaseRNSDecompositionVectorSize. */

@@ -159,6 +159,13 @@ class BasisExtender {
   void GadgetProduct(int lq, int lp, const Poly& cx, const Poly& evkQ, const Poly& evkP, int beta, Poly& ct0, Poly& ct1) const {
     check(rh_bext_gadget_product(h_.get(), lq, lp, cx.data(), evkQ.data(), evkP.data(), beta, ct0.data(), ct1.data(), cx.npoly()));
   }
+  // ct_c = add_c + GadgetProduct(cx)_c: the ring.Add that follows the product in Relinearize / mulRelin / Automorphism,
+  // folded into ModDown's epilogue (add0 / add1 may be null and may alias ct0 / ct1)
+  void GadgetProductThenAdd(int lq, int lp, const Poly& cx, const Poly& evkQ, const Poly& evkP, int beta, const Poly* add0, const Poly* add1,
+                            Poly& ct0, Poly& ct1) const {
+    check(rh_bext_gadget_product_then_add(h_.get(), lq, lp, cx.data(), evkQ.data(), evkP.data(), beta, add0 ? add0->data() : nullptr,
+                                          add1 ? add1->data() : nullptr, ct0.data(), ct1.data(), cx.npoly()));
+  }
   // Evaluator.DecomposeNTT / GadgetProductHoisted (core/rlwe/evaluator_gadget_product.go:431-453, 326-429): decompQ / decompP
   // hold beta * npoly polys (digit i of poly k = poly i*npoly + k)
   void DecomposeNTT(int lq, int lp, const Poly& c2, bool c2IsNTT, Poly& decompQ, Poly& decompP) const {

@@ -66,10 +66,7 @@ class Evaluator:
             if relin:
                 if self.rlk is None or self.ks is None:
                     raise RingHipError("cannot MulRelin: Relinearize: relinearization key is missing")
-                tmp = Ciphertext([new(), new()], is_ntt=True)
-                self.ks.GadgetProduct(level, c2, self.rlk, tmp)
-                rq.Add(c0, tmp.Value[0], opOut.Value[0])
-                rq.Add(c1, tmp.Value[1], opOut.Value[1])
+                self.ks.GadgetProductThenAdd(level, c2, self.rlk, c0, c1, opOut)      # GadgetProduct + the two Adds (:850-852)
         elif d0 + d1 == 1 or (d0 == 0 and d1 == 0):
             pt, ct = (op0, op1) if d0 == 0 else (op1, op0)
             if opOut.Degree() != max(d0, d1):

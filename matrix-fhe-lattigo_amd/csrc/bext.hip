@@ -172,7 +172,7 @@ bext_sign_copy_kernel(const u64* in, int in_rows, int src_limb, u64 qd, int ntgt
 struct rh_bext {
   rh_ring* Q = nullptr; rh_ring* P = nullptr;
   std::map<std::array<int, 5>, BextPlan> plans;
-  u64* buf[7] = {}; size_t buf_words[7] = {};      // 0,1: ModDownNTT buffers; 2..6: gadget product (keyswitch.hip)
+  u64* buf[9] = {}; size_t buf_words[9] = {};      // 0,1: ModDownNTT buffers; 2..8: gadget product (keyswitch.hip)
 };
 
 template <class T>
@@ -239,7 +239,7 @@ extern "C" void rh_bext_destroy(rh_bext* be) {
     void* ptrs[] = {p.d_S, p.d_T, p.d_coef, p.d_vt, p.d_sign};
     for (void* q : ptrs) if (q) (void)hipFree(q);
   }
-  for (int i = 0; i < 7; ++i) if (be->buf[i]) (void)hipFree(be->buf[i]);
+  for (int i = 0; i < 9; ++i) if (be->buf[i]) (void)hipFree(be->buf[i]);
   delete be;
 }
 
@@ -336,6 +336,9 @@ extern "C" int rh_bext_moddown_qp_to_p(rh_bext* be, int levelQ, int levelP, cons
 
 // ModDownQPtoQNTT (:241-258): INTTLazy on P, ModUpPtoQ, NTTLazy on Q, fused subtract-multiply
 extern "C" int rh_bext_moddown_qp_to_q_ntt(rh_bext* be, int levelQ, int levelP, const uint64_t* p1Q, const uint64_t* p1P, uint64_t* p2Q, int npoly) {
+  return rh_bext_moddown_ntt_add(be, levelQ, levelP, p1Q, p1P, p2Q, npoly, nullptr);
+}
+int rh_bext_moddown_ntt_add(rh_bext* be, int levelQ, int levelP, const u64* p1Q, const u64* p1P, u64* p2Q, int npoly, const u64* addend) {
   if (int rc = check_levels(be, levelQ, levelP, true)) return rc;
   if (be->Q->kind != RH_RING_STANDARD || be->P->kind != RH_RING_STANDARD) return rh_fail(RH_ERR_UNSUPPORTED, "ModDownQPtoQNTT needs standard rings");
   const size_t N = be->Q->N;
@@ -351,9 +354,12 @@ extern "C" int rh_bext_moddown_qp_to_q_ntt(rh_bext* be, int levelQ, int levelP, 
   std::vector<u64> Ps(be->P->moduli.begin(), be->P->moduli.begin() + levelP + 1);
   for (int i = 0; i <= levelQ; ++i) sc[i] = be->Q->moduli[i] - moddown_const(Ps, be->Q->moduli[i]);
   if (rh_can_fuse_submul(be->Q))                 // the subtract-multiply rides in the forward tile kernel's epilogue
-    return rh_std_ntt_submul_launch(be->Q, buffQ, npoly, levelQ + 1, 0, p1Q, levelQ + 1, p2Q, levelQ + 1, sc.data());
+    return rh_std_ntt_submul_launch(be->Q, buffQ, npoly, levelQ + 1, 0, p1Q, levelQ + 1, p2Q, levelQ + 1, sc.data(), false, addend, levelQ + 1);
   if (int rc = rh_std_ntt_launch(be->Q, buffQ, buffQ, npoly, levelQ + 1, 0, false, false, 0)) return rc;
-  return rh_vec_launch(be->Q, RH_OP_SUB_THEN_MUL_SCALAR_MONT_TWO_MODULUS, buffQ, p1Q, p2Q, npoly, levelQ + 1, 0, sc.data(), nullptr);
+  if (!addend) return rh_vec_launch(be->Q, RH_OP_SUB_THEN_MUL_SCALAR_MONT_TWO_MODULUS, buffQ, p1Q, p2Q, npoly, levelQ + 1, 0, sc.data(), nullptr);
+  // the output may be the addend's own buffer: finish in the scratch, add last
+  if (int rc = rh_vec_launch(be->Q, RH_OP_SUB_THEN_MUL_SCALAR_MONT_TWO_MODULUS, buffQ, p1Q, buffQ, npoly, levelQ + 1, 0, sc.data(), nullptr)) return rc;
+  return rh_vec_launch(be->Q, RH_OP_ADD, buffQ, addend, p2Q, npoly, levelQ + 1, 0, nullptr, nullptr);
 }
 
 // DecomposeAndSplit (:381-502)

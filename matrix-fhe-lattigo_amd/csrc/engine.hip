@@ -557,7 +557,7 @@ int rh_std_ntt_expand_cols_launch(rh_ring* r, const u64* tmp, u64* buf, int npol
 }
 
 int rh_std_ntt_submul_launch(rh_ring* r, u64* buf, int npoly, int Lrows, int limb0, const u64* y, int y_rows, u64* out, int out_rows,
-                             const u64* scalars_host, bool cols_done) {
+                             const u64* scalars_host, bool cols_done, const u64* z, int z_rows) {
   static_assert(RH_MAX_LIMBS_K == RH_MAX_LIMBS, "limb bound mismatch");
   if (!rh_can_fuse_submul(r)) return rh_fail(RH_ERR_UNSUPPORTED, "fused subtract-multiply needs a standard ring with N >= 4096");
   const unsigned rows = (unsigned)npoly * (unsigned)Lrows;
@@ -568,7 +568,7 @@ int rh_std_ntt_submul_launch(rh_ring* r, u64* buf, int npoly, int Lrows, int lim
   LimbScalars sc; memset(&sc, 0, sizeof(sc)); memcpy(sc.s, scalars_host, (size_t)Lrows * 8);
   const size_t toff = (size_t)limb0 * r->N;
   ntt_fwd_tile_submul<<<rows << S1, 256, 0, r->stream>>>(buf, r->d_twk_fwd + toff, r->d_consts + limb0, Lrows, r->logN, npoly, y, y_rows,
-                                                         out, out_rows, sc);
+                                                         out, out_rows, sc, z, z_rows);
   return check_launch("ntt_fwd_tile_submul");
 }
 

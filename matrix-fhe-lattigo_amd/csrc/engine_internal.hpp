@@ -60,7 +60,7 @@ int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows,
 int rh_std_ntt_fwd_strided(rh_ring* r, u64* data, int npoly, int Lrows, int limb0, int Ls);
 bool rh_can_fuse_submul(const rh_ring* r);
 int rh_std_ntt_submul_launch(rh_ring* r, u64* buf, int npoly, int Lrows, int limb0, const u64* y, int y_rows, u64* out, int out_rows,
-                             const u64* scalars_host, bool cols_done = false);
+                             const u64* scalars_host, bool cols_done = false, const u64* z = nullptr, int z_rows = 0);
 int rh_std_ntt_expand_cols_launch(rh_ring* r, const u64* tmp, u64* buf, int npoly, int Lrows, const void* table_dev, int mode, u64 qL);
 int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3, int npoly, int Lrows, int limb0,
                   const u64* s0, const u64* s1);
@@ -78,3 +78,5 @@ struct rh_bext;
 rh_ring* rh_bext_ringQ(rh_bext* be);
 rh_ring* rh_bext_ringP(rh_bext* be);
 int rh_bext_scratch(rh_bext* be, int which, size_t words, u64** out);
+// ModDownQPtoQNTT with an optional addend: p2Q = [addend +] (p1Q - ext(p1P)) / P   (addend: the ring.Add that follows a key switch)
+int rh_bext_moddown_ntt_add(rh_bext* be, int levelQ, int levelP, const u64* p1Q, const u64* p1P, u64* p2Q, int npoly, const u64* addend);

@@ -157,7 +157,11 @@ extern "C" int rh_bext_decompose_ntt(rh_bext* be, int levelQ, int levelP, const 
 // Evaluator.GadgetProductHoisted (:326-349) = gadgetProductMultiplePLazyHoisted (:373-429) + ModDown NTT->NTT (:33-46).
 // cx != null (internal, direct product): the digits' own limbs of decompQ were not filled; the multiply-accumulate reads them from cx.
 static int hoisted_tail(rh_bext* be, int levelQ, int levelP, const uint64_t* decompQ, const uint64_t* decompP, const uint64_t* evkQ,
-                        const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly, const uint64_t* cx) {
+                        const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly, const uint64_t* cx,
+                        const uint64_t* add0 = nullptr, const uint64_t* add1 = nullptr, uint64_t* out0 = nullptr, uint64_t* out1 = nullptr) {
+  // ct0 / ct1 hold the Q-part accumulators; results go to out_c (default: ct_c itself) as [add_c +] ModDown(ct_c, P part)
+  if (!out0) out0 = ct0;
+  if (!out1) out1 = ct1;
   if (!decompQ || !decompP || !evkQ || !evkP || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "gadget_product_hoisted: null argument");
   int beta; if (int rc = ks_check(be, levelQ, levelP, beta_key, "gadget_product_hoisted", &beta)) return rc;
   if (npoly <= 0) return RH_OK;
@@ -171,16 +175,16 @@ static int hoisted_tail(rh_bext* be, int levelQ, int levelP, const uint64_t* dec
   ReduceSchedule rs(RQ, levelQ, RP, levelP);
   if (int rc = mac_all(RQ, decompQ, wq, evkQ, beta, rs.QiOverF, ct0, ct1, npoly, LQ, cx, LP)) return rc;
   if (int rc = mac_all(RP, decompP, wp, evkP, beta, rs.PiOverF, aP0, aP1, npoly, LP)) return rc;
-  if (int rc = rh_bext_moddown_qp_to_q_ntt(be, levelQ, levelP, ct0, aP0, ct0, npoly)) return rc;
-  return rh_bext_moddown_qp_to_q_ntt(be, levelQ, levelP, ct1, aP1, ct1, npoly);
+  if (int rc = rh_bext_moddown_ntt_add(be, levelQ, levelP, ct0, aP0, out0, npoly, add0)) return rc;
+  return rh_bext_moddown_ntt_add(be, levelQ, levelP, ct1, aP1, out1, npoly, add1);
 }
 extern "C" int rh_bext_gadget_product_hoisted(rh_bext* be, int levelQ, int levelP, const uint64_t* decompQ, const uint64_t* decompP,
                                               const uint64_t* evkQ, const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly) {
   return hoisted_tail(be, levelQ, levelP, decompQ, decompP, evkQ, evkP, beta_key, ct0, ct1, npoly, nullptr);
 }
 
-extern "C" int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, const uint64_t* evkQ,
-                                      const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly) {
+static int gadget_product_impl(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, const uint64_t* evkQ, const uint64_t* evkP,
+                               int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly, const uint64_t* add0, const uint64_t* add1) {
   if (!cx || !evkQ || !evkP || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "gadget_product: null argument");
   int beta; if (int rc = ks_check(be, levelQ, levelP, beta_key, "gadget_product", &beta)) return rc;
   if (npoly <= 0) return RH_OK;
@@ -198,5 +202,21 @@ extern "C" int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const
   if (int rc = rh_std_ntt_launch(RQ, cx, cxInv, npoly, LQ, 0, true, false, 0)) return rc;                  // ringQ.INTT(cxNTT, cxInvNTT) (:138)
   for (int i = 0; i < beta; ++i)
     if (int rc = decompose_single_ntt(be, levelQ, levelP, i, cx, cxInv, decQ + (size_t)i * wq, decP + (size_t)i * wp, npoly, false)) return rc;
-  return hoisted_tail(be, levelQ, levelP, decQ, decP, evkQ, evkP, beta_key, ct0, ct1, npoly, cx);
+  if (!add0 && !add1) return hoisted_tail(be, levelQ, levelP, decQ, decP, evkQ, evkP, beta_key, ct0, ct1, npoly, cx);
+  u64 *acc0, *acc1;                                  // accumulate beside the outputs: they may alias the addends (or cx)
+  if (int rc = rh_bext_scratch(be, 7, wq, &acc0)) return rc;
+  if (int rc = rh_bext_scratch(be, 8, wq, &acc1)) return rc;
+  return hoisted_tail(be, levelQ, levelP, decQ, decP, evkQ, evkP, beta_key, acc0, acc1, npoly, cx, add0, add1, ct0, ct1);
+}
+extern "C" int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, const uint64_t* evkQ,
+                                      const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly) {
+  return gadget_product_impl(be, levelQ, levelP, cx, evkQ, evkP, beta_key, ct0, ct1, npoly, nullptr, nullptr);
+}
+// ct_c = add_c + GadgetProduct(cx)_c (ring.Add, canonical): the Add that follows the product in Relinearize / mulRelin /
+// applyEvaluationKey / Automorphism rides in ModDown's tile epilogue.  add0 / add1 may be NULL (no addend for that component)
+// and may alias ct0 / ct1 (the accumulation happens in scratch; outputs are written last).
+extern "C" int rh_bext_gadget_product_then_add(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, const uint64_t* evkQ,
+                                               const uint64_t* evkP, int beta_key, const uint64_t* add0, const uint64_t* add1,
+                                               uint64_t* ct0, uint64_t* ct1, int npoly) {
+  return gadget_product_impl(be, levelQ, levelP, cx, evkQ, evkP, beta_key, ct0, ct1, npoly, add0, add1);
 }

@@ -172,7 +172,7 @@ ntt_fwd_tile(const u64* in, u64* out, const typename P::tw_t* __restrict__ twk,
 struct LimbScalars { u64 s[RH_MAX_LIMBS_K]; };
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // <= 128 VGPRs: 4 workgroups per CU like the asm body
 ntt_fwd_tile_submul(const u64* in, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts, int L, int logN, int npoly,
-                    const u64* y, int y_rows, u64* out, int out_rows, LimbScalars sc) {
+                    const u64* y, int y_rows, u64* out, int out_rows, LimbScalars sc, const u64* z, int z_rows) {   // z != null: out = CRed(... + z) (the ring.Add that follows a key switch)
   __shared__ u64 lds[LDS_WORDS];
   const int tid = threadIdx.x;
   const u32 b = blockIdx.x;
@@ -208,10 +208,13 @@ ntt_fwd_tile_submul(const u64* in, const tw2* __restrict__ twk, const LimbConsts
   const size_t yb = (((size_t)poly * y_rows + limb) << logN) + ((size_t)tile << LT);
   const size_t ob = (((size_t)poly * out_rows + limb) << logN) + ((size_t)tile << LT);
   const u64 sl = sc.s[limb], q2 = 2 * c.q;
+  const size_t zb = (((size_t)poly * z_rows + limb) << logN) + ((size_t)tile << LT);
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const u64 v = lds[LDS_PAD(tid + 256 * k)];
-    out[ob + tid + 256 * k] = mred(q2 - y[yb + tid + 256 * k] + v, sl, c.q, c.qinv);
+    u64 rr = mred(q2 - y[yb + tid + 256 * k] + v, sl, c.q, c.qinv);
+    if (z) rr = cred(rr + z[zb + tid + 256 * k], c.q);
+    out[ob + tid + 256 * k] = rr;
   }
 }
 

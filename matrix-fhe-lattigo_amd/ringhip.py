@@ -101,6 +101,7 @@ def lib():
         "rh_bext_moddown_qp_to_p": (i, [vp, i, i, vp, vp, vp, i]),
         "rh_bext_decompose_and_split": (i, [vp, i, i, i, i, vp, vp, vp, i]),
         "rh_bext_gadget_product": (i, [vp, i, i, vp, vp, vp, i, vp, vp, i]),
+        "rh_bext_gadget_product_then_add": (i, [vp, i, i, vp, vp, vp, i, vp, vp, vp, vp, i]),
         "rh_bext_decompose_ntt": (i, [vp, i, i, vp, i, vp, vp, i]),
         "rh_bext_gadget_product_hoisted": (i, [vp, i, i, vp, vp, vp, vp, i, vp, vp, i]),
         "rh_kshard_create": (i, [C.POINTER(vp), vp, vp, U64P, i, U64P, i, C.POINTER(i), i, C.POINTER(i), i]),

@@ -56,6 +56,14 @@ class Evaluator:
         _check(lib().rh_bext_gadget_product(self.be._h, levelQ, gadgetCt.LevelP(), cx.ptr, gadgetCt.Q.ptr, gadgetCt.P.ptr,
                                             gadgetCt.digits, ct.Value[0].ptr, ct.Value[1].ptr, cx.npoly))
 
+    def GadgetProductThenAdd(self, levelQ, cx, gadgetCt, add0, add1, ct):
+        """ct[c] = add_c + GadgetProduct(cx)[c] (ring.Add, canonical) -- the Add the callers below issue right after the
+        product, folded into ModDown's tile epilogue.  add0 / add1: DevicePoly or None; they may be ct.Value[c] themselves."""
+        levelQ = min(levelQ, gadgetCt.LevelQ())
+        _check(lib().rh_bext_gadget_product_then_add(self.be._h, levelQ, gadgetCt.LevelP(), cx.ptr, gadgetCt.Q.ptr, gadgetCt.P.ptr,
+                                                     gadgetCt.digits, add0.ptr if add0 is not None else None,
+                                                     add1.ptr if add1 is not None else None, ct.Value[0].ptr, ct.Value[1].ptr, cx.npoly))
+
     def BaseRNSDecompositionVectorSize(self, levelQ, levelP):
         return (levelQ + levelP + 1) // (levelP + 1)                  # core/rlwe/params.go:635-642
 
@@ -85,9 +93,7 @@ class Evaluator:
         level = min(ctIn.Level(), opOut.Level())
         ringQ = self.ringQ.AtLevel(level)
         npoly = ctIn.Value[1].npoly
-        tmp = Ciphertext([DevicePoly(ringQ, npoly, level + 1), opOut.Value[1]], is_ntt=True)   # component 1 lands in opOut directly
-        self.GadgetProduct(level, ctIn.Value[1], evk, tmp)
-        ringQ.Add(ctIn.Value[0], tmp.Value[0], opOut.Value[0])
+        self.GadgetProductThenAdd(level, ctIn.Value[1], evk, ctIn.Value[0], None, opOut)   # (:108-111) with the Add in the epilogue
         opOut.IsNTT = True
 
     def Relinearize(self, ctIn, opOut, rlk=None):
@@ -102,10 +108,7 @@ class Evaluator:
         level = min(ctIn.Level(), opOut.Level())
         ringQ = self.ringQ.AtLevel(level)
         npoly = ctIn.Value[2].npoly
-        tmp = Ciphertext([DevicePoly(ringQ, npoly, level + 1), DevicePoly(ringQ, npoly, level + 1)], is_ntt=True)
-        self.GadgetProduct(level, ctIn.Value[2], rlk, tmp)
-        ringQ.Add(ctIn.Value[0], tmp.Value[0], opOut.Value[0])
-        ringQ.Add(ctIn.Value[1], tmp.Value[1], opOut.Value[1])
+        self.GadgetProductThenAdd(level, ctIn.Value[2], rlk, ctIn.Value[0], ctIn.Value[1], opOut)   # (:144-146)
         opOut.IsNTT = True
 
     # ---- core/rlwe/evaluator_automorphism.go -----------------------------------------------------------------
@@ -139,8 +142,9 @@ class Evaluator:
         evk = self._galois_key(galEl)
         npoly = ctIn.Value[1].npoly
         tmp = Ciphertext([DevicePoly(ringQ, npoly, level + 1), DevicePoly(ringQ, npoly, level + 1)], is_ntt=True)
-        self.GadgetProduct(level, ctIn.Value[1], evk, tmp)
-        self._finish(ringQ, ctIn, tmp, galEl, opOut)
+        self.GadgetProductThenAdd(level, ctIn.Value[1], evk, ctIn.Value[0], None, tmp)         # product + ringQ.Add (:42-44)
+        ringQ.AutomorphismNTT(tmp.Value[0], galEl, opOut.Value[0])   # AutomorphismNTTWithIndex (ring/automorphism.go:52-73)
+        ringQ.AutomorphismNTT(tmp.Value[1], galEl, opOut.Value[1])
         opOut.IsNTT = ctIn.IsNTT
 
     def AutomorphismHoisted(self, level, ctIn, c1DecompQP, galEl, opOut):
