@@ -191,7 +191,7 @@ func (d *DeviceRing) DivRoundByLastModulusManyNTT(nbRescales int, p0, p1 *DevPol
 
 // TensorDegree1 runs the degree-1 x degree-1 tensoring of ckks mulRelin (schemes/ckks/evaluator.go:821-834) as one kernel.
 func (d *DeviceRing) TensorDegree1(a0, a1, b0, b1, c0, c1, c2 *DevPoly) {
-	d.must(C.rh_ring_tensor_degree1(d.h, a0.ptr, a1.ptr, b0.ptr, b1.ptr, c0.ptr, c1.ptr, c2.ptr, C.int(a0.npoly), C.int(a0.limbs-1)))
+	d.must(C.rh_ring_tensor_degree1(d.h, a0.ptr, a1.ptr, b0.ptr, b1.ptr, c0.ptr, c1.ptr, c2.ptr, C.int(a0.npoly), C.int(a0.limbs-1), 1))
 }
 
 // AutomorphismNTT mirrors ring.Ring.AutomorphismNTT (ring/automorphism.go:52-73).

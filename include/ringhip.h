@@ -120,11 +120,12 @@ int rh_ring_vec_op(rh_ring* r, int opcode, const uint64_t* p1_dev, const uint64_
 int rh_ring_div_by_last_modulus_many(rh_ring* r, int round, int level, int nb, uint64_t* p0_dev, uint64_t* p1_dev, int p1_rows, int npoly);
 int rh_ring_div_by_last_modulus_many_ntt(rh_ring* r, int round, int level, int nb, const uint64_t* p0_dev, uint64_t* p1_dev, int p1_rows, int npoly);
 
-/* Degree-1 x degree-1 tensoring of ckks mulRelin (schemes/ckks/evaluator.go:821-834) in one pass:
+/* Degree-1 x degree-1 tensoring in one pass.  mform_first = 1: ckks mulRelin (schemes/ckks/evaluator.go:821-834),
  * c0 = MRed(MForm(a0), b0), c1 = CRed(MRed(MForm(a0), b1) + MRed(MForm(a1), b0)), c2 = MRed(MForm(a1), b1) -- the values the six
- * ring calls of the reference produce.  All blocks: npoly polys of level+1 limbs, NTT domain. */
+ * ring calls of the reference produce.  mform_first = 0: matrix_ckks.Evaluator.Mul (schemes/matrix_ckks/evaluator.go:166-173),
+ * the same without the MForm (its four ring calls).  All blocks: npoly polys of level+1 limbs, NTT domain; any ring kind. */
 int rh_ring_tensor_degree1(rh_ring* r, const uint64_t* a0_dev, const uint64_t* a1_dev, const uint64_t* b0_dev, const uint64_t* b1_dev,
-                           uint64_t* c0_dev, uint64_t* c1_dev, uint64_t* c2_dev, int npoly, int level);
+                           uint64_t* c0_dev, uint64_t* c1_dev, uint64_t* c2_dev, int npoly, int level, int mform_first);
 
 /* ---- Galois automorphisms X -> X^gen (ring/automorphism.go), power-of-two rings, never in place.
  *   rh_ring_automorphism_ntt: AutomorphismNTT (:39-47) / AutomorphismNTTWithIndex (:52-81); add_lazy != 0:

@@ -117,8 +117,8 @@ class Ring {
   }
   // ring/automorphism.go
   // ckks mulRelin's degree-1 x degree-1 tensoring as one kernel (schemes/ckks/evaluator.go:821-834)
-  void TensorDegree1(const Poly& a0, const Poly& a1, const Poly& b0, const Poly& b1, Poly& c0, Poly& c1, Poly& c2) const {
-    check(rh_ring_tensor_degree1(h_.get(), a0.data(), a1.data(), b0.data(), b1.data(), c0.data(), c1.data(), c2.data(), a0.npoly(), level_));
+  void TensorDegree1(const Poly& a0, const Poly& a1, const Poly& b0, const Poly& b1, Poly& c0, Poly& c1, Poly& c2, bool mformFirst = true) const {
+    check(rh_ring_tensor_degree1(h_.get(), a0.data(), a1.data(), b0.data(), b1.data(), c0.data(), c1.data(), c2.data(), a0.npoly(), level_, mformFirst ? 1 : 0));
   }
   void AutomorphismNTT(const Poly& in, uint64_t gen, Poly& out) const { check(rh_ring_automorphism_ntt(h_.get(), level_, in.data(), gen, out.data(), in.npoly(), 0)); }
   void Automorphism(const Poly& in, uint64_t gen, Poly& out) const { check(rh_ring_automorphism(h_.get(), level_, in.data(), gen, out.data(), in.npoly())); }

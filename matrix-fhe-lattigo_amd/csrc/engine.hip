@@ -732,7 +732,7 @@ int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3,
 // with the same formulas element by element (7 operands of traffic instead of 23).  Outputs may alias inputs element-wise.
 __global__ void __launch_bounds__(256)
 tensor_degree1_kernel(const u64* a0, const u64* a1, const u64* b0, const u64* b1, u64* c0, u64* c1, u64* c2, unsigned n,
-                      const LimbConsts* __restrict__ consts, int L) {
+                      const LimbConsts* __restrict__ consts, int L, int mform_first) {   // 0: no MForm (matrix_ckks.Evaluator.Mul, evaluator.go:166-173)
   const u32 row = blockIdx.x, limb = row % (u32)L;
   const LimbConsts c = consts[limb];
   const size_t ro = (size_t)row * n;
@@ -742,12 +742,12 @@ tensor_degree1_kernel(const u64* a0, const u64* a1, const u64* b0, const u64* b1
     const ulonglong2 y0 = *reinterpret_cast<const ulonglong2*>(b0 + o), y1 = *reinterpret_cast<const ulonglong2*>(b1 + o);
     ulonglong2 r0, r1, r2;
     {
-      const u64 m0 = mform(x0.x, c.q, c.bred0, c.bred1), m1 = mform(x1.x, c.q, c.bred0, c.bred1);
+      const u64 m0 = mform_first ? mform(x0.x, c.q, c.bred0, c.bred1) : x0.x, m1 = mform_first ? mform(x1.x, c.q, c.bred0, c.bred1) : x1.x;
       r0.x = mred(m0, y0.x, c.q, c.qinv); r2.x = mred(m1, y1.x, c.q, c.qinv);
       r1.x = cred(mred(m0, y1.x, c.q, c.qinv) + mred(m1, y0.x, c.q, c.qinv), c.q);
     }
     {
-      const u64 m0 = mform(x0.y, c.q, c.bred0, c.bred1), m1 = mform(x1.y, c.q, c.bred0, c.bred1);
+      const u64 m0 = mform_first ? mform(x0.y, c.q, c.bred0, c.bred1) : x0.y, m1 = mform_first ? mform(x1.y, c.q, c.bred0, c.bred1) : x1.y;
       r0.y = mred(m0, y0.y, c.q, c.qinv); r2.y = mred(m1, y1.y, c.q, c.qinv);
       r1.y = cred(mred(m0, y1.y, c.q, c.qinv) + mred(m1, y0.y, c.q, c.qinv), c.q);
     }
@@ -755,7 +755,7 @@ tensor_degree1_kernel(const u64* a0, const u64* a1, const u64* b0, const u64* b1
   }
 }
 extern "C" int rh_ring_tensor_degree1(rh_ring* r, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0, const uint64_t* b1,
-                                      uint64_t* c0, uint64_t* c1, uint64_t* c2, int npoly, int level) {
+                                      uint64_t* c0, uint64_t* c1, uint64_t* c2, int npoly, int level, int mform_first) {
   if (!r || !a0 || !a1 || !b0 || !b1 || !c0 || !c1 || !c2) return rh_fail(RH_ERR_ARG, "tensor_degree1: null argument");
   if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "tensor_degree1: level %d out of range [0,%d)", level, r->L);
   if (npoly < 0) return rh_fail(RH_ERR_ARG, "tensor_degree1: npoly < 0");
@@ -764,7 +764,7 @@ extern "C" int rh_ring_tensor_degree1(rh_ring* r, const uint64_t* a0, const uint
   (void)hipSetDevice(r->device);
   (void)hipGetLastError();
   unsigned chunks = (n / 2 + 1023) / 1024; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
-  tensor_degree1_kernel<<<dim3(rows, chunks), 256, 0, r->stream>>>(a0, a1, b0, b1, c0, c1, c2, n, r->d_consts, level + 1);
+  tensor_degree1_kernel<<<dim3(rows, chunks), 256, 0, r->stream>>>(a0, a1, b0, b1, c0, c1, c2, n, r->d_consts, level + 1, mform_first);
   return check_launch("tensor_degree1");
 }
 

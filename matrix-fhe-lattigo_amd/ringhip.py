@@ -93,7 +93,7 @@ def lib():
         "rh_ring_div_by_last_modulus_many_ntt": (i, [vp, i, i, i, vp, vp, i, i]),
         "rh_ring_automorphism_ntt": (i, [vp, i, vp, C.c_uint64, vp, i, i]),
         "rh_ring_automorphism": (i, [vp, i, vp, C.c_uint64, vp, i]),
-        "rh_ring_tensor_degree1": (i, [vp, vp, vp, vp, vp, vp, vp, vp, i, i]),
+        "rh_ring_tensor_degree1": (i, [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i]),
         "rh_bext_create": (i, [C.POINTER(vp), vp, vp]), "rh_bext_destroy": (None, [vp]),
         "rh_bext_modup_q_to_p": (i, [vp, i, i, vp, vp, i]), "rh_bext_modup_p_to_q": (i, [vp, i, i, vp, vp, i]),
         "rh_bext_moddown_qp_to_q": (i, [vp, i, i, vp, vp, vp, i]),
@@ -301,9 +301,11 @@ class Ring:
         self._chk(p1, p2); _check(lib().rh_ring_intt(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 1))
 
     # ---- automorphisms (ring/automorphism.go) ---------------------------------------------------------------
-    def TensorDegree1(self, a0, a1, b0, b1, c0, c1, c2):
-        """ckks mulRelin's degree-1 x degree-1 tensoring (schemes/ckks/evaluator.go:821-834) as one kernel"""
-        _check(lib().rh_ring_tensor_degree1(self._h, a0.ptr, a1.ptr, b0.ptr, b1.ptr, c0.ptr, c1.ptr, c2.ptr, a0.npoly, self.level))
+    def TensorDegree1(self, a0, a1, b0, b1, c0, c1, c2, mform_first=True):
+        """degree-1 x degree-1 tensoring as one kernel: ckks mulRelin (schemes/ckks/evaluator.go:821-834) with mform_first,
+        matrix_ckks.Evaluator.Mul (schemes/matrix_ckks/evaluator.go:166-173) without"""
+        _check(lib().rh_ring_tensor_degree1(self._h, a0.ptr, a1.ptr, b0.ptr, b1.ptr, c0.ptr, c1.ptr, c2.ptr, a0.npoly, self.level,
+                                            1 if mform_first else 0))
 
     def AutomorphismNTT(self, polIn, gen, polOut):
         _check(lib().rh_ring_automorphism_ntt(self._h, self.level, polIn.ptr, int(gen), polOut.ptr, polIn.npoly, 0))

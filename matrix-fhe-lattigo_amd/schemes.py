@@ -28,6 +28,7 @@ class MatrixCKKSEvaluator:
 
     def __init__(self, ringQ):
         self.ringQ = ringQ
+        self.fused_tensor = True
 
     def Mul(self, ct0, ct1, ctOut):
         """evaluator.go:114-192.  Reproduced as written, including its two side effects: inputs not yet in the NTT
@@ -56,6 +57,8 @@ class MatrixCKKSEvaluator:
         elif d0 == 1 and d1 == 0:
             rq.MulCoeffsMontgomery(a[0], b[0], o[0])
             rq.MulCoeffsMontgomery(a[1], b[0], o[1])
+        elif self.fused_tensor:                      # the four ring calls below as one kernel (same bits)
+            rq.TensorDegree1(a[0], a[1], b[0], b[1], o[0], o[1], o[2], mform_first=False)
         else:
             rq.MulCoeffsMontgomery(a[0], b[0], o[0])
             rq.MulCoeffsMontgomery(a[0], b[1], o[1])

@@ -75,6 +75,12 @@ def test_matrix_ckks_mul_degree1(rh, oracle, N, B):
             e2 = naive_mul_3n(A1, B1, q, N)
             for c, e in enumerate((e0, e1, e2)):
                 assert [int(v) for v in got[c][0, i]] == [(v * rinv) % q for v in e]
+    ev.fused_tensor = False                                      # the four separate ring calls: same bits
+    out1 = rh.Ciphertext([ring.NewPoly(B) for _ in range(3)])
+    ev.Mul(ct0, ct1, out1)
+    for c in range(3):
+        assert np.array_equal(out1.Value[c].numpy(), got[c])
+    ev.fused_tensor = True
     # second call with inputs already in the NTT domain: same result, inputs untouched
     keep = ct0.Value[0].numpy().copy()
     out2 = rh.Ciphertext([ring.NewPoly(B) for _ in range(3)])
