@@ -177,6 +177,11 @@ int rh_bext_gadget_product_hoisted(rh_bext* be, int levelQ, int levelP, const ui
                                    const uint64_t* evkQ_dev, const uint64_t* evkP_dev, int beta_key, uint64_t* ct0_dev,
                                    uint64_t* ct1_dev, int npoly);
 
+/* the same with the ring.Add of AutomorphismHoisted (core/rlwe/evaluator_automorphism.go:88-89): ct_c = add_c + product_c */
+int rh_bext_gadget_product_hoisted_then_add(rh_bext* be, int levelQ, int levelP, const uint64_t* decompQ_dev, const uint64_t* decompP_dev,
+                                            const uint64_t* evkQ_dev, const uint64_t* evkP_dev, int beta_key, const uint64_t* add0_dev,
+                                            const uint64_t* add1_dev, uint64_t* ct0_dev, uint64_t* ct1_dev, int npoly);
+
 /* ---- limb-sharded hybrid key switch (BASELINE config 5): one process per GPU owns a subset of the limbs
  * of Q and P and the matching slice of the evaluation key.  Same arithmetic as rh_bext_gadget_product, cut where
  * reconstructRNS (ring/basis_extension.go:550-594) needs limbs of other owners; the exchange (an all-gather of the

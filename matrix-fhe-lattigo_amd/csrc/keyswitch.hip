@@ -182,6 +182,20 @@ extern "C" int rh_bext_gadget_product_hoisted(rh_bext* be, int levelQ, int level
                                               const uint64_t* evkQ, const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly) {
   return hoisted_tail(be, levelQ, levelP, decompQ, decompP, evkQ, evkP, beta_key, ct0, ct1, npoly, nullptr);
 }
+// hoisted product with the ring.Add that follows it in AutomorphismHoisted (core/rlwe/evaluator_automorphism.go:88-89)
+extern "C" int rh_bext_gadget_product_hoisted_then_add(rh_bext* be, int levelQ, int levelP, const uint64_t* decompQ, const uint64_t* decompP,
+                                                       const uint64_t* evkQ, const uint64_t* evkP, int beta_key, const uint64_t* add0,
+                                                       const uint64_t* add1, uint64_t* ct0, uint64_t* ct1, int npoly) {
+  if (!add0 && !add1) return hoisted_tail(be, levelQ, levelP, decompQ, decompP, evkQ, evkP, beta_key, ct0, ct1, npoly, nullptr);
+  if (!be || npoly <= 0) return npoly == 0 && be ? RH_OK : rh_fail(RH_ERR_ARG, "gadget_product_hoisted_then_add: bad argument");
+  rh_ring* RQ = rh_bext_ringQ(be);
+  if (levelQ < 0 || levelQ >= RQ->L) return rh_fail(RH_ERR_ARG, "gadget_product_hoisted_then_add: levelQ out of range");
+  const size_t wq = (size_t)npoly * (levelQ + 1) * RQ->N;
+  u64 *acc0, *acc1;
+  if (int rc = rh_bext_scratch(be, 7, wq, &acc0)) return rc;
+  if (int rc = rh_bext_scratch(be, 8, wq, &acc1)) return rc;
+  return hoisted_tail(be, levelQ, levelP, decompQ, decompP, evkQ, evkP, beta_key, acc0, acc1, npoly, nullptr, add0, add1, ct0, ct1);
+}
 
 static int gadget_product_impl(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, const uint64_t* evkQ, const uint64_t* evkP,
                                int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly, const uint64_t* add0, const uint64_t* add1) {

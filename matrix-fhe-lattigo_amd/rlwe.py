@@ -117,11 +117,6 @@ class Evaluator:
             raise RingHipError("cannot apply Automorphism: GaloisKey[%d] is missing" % galEl)
         return self.galois_keys[galEl]
 
-    def _finish(self, ringQ, ctIn, tmp, galEl, opOut):
-        ringQ.Add(tmp.Value[0], ctIn.Value[0], tmp.Value[0])
-        ringQ.AutomorphismNTT(tmp.Value[0], galEl, opOut.Value[0])   # AutomorphismNTTWithIndex (ring/automorphism.go:52-73)
-        ringQ.AutomorphismNTT(tmp.Value[1], galEl, opOut.Value[1])
-
     def _check_degree1_ntt(self, ctIn, opOut, who):
         if ctIn.Degree() != 1 or opOut.Degree() != 1:
             raise RingHipError("cannot apply %s: input and output Ciphertext must be of degree 1" % who)
@@ -156,6 +151,9 @@ class Evaluator:
         evk = self._galois_key(galEl)
         npoly = ctIn.Value[1].npoly
         tmp = Ciphertext([DevicePoly(ringQ, npoly, level + 1), DevicePoly(ringQ, npoly, level + 1)], is_ntt=True)
-        self.GadgetProductHoisted(level, c1DecompQP, evk, tmp)
-        self._finish(ringQ, ctIn, tmp, galEl, opOut)
+        dq, dp = c1DecompQP
+        _check(lib().rh_bext_gadget_product_hoisted_then_add(self.be._h, level, evk.LevelP(), dq.ptr, dp.ptr, evk.Q.ptr, evk.P.ptr, evk.digits,
+                                                             ctIn.Value[0].ptr, None, tmp.Value[0].ptr, tmp.Value[1].ptr, npoly))   # product + Add (:88-89)
+        ringQ.AutomorphismNTT(tmp.Value[0], galEl, opOut.Value[0])
+        ringQ.AutomorphismNTT(tmp.Value[1], galEl, opOut.Value[1])
         opOut.IsNTT = ctIn.IsNTT
