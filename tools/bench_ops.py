@@ -108,6 +108,18 @@ e = entry("CKKS MulRelin + Rescale N=2^16 Q=24 P=6 (tensor, key switch, 2 adds, 
           0.0, B, "ctmul")
 e.pop("algorithmic_GBps"); e.pop("frac_of_8TBps")
 res.append(e)
+# rotations of one ciphertext with a shared decomposition (core/rlwe/evaluator_automorphism.go:62-105): DecomposeNTT once, then per rotation
+# GadgetProductHoisted + Add + two NTT-domain automorphisms
+gal = 5
+kev = rh.rlwe.Evaluator(rq, rp, galois_keys={gal: gct})
+dec = kev.DecomposeNTT(23, 5, ctA.Value[1], True)
+ms_dec = timed(lambda: kev.DecomposeNTT(23, 5, ctA.Value[1], True), reps=3, warm=1)
+ms_rot = timed(lambda: kev.AutomorphismHoisted(23, ctA, dec, gal, ctO), reps=3, warm=1)
+e = entry("hoisted rotation N=2^16 Q=24 P=6: DecomposeNTT once (%.3f ms per batch of %d), then per rotation" % (ms_dec, B), ms_rot, 0.0, B, "rotation")
+e.pop("algorithmic_GBps"); e.pop("frac_of_8TBps")
+res.append(e)
+del dec
+kev.close()
 del ctA, ctB, ctO, ctR, gct
 cev.close()
 del pq, pp, poq, pop, xq, xp, oq, op_, p0, p1, c0, c1, evq, evp
