@@ -362,6 +362,30 @@ int rh_bext_moddown_ntt_add(rh_bext* be, int levelQ, int levelP, const u64* p1Q,
   return rh_vec_launch(be->Q, RH_OP_ADD, buffQ, addend, p2Q, npoly, levelQ + 1, 0, nullptr, nullptr);
 }
 
+// The two ModDowns that end a key switch (one per ciphertext component) as one batch of 2*npoly polys up to the tile stages:
+// p1P holds both P parts back to back ([2][npoly][levelP+1][N]); Q parts, outputs and addends are separate blocks.
+int rh_bext_moddown_ntt_pair(rh_bext* be, int levelQ, int levelP, const u64* q0, const u64* q1, const u64* p1P, u64* out0, u64* out1,
+                             int npoly, const u64* add0, const u64* add1) {
+  if (int rc = check_levels(be, levelQ, levelP, true)) return rc;
+  const size_t N = be->Q->N, wq = (size_t)npoly * (levelQ + 1) * N, wp = (size_t)npoly * (levelP + 1) * N;
+  if (!rh_can_fuse_submul(be->Q) || be->P->kind != RH_RING_STANDARD) {          // small rings: component by component
+    if (int rc = rh_bext_moddown_ntt_add(be, levelQ, levelP, q0, p1P, out0, npoly, add0)) return rc;
+    return rh_bext_moddown_ntt_add(be, levelQ, levelP, q1, p1P + wp, out1, npoly, add1);
+  }
+  if (int rc = ensure_buf(be, 0, 2 * wq)) return rc;
+  if (int rc = ensure_buf(be, 1, 2 * wp)) return rc;
+  u64* buffQ = be->buf[0]; u64* buffP = be->buf[1];
+  if (int rc = rh_std_ntt_launch(be->P, p1P, buffP, 2 * npoly, levelP + 1, 0, true, true, 0)) return rc;       // ringP.INTTLazy, both components
+  BextPlan* p; if (int rc = get_modup_plan(be, 0, 1, levelP, levelQ, &p)) return rc;
+  if (int rc = launch_plan(be, *p, buffP, levelP + 1, 0, buffQ, levelQ + 1, nullptr, 0, nullptr, 0, 2 * npoly, BEXT_ADD_CRED)) return rc;
+  if (be->Q->logN > 12) if (int rc = rh_std_ntt_launch(be->Q, buffQ, buffQ, 2 * npoly, levelQ + 1, 0, false, false, 1)) return rc;   // column stages
+  std::vector<u64> sc(levelQ + 1);
+  std::vector<u64> Ps(be->P->moduli.begin(), be->P->moduli.begin() + levelP + 1);
+  for (int i = 0; i <= levelQ; ++i) sc[i] = be->Q->moduli[i] - moddown_const(Ps, be->Q->moduli[i]);
+  if (int rc = rh_std_ntt_submul_launch(be->Q, buffQ, npoly, levelQ + 1, 0, q0, levelQ + 1, out0, levelQ + 1, sc.data(), true, add0, levelQ + 1)) return rc;
+  return rh_std_ntt_submul_launch(be->Q, buffQ + wq, npoly, levelQ + 1, 0, q1, levelQ + 1, out1, levelQ + 1, sc.data(), true, add1, levelQ + 1);
+}
+
 // DecomposeAndSplit (:381-502)
 extern "C" int rh_bext_decompose_and_split(rh_bext* be, int levelQ, int levelP, int nbPi, int digit, const uint64_t* p0Q,
                                            uint64_t* p1Q, uint64_t* p1P, int npoly) {

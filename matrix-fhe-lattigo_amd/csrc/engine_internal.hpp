@@ -80,3 +80,5 @@ rh_ring* rh_bext_ringP(rh_bext* be);
 int rh_bext_scratch(rh_bext* be, int which, size_t words, u64** out);
 // ModDownQPtoQNTT with an optional addend: p2Q = [addend +] (p1Q - ext(p1P)) / P   (addend: the ring.Add that follows a key switch)
 int rh_bext_moddown_ntt_add(rh_bext* be, int levelQ, int levelP, const u64* p1Q, const u64* p1P, u64* p2Q, int npoly, const u64* addend);
+int rh_bext_moddown_ntt_pair(rh_bext* be, int levelQ, int levelP, const u64* q0, const u64* q1, const u64* p1P, u64* out0, u64* out1,
+                             int npoly, const u64* add0, const u64* add1);

@@ -168,15 +168,14 @@ static int hoisted_tail(rh_bext* be, int levelQ, int levelP, const uint64_t* dec
   rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
   const int LQ = levelQ + 1, LP = levelP + 1, N = RQ->N;
   const size_t wq = (size_t)npoly * LQ * N, wp = (size_t)npoly * LP * N;
-  u64 *aP0, *aP1;
-  if (int rc = rh_bext_scratch(be, 5, wp, &aP0)) return rc;
-  if (int rc = rh_bext_scratch(be, 6, wp, &aP1)) return rc;
+  u64 *aP0, *aP1;                                  // both P-part accumulators back to back: ModDown transforms them as one batch
+  if (int rc = rh_bext_scratch(be, 5, 2 * wp, &aP0)) return rc;
+  aP1 = aP0 + wp;
   const size_t evq_stride = (size_t)RQ->L * N, evp_stride = (size_t)RP->L * N;
   ReduceSchedule rs(RQ, levelQ, RP, levelP);
   if (int rc = mac_all(RQ, decompQ, wq, evkQ, beta, rs.QiOverF, ct0, ct1, npoly, LQ, cx, LP)) return rc;
   if (int rc = mac_all(RP, decompP, wp, evkP, beta, rs.PiOverF, aP0, aP1, npoly, LP)) return rc;
-  if (int rc = rh_bext_moddown_ntt_add(be, levelQ, levelP, ct0, aP0, out0, npoly, add0)) return rc;
-  return rh_bext_moddown_ntt_add(be, levelQ, levelP, ct1, aP1, out1, npoly, add1);
+  return rh_bext_moddown_ntt_pair(be, levelQ, levelP, ct0, ct1, aP0, out0, out1, npoly, add0, add1);
 }
 extern "C" int rh_bext_gadget_product_hoisted(rh_bext* be, int levelQ, int levelP, const uint64_t* decompQ, const uint64_t* decompP,
                                               const uint64_t* evkQ, const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly) {
