@@ -18,10 +18,19 @@ class Evaluator:
         self.nb_rescales = int(levels_consumed_per_rescaling)
         self.fused_tensor = True          # regular ct x ct case: rh_ring_tensor_degree1 instead of six element-wise launches (same bits)
         self.ks = rlwe.Evaluator(ringQ, ringP) if ringP is not None else None
+        self._pool = {}
 
     def close(self):
+        self._pool.clear()
         if self.ks:
             self.ks.close()
+
+    def _buffer(self, tag, ring, npoly, limbs):
+        key = (tag, id(ring._h), npoly, limbs)
+        p = self._pool.get(key)
+        if p is None:
+            p = self._pool[key] = DevicePoly(ring, npoly, limbs)
+        return p
 
     def _same_level(self, *cts):
         lv = {c.Level() for c in cts}
@@ -38,7 +47,11 @@ class Evaluator:
         level = self._same_level(op0, op1, opOut)
         rq = self.ringQ.AtLevel(level)
         npoly = op0.Value[0].npoly
-        new = lambda: DevicePoly(rq, npoly, level + 1)
+        counter = [0]
+
+        def new():                         # eval.buffQ[i]: evaluator-owned, allocated once per shape
+            counter[0] += 1
+            return self._buffer("buffQ%d" % counter[0], rq, npoly, level + 1)
         d0, d1 = op0.Degree(), op1.Degree()
         if d0 == 1 and d1 == 1:
             need = 1 if relin else 2

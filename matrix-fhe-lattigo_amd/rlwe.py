@@ -45,9 +45,21 @@ class Evaluator:
         self.ringQ, self.ringP = ringQ, ringP
         self.be = BasisExtender(ringQ, ringP)
         self.galois_keys = dict(galois_keys or {})
+        self._pool = {}
 
     def close(self):
+        self._pool.clear()
         self.be.close()
+
+    def buffer(self, tag, ring, npoly, limbs):
+        """evaluator-owned scratch poly (the reference's eval.BuffQP / BuffCt): allocated once per shape, reused by every call --
+        no hipMalloc / hipFree (and their implicit synchronisation) on the hot path.  Not thread-safe, like the reference's
+        buffers (use one Evaluator per thread: Evaluator.ShallowCopy in the reference)."""
+        key = (tag, id(ring._h), npoly, limbs)
+        p = self._pool.get(key)
+        if p is None:
+            p = self._pool[key] = DevicePoly(ring, npoly, limbs)
+        return p
 
     # ---- core/rlwe/evaluator_gadget_product.go ---------------------------------------------------------------
     def GadgetProduct(self, levelQ, cx, gadgetCt, ct):
@@ -136,7 +148,7 @@ class Evaluator:
             return
         evk = self._galois_key(galEl)
         npoly = ctIn.Value[1].npoly
-        tmp = Ciphertext([DevicePoly(ringQ, npoly, level + 1), DevicePoly(ringQ, npoly, level + 1)], is_ntt=True)
+        tmp = Ciphertext([self.buffer("auto0", ringQ, npoly, level + 1), self.buffer("auto1", ringQ, npoly, level + 1)], is_ntt=True)
         self.GadgetProductThenAdd(level, ctIn.Value[1], evk, ctIn.Value[0], None, tmp)         # product + ringQ.Add (:42-44)
         ringQ.AutomorphismNTT(tmp.Value[0], galEl, opOut.Value[0])   # AutomorphismNTTWithIndex (ring/automorphism.go:52-73)
         ringQ.AutomorphismNTT(tmp.Value[1], galEl, opOut.Value[1])
@@ -150,7 +162,7 @@ class Evaluator:
             return self.Automorphism(ctIn, 1, opOut)
         evk = self._galois_key(galEl)
         npoly = ctIn.Value[1].npoly
-        tmp = Ciphertext([DevicePoly(ringQ, npoly, level + 1), DevicePoly(ringQ, npoly, level + 1)], is_ntt=True)
+        tmp = Ciphertext([self.buffer("auto0", ringQ, npoly, level + 1), self.buffer("auto1", ringQ, npoly, level + 1)], is_ntt=True)
         dq, dp = c1DecompQP
         _check(lib().rh_bext_gadget_product_hoisted_then_add(self.be._h, level, evk.LevelP(), dq.ptr, dp.ptr, evk.Q.ptr, evk.P.ptr, evk.digits,
                                                              ctIn.Value[0].ptr, None, tmp.Value[0].ptr, tmp.Value[1].ptr, npoly))   # product + Add (:88-89)
