@@ -1,16 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- forward NTT throughput at the BASELINE metric size (N = 2^16, 16 RNS limbs) on N MI355X GPUs.
+"""bench.py -- the ring hot path on N MI355X GPUs of one node, one process per GPU.
 
-A step = Ring.NTT (forward, canonical output: ring/ntt.go:127-131) over one device-resident batch of `--batch` polys
-of 16 limbs (Qi60[0:16], ring/test_params.go:15-22), in place.  value = polys transformed per second over all ranks
-(weak scaling: every rank owns its own batch; limbs and polys are independent so there is no data-path collective).
+--workload ntt (default, the BASELINE metric): a step = Ring.NTT (forward, canonical output: ring/ntt.go:127-131) over one
+  device-resident batch of `--batch` polys of 16 limbs (Qi60[0:16], ring/test_params.go:15-22) at N = 2^16, in place.
+  value = polys transformed per second over all ranks (weak scaling: every rank owns its own batch; limbs and polys are
+  independent, so there is no data-path collective -- torch.distributed only carries the barrier and the max-over-ranks).
+--workload keyswitch (BASELINE config 5): a step = rlwe.Evaluator.GadgetProduct (core/rlwe/evaluator_gadget_product.go:16-30)
+  of `--batch` polys at N = 2^16, Q = Qi60[0:24], P = Pi60[0:6], LIMB-sharded over the ranks (sharding.LimbShardedKeySwitch):
+  the one path with a real exchange step (all-gather of the digit's source limbs and of the P part, RCCL over xGMI).
+  value = key switches per second of the whole job (strong scaling: the same batch, limbs divided).
 
-One JSON line on stdout (rank 0).  `roofline` is measured live with HIP events on the launch stream over the timed
-region; `cpu_baseline` times the oracle's C restatement of nttUnrolled16Lazy+reducevec on the host cores (rank 0, N=1).
-"""
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (fresh processes, before
+any GPU call) and relays rank 0's JSON line; under torchrun (WORLD_SIZE set) it is one rank.
+
+One JSON line on stdout (rank 0).  `roofline` is measured live with HIP events on the launch stream over the timed region;
+`verified` says the timed region's own output was checked against the CPU oracle after timing; `cpu_baseline` times the
+oracle's C restatement of nttUnrolled16Lazy + reducevec on the host cores (rank 0, N = 1)."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,98 +30,84 @@ sys.path.insert(0, ROOT)
 QI60 = [0x1fffffffffe00001, 0x1fffffffffc80001, 0x1fffffffffb40001, 0x1fffffffff500001,
         0x1fffffffff380001, 0x1fffffffff000001, 0x1ffffffffef00001, 0x1ffffffffee80001,
         0x1ffffffffeb40001, 0x1ffffffffe780001, 0x1ffffffffe600001, 0x1ffffffffe4c0001,
-        0x1ffffffffdf40001, 0x1ffffffffdac0001, 0x1ffffffffda40001, 0x1ffffffffc680001]
+        0x1ffffffffdf40001, 0x1ffffffffdac0001, 0x1ffffffffda40001, 0x1ffffffffc680001,
+        0x1ffffffffc000001, 0x1ffffffffb880001, 0x1ffffffffb7c0001, 0x1ffffffffb300001,
+        0x1ffffffffb1c0001, 0x1ffffffffadc0001, 0x1ffffffffa400001, 0x1ffffffffa140001]
+PI60 = [0x1ffffffff6c80001, 0x1ffffffff6140001, 0x1ffffffff5f40001, 0x1ffffffff5700001,
+        0x1ffffffff4bc0001, 0x1ffffffff4380001]
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="polys per GPU per step (1024 -> 8 GiB, >> 256 MiB Infinity Cache)")
+    ap.add_argument("--workload", default="ntt", choices=["ntt", "keyswitch"])
+    ap.add_argument("--batch", type=int, default=-1, help="ntt: polys per GPU per step (default 1024 -> 8 GiB, >> 256 MiB Infinity Cache); "
+                                                           "keyswitch: polys per step of the whole job (default 64)")
     ap.add_argument("--logn", type=int, default=16)
-    ap.add_argument("--limbs", type=int, default=16)
+    ap.add_argument("--limbs", type=int, default=16, help="ntt workload: limbs of the ring (Qi60[0:limbs])")
     ap.add_argument("--chunk", type=int, default=-1, help="polys per (column,tile) kernel pair; -1 = engine default")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed region's output")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--persistent", type=int, default=-1)
-    ap.add_argument("--cluster", type=int, default=-1)
-    ap.add_argument("--cluster-wgs", type=int, default=-1)
-    ap.add_argument("--unsafe", type=int, default=0)
-    ap.add_argument("--order-mix", type=int, default=-1)
     ap.add_argument("--lds-pad", type=int, default=0, help="experiment: extra dynamic LDS bytes per workgroup of the fused launch (occupancy sensitivity)")
-    ap.add_argument("--asm-cols", type=int, default=-1, help="hand-scheduled column stages at N=2^16 (default on)")
-    ap.add_argument("--prefetch", type=int, default=-1, help="fused launch with tile loads ahead of the column stages (default off: measured no gain)")
-    ap.add_argument("--cols2", type=int, default=-1)
-    ap.add_argument("--group", type=int, default=-1, help="polys per group of the persistent pipeline")
-    ap.add_argument("--asm", type=int, default=-1, help="1/0: hand-scheduled vs C++ forward tile kernel; -1 = engine default")
-    args = ap.parse_args()
+    ap.add_argument("--asm-cols", type=int, default=-1, help="hand-scheduled column stages (default on)")
+    ap.add_argument("--asm", type=int, default=-1, help="1/0: hand-scheduled vs C++ tile kernels; -1 = engine default")
+    ap.add_argument("--tune", action="append", default=[], help="key=value for rh_ring_set_tuning (repeatable)")
+    return ap.parse_args()
 
-    import numpy as np
+
+def spawn_ranks(args):
+    """--gpus N > 1 without a launcher: start N fresh rank processes (this parent makes no GPU call), relay rank 0's line"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+        sys.exit(1)
+
+
+def init_dist(args):
     import torch
-    import matrix_fhe_lattigo_amd as rh
-
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if args.single_device:
-        local_rank = 0
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist, ranks_seen = None, 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=args.dist_backend)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        assert dist.get_world_size() == world
+        one = torch.ones(1, dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(one)                                   # a real collective over the backend (RCCL when nccl)
+        ranks_seen = int(one.item())
+        assert ranks_seen == world, "all_reduce of ones returned %d, world is %d" % (ranks_seen, world)
+    return rank, local_rank, world, dist, dev, ranks_seen
 
-    N, L, B = 1 << args.logn, args.limbs, args.batch
-    mods = QI60[:L]
-    ring = rh.Ring(N, mods, device=local_rank)
-    stream = torch.cuda.current_stream()
-    ring.set_stream(stream.cuda_stream)
-    if args.chunk >= 0:
-        ring.set_tuning("chunk_polys", args.chunk)
-    if args.asm >= 0:
-        ring.set_tuning("asm_tile", args.asm)
-    if args.cluster >= 0:
-        ring.set_tuning("cluster", args.cluster)
-    if args.cluster_wgs >= 1:
-        ring.set_tuning("cluster_wgs_per_cu", args.cluster_wgs)
-    if args.persistent >= 0:
-        ring.set_tuning("persistent", args.persistent)
-    if args.cols2 >= 0:
-        ring.set_tuning("cols2", args.cols2)
-    if args.lds_pad > 0:
-        ring.set_tuning("dbg_lds_pad", args.lds_pad)
-    if args.asm_cols >= 0:
-        ring.set_tuning("asm_cols", args.asm_cols)
-    if args.prefetch >= 0:
-        ring.set_tuning("prefetch", args.prefetch)
-    if args.order_mix >= 0:
-        ring.set_tuning("order_mix", args.order_mix)
-    if args.unsafe:
-        ring.set_tuning("persist_unsafe_timing", 1)
-    if args.group >= 1:
-        ring.set_tuning("group_polys", args.group)
 
-    # synthetic input: i.i.d. residues in [0, q_i), seeded, generated on the device
-    g = torch.Generator(device=dev); g.manual_seed(0x5eed + rank)
-    data = torch.empty((B, L, N), dtype=torch.int64, device=dev)
-    qs = torch.tensor(mods, dtype=torch.int64, device=dev).view(1, L, 1)
-    for b0 in range(0, B, 64):
-        blk = torch.randint(0, 1 << 62, (min(64, B - b0), L, N), dtype=torch.int64, device=dev, generator=g)
-        data[b0:b0 + blk.shape[0]] = blk % qs
-    poly = rh.DevicePoly.from_torch(ring, data)
-
-    def step():
-        ring.NTT(poly, poly)
-
+def timed_region(step, args, dist, dev, stream):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks"""
+    import torch
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -128,14 +124,110 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    ring.sync()                                   # raises if the pipeline reported a hand-off time-out
-    wall = t1 - t0
+    wall = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)
     if dist is not None:
         t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(t[0]), float(t[1])
+    return wall, dev_ms
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, N, mods):
+    import oracle
+    L = len(mods)
+    ncpu = os.cpu_count() or 1
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else ncpu
+    t_probe = oracle.time_ntt_forward(N, mods, 1, 1)            # one L-limb poly, one thread
+    reps = max(1, int(args.cpu_seconds / max(t_probe, 1e-6)))
+    t_cpu = oracle.time_ntt_forward(N, mods, reps, 1)
+    out = {"value": reps / t_cpu, "unit": "NTT/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+           "sample": "%d forward NTTs of one %d-limb N=2^%d poly, single thread (the Go loop over limbs is single-threaded), C restatement of "
+                     "nttUnrolled16Lazy+reducevec (oracle/ring_oracle.c); host has %d cores, %d usable by this process" % (reps, L, args.logn, ncpu, avail)}
+    if avail > 1:
+        # every core this process may use, (poly, limb) units spread over the threads (a goroutine-per-limb caller of the reference
+        # over a batch): a short extra sample, reported beside the like-for-like one
+        npolys = max(1, -(-avail // L))
+        reps_mt = max(1, int(0.4 * args.cpu_seconds * avail / max(t_probe * npolys, 1e-6)))
+        t_mt = oracle.time_ntt_forward_polys(N, mods, npolys, reps_mt, avail)
+        out["all_cores"] = {"value": npolys * reps_mt / t_mt, "unit": "NTT/s", "cores": avail,
+                            "sample": "%d passes over %d polys, %d (poly, limb) units spread over the %d threads this process may use "
+                                      "(of %d host cores)" % (reps_mt, npolys, npolys * L, avail, ncpu)}
+    return out
+
+
+def load_json(name):
+    p = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(p))
+    except (OSError, ValueError):
+        return None
+
+
+# ------------------------------------------------------------------------------------------------ workload: ntt
+def run_ntt(args):
+    import numpy as np
+    import torch
+    import matrix_fhe_lattigo_amd as rh
+    rank, local_rank, world, dist, dev, ranks_seen = init_dist(args)
+    N, L = 1 << args.logn, args.limbs
+    B = args.batch if args.batch > 0 else 1024
+    mods = QI60[:L]
+    ring = rh.Ring(N, mods, device=local_rank)
+    stream = torch.cuda.current_stream()
+    ring.set_stream(stream.cuda_stream)
+    if args.chunk >= 0:
+        ring.set_tuning("chunk_polys", args.chunk)
+    if args.asm >= 0:
+        ring.set_tuning("asm_tile", args.asm)
+    if args.lds_pad > 0:
+        ring.set_tuning("dbg_lds_pad", args.lds_pad)
+    if args.asm_cols >= 0:
+        ring.set_tuning("asm_cols", args.asm_cols)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        ring.set_tuning(k, int(v))
+
+    # synthetic input: i.i.d. residues in [0, q_i), seeded, generated on the device
+    g = torch.Generator(device=dev); g.manual_seed(0x5eed + rank)
+    data = torch.empty((B, L, N), dtype=torch.int64, device=dev)
+    qs = torch.tensor(mods, dtype=torch.int64, device=dev).view(1, L, 1)
+    for b0 in range(0, B, 64):
+        blk = torch.randint(0, 1 << 62, (min(64, B - b0), L, N), dtype=torch.int64, device=dev, generator=g)
+        data[b0:b0 + blk.shape[0]] = blk % qs
+    poly = rh.DevicePoly.from_torch(ring, data)
+    spots = sorted({(0, 0), (min(B - 1, B // 2 + 1), min(L - 1, 7)), (B - 1, L - 1)})
+    saved = {s: data[s[0], s[1]].cpu().numpy().view(np.uint64).copy() for s in spots} if rank == 0 else {}
+
+    def step():
+        ring.NTT(poly, poly)
+
+    wall, dev_ms = timed_region(step, args, dist, dev, stream)
+    ring.sync()
+    # verification of the timed region's own output (rank 0): the buffer has been transformed warmup + steps times in place
+    verified = None
+    if rank == 0 and not args.no_verify:
+        import oracle
+        k = args.warmup + args.steps
+        verified = True
+        for (p, l), x in saved.items():
+            sr = oracle.SubRingConsts(N, mods[l])
+            for _ in range(k):
+                x = oracle.ntt(x, sr)
+            if not np.array_equal(data[p, l].cpu().numpy().view(np.uint64), x):
+                verified = False
+        if not verified:
+            sys.stderr.write("bench.py: OUTPUT MISMATCH vs oracle after %d forward transforms\n" % k)
 
     # per-kernel device time (HIP events on the same stream), outside the timed region
     kern = {}
@@ -151,7 +243,6 @@ def main():
             b.record(stream)
             torch.cuda.synchronize()
             kern[name] = a.elapsed_time(b) / reps
-
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -163,59 +254,134 @@ def main():
     launch_ms = dev_ms / args.steps                     # device time of one whole forward transform of the batch
     achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-    if os.path.exists(tpath):
-        try:                                            # PMC-measured bytes (profiles/), valid for the profiled shape only
-            tj = json.load(open(tpath))
-            if tj.get("config", {}).get("logn") == args.logn and tj.get("config", {}).get("limbs") == L:
-                traffic = tj["hbm_bytes_per_poly"] * B
-        except Exception:
-            traffic = None
+    tj = load_json("latest_traffic.json")
+    if tj and tj.get("config", {}).get("logn") == args.logn and tj.get("config", {}).get("limbs") == L:
+        traffic = tj["hbm_bytes_per_poly"] * B          # PMC-measured bytes (profiles/), valid for the profiled shape only
     # what is actually launched inside the timed region (engine.hip: rh_std_ntt_launch)
-    chunk = args.chunk if args.chunk >= 0 else (max(1, 2048 // L) if B > max(1, 2048 // L) else 0)   # engine.hip auto rule
-    special = args.cluster == 1 or args.persistent == 1
-    if special:
-        launches, kname = 1, "ntt_fwd_cluster / ntt_fwd_persistent (experimental single launch)"
-    elif args.logn > 12 and chunk > 0 and B > chunk:
+    span = max(1, 2048 // L)
+    chunk = args.chunk if args.chunk >= 0 else (span if B > span else 0)   # engine.hip auto rule
+    if args.logn > 12 and chunk > 0 and B > chunk:
         launches = -(-B // chunk) + 1
         kname = ("ntt_fwd_fused_asm<%d>: column stages of one %d-poly span + tile stages of the previous span; %d launches per step "
                  "(first and last carry one half), each moves the algorithmic bytes of one span's whole transform" % (args.logn - 12, chunk, launches))
     else:
         launches, kname = (2 if args.logn > 12 else 1), "ntt_fwd_cols + ntt_fwd_tile_asm (two launches = one forward transform)"
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": (traffic / launches) if traffic is not None else None,      # PMC bytes per launch, like algorithmic_bytes_per_launch
+            "traffic_per_step": traffic, "kernel": kname, "launches_per_step": launches,
+            "avg_launch_ms": launch_ms / launches, "algorithmic_bytes_per_launch": alg_bytes / launches,
+            "algorithmic_bytes_per_step": alg_bytes, "device_ms_per_step": launch_ms, "standalone_kernel_ms": kern}
+    vj = load_json("latest_valu.json")                  # SQ_INSTS_VALU per step + measured issue peak (profiles/), profiled shape only
+    if vj and vj.get("config", {}).get("logn") == args.logn and vj.get("config", {}).get("limbs") == L:
+        winstr = vj["valu_wave_instructions_per_poly"] * B
+        issue = winstr / (launch_ms * 1e-3) / 1e9
+        roof["valu"] = {"note": "the transform is VALU-issue bound before it is HBM-bound (DESIGN.md 3): 64-bit modular butterflies, no MFMA-shaped work",
+                        "wave_instructions_per_step": winstr, "achieved_Gwinstr_per_s": issue,
+                        "issue_peak_Gwinstr_per_s": vj["issue_peak_Gwinstr_per_s"], "frac_of_issue_peak": issue / vj["issue_peak_Gwinstr_per_s"],
+                        "butterfly_ceiling_NTT_per_s": vj["butterfly_ceiling_limb_ntt_per_s"] / L,
+                        "frac_of_butterfly_ceiling": (B / (launch_ms * 1e-3)) / (vj["butterfly_ceiling_limb_ntt_per_s"] / L),
+                        "source": vj.get("source")}
     out = {
-        "metric": "forward-NTT/s at N=2^16, 16 RNS limbs; achieved HBM GB/s vs peak",
+        "metric": "forward-NTT/s at N=2^%d, %d RNS limbs; achieved HBM GB/s vs peak" % (args.logn, L),
         "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64", "data": "synthetic",
+        "dtype": "u64", "data": "synthetic", "verified": verified,
         "config": {"workload": "Ring.NTT forward, N=2^%d, %d limbs (Qi60[0:%d]), batch %d polys/GPU, in place, device-resident" % (args.logn, L, L, B),
-                   "parallelism": "batch-shard x%d, no collective" % world, "limb_ntt_per_s": value * L},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": (traffic / launches) if traffic is not None else None,      # PMC bytes per launch, like algorithmic_bytes_per_launch
-                     "traffic_per_step": traffic, "kernel": kname, "launches_per_step": launches,
-                     "avg_launch_ms": launch_ms / launches, "algorithmic_bytes_per_launch": alg_bytes / launches,
-                     "algorithmic_bytes_per_step": alg_bytes, "device_ms_per_step": launch_ms,
-                     "standalone_kernel_ms": kern},
+                   "parallelism": "batch-shard x%d, no data-path collective" % world, "limb_ntt_per_s": value * L,
+                   "dist_backend": args.dist_backend if world > 1 else None, "rccl_ranks" if args.dist_backend == "nccl" else "dist_ranks": ranks_seen},
+        "roofline": roof,
     }
     if world == 1 and not args.no_cpu:
-        import oracle
-        ncpu = os.cpu_count() or 1
-        t_probe = oracle.time_ntt_forward(N, mods, 1, 1)            # one 16-limb poly, one thread
-        reps = max(1, int(args.cpu_seconds / max(t_probe, 1e-6)))
-        t_cpu = oracle.time_ntt_forward(N, mods, reps, 1)
-        out["cpu_baseline"] = {"value": reps / t_cpu, "unit": "NTT/s", "cores": 1, "kind": "port",
-                               "sample": "%d forward NTTs of one 16-limb N=2^%d poly, single thread (the Go loop is single-threaded), "
-                                         "C restatement of nttUnrolled16Lazy+reducevec (oracle/ring_oracle.c), host has %d cores" % (reps, args.logn, ncpu)}
-        # the same work spread over this process's share of the host cores (limbs of a poly are independent): what a
-        # goroutine-per-limb caller of the reference could reach; a short extra sample, reported beside the like-for-like one
-        nthr = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else ncpu, L)
-        if nthr > 1:
-            reps_mt = max(nthr, int(0.4 * args.cpu_seconds * nthr / max(t_probe, 1e-6)))
-            t_mt = oracle.time_ntt_forward(N, mods, reps_mt, nthr)
-            out["cpu_baseline"]["all_cores"] = {"value": reps_mt / t_mt, "unit": "NTT/s", "cores": nthr,
-                                                "sample": "%d forward NTTs, limbs spread over %d threads" % (reps_mt, nthr)}
+        out["cpu_baseline"] = cpu_baseline(args, N, mods)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ workload: keyswitch
+def run_keyswitch(args):
+    import numpy as np
+    import torch
+    import matrix_fhe_lattigo_amd as rh
+    from matrix_fhe_lattigo_amd import sharding
+    rank, local_rank, world, dist, dev, ranks_seen = init_dist(args)
+    N = 1 << args.logn
+    B = args.batch if args.batch > 0 else 64
+    Q, P = QI60[:24], PI60[:6]
+    nq, npl = len(Q), len(P)
+    ks = sharding.LimbShardedKeySwitch(N, Q, P, rank, world, dist=dist if world > 1 else None, device=local_rank)
+    beta = ks.beta
+    stream = torch.cuda.current_stream()
+    # synthetic inputs: the SAME (seeded) full-size case on every rank, each keeps its limbs (uniform key: SURVEY 8d)
+    g = torch.Generator(device=dev)
+
+    def limb_rows(seed, nlead, mods, i):
+        """(nlead, N) uniform residues of global limb i: the unit of generation, identical on whichever rank draws it"""
+        g.manual_seed(seed * 1000 + i)
+        return torch.randint(0, 1 << 62, (nlead, N), dtype=torch.int64, device=dev, generator=g) % mods[i]
+
+    def rows(seed, lead, mods, own):
+        out = torch.empty(tuple(lead) + (len(own), N), dtype=torch.int64, device=dev)
+        flat = out.view(-1, len(own), N)
+        for k, i in enumerate(own):
+            flat[:, k] = limb_rows(seed, flat.shape[0], mods, i)
+        return out
+    cx = rows(1, (B,), Q, ks.ownQ)
+    evkQ = rows(2, (beta, 2), Q, ks.ownQ)
+    evkP = rows(3, (beta, 2), P, ks.ownP) if ks.ownP else None
+    ct0, ct1 = torch.empty_like(cx), torch.empty_like(cx)
+
+    def step():
+        ks.GadgetProduct(cx, evkQ, evkP, ct0, ct1)
+
+    wall, dev_ms = timed_region(step, args, dist, dev, stream)
+    verified = None
+    if not args.no_verify:                                 # poly 0 of this rank's owned limbs against the oracle composition
+        from oracle import compose
+        host = lambda t: t.cpu().numpy().view(np.uint64)
+        cx_f = np.stack([host(limb_rows(1, B, Q, i)[0]) for i in range(nq)])                                   # poly 0, every limb
+        ekq = np.stack([host(limb_rows(2, beta * 2, Q, i)) for i in range(nq)], axis=1).reshape(beta, 2, nq, N)
+        ekp = np.stack([host(limb_rows(3, beta * 2, P, j)) for j in range(npl)], axis=1).reshape(beta, 2, npl, N)
+        e0, e1 = compose.gadget_product(N, Q, P, nq - 1, npl - 1, cx_f, ekq, ekp)
+        ok = np.array_equal(host(ct0[0]), e0[ks.ownQ]) and np.array_equal(host(ct1[0]), e1[ks.ownQ])
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        if dist is not None:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        verified = bool(flag.item() == 1.0)
+    if rank == 0:
+        ms_per_step = wall * 1e3 / args.steps
+        value = B * args.steps / wall
+        launch_ms = dev_ms / args.steps
+        # SURVEY 8(d): limb transforms x 16 N + the evaluation-key read 2 beta (L+k) 8 N, whole job
+        limb_ntts = nq + beta * (nq + npl) - nq + 2 * (npl + nq)      # INTT(cx) + per digit NTTs (own limbs skipped: -nq in total) + 2 ModDowns
+        alg = B * limb_ntts * 16.0 * N + 2.0 * beta * (nq + npl) * 8.0 * N
+        achieved = alg / (launch_ms * 1e-3) / 1e9
+        out = {
+            "metric": "key-switch (hybrid gadget product)/s at N=2^%d, %d Q + %d P moduli, limb-sharded" % (args.logn, nq, npl),
+            "value": value, "unit": "key-switch/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic", "verified": verified,
+            "config": {"workload": "rlwe.Evaluator.GadgetProduct, N=2^%d, Q=Qi60[0:24], P=Pi60[0:6], beta=%d, batch %d polys per step (whole job), "
+                                   "uniform key shared by the batch" % (args.logn, beta, B),
+                       "parallelism": "limb-shard x%d (round-robin over Q++P), all-gather of source limbs per digit and of the P part" % world,
+                       "dist_backend": args.dist_backend if world > 1 else None, "rccl_ranks" if args.dist_backend == "nccl" else "dist_ranks": ranks_seen},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * world),
+                         "traffic": None, "kernel": "whole gadget product (%d limb transforms + key multiply-accumulate + basis extensions per poly)" % limb_ntts,
+                         "algorithmic_bytes_per_step": alg, "device_ms_per_step": launch_ms},
+        }
+        print(json.dumps(out), flush=True)
+    ks.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
+    if args.workload == "keyswitch":
+        return run_keyswitch(args)
+    return run_ntt(args)
 
 
 if __name__ == "__main__":

@@ -285,9 +285,17 @@ class Ring:
 
     # ---- NTT (ring/ntt.go:127-152) -----------------------------------------------------------------------------
     def _chk(self, *polys):
+        """The C ABI strides every block by level+1 rows per poly (ringhip.h "Data model"), so a batch must be allocated at
+        exactly the level it is used at.  The reference's ring.AtLevel(l) on polys with MORE limbs (ring/ring.go:192-213)
+        is accepted for a single poly only (its leading limbs are contiguous); a batch raises instead of striding wrongly."""
         for p in polys:
-            if p is not None and (p.limbs < self.level + 1):
+            if p is None:
+                continue
+            if p.limbs < self.level + 1:
                 raise RingHipError("poly has %d limbs, ring level needs %d" % (p.limbs, self.level + 1))
+            if p.limbs != self.level + 1 and p.npoly > 1:
+                raise RingHipError("batch of %d polys has %d limbs per poly but the ring view is at level %d: device blocks are "
+                                   "strided by level+1 rows, allocate the batch at that level" % (p.npoly, p.limbs, self.level))
 
     def NTT(self, p1, p2):
         self._chk(p1, p2); _check(lib().rh_ring_ntt(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 0))
@@ -305,16 +313,20 @@ class Ring:
     def TensorDegree1(self, a0, a1, b0, b1, c0, c1, c2, mform_first=True):
         """degree-1 x degree-1 tensoring as one kernel: ckks mulRelin (schemes/ckks/evaluator.go:821-834) with mform_first,
         matrix_ckks.Evaluator.Mul (schemes/matrix_ckks/evaluator.go:166-173) without"""
+        self._chk(a0, a1, b0, b1, c0, c1, c2)
         _check(lib().rh_ring_tensor_degree1(self._h, a0.ptr, a1.ptr, b0.ptr, b1.ptr, c0.ptr, c1.ptr, c2.ptr, a0.npoly, self.level,
                                             1 if mform_first else 0))
 
     def AutomorphismNTT(self, polIn, gen, polOut):
+        self._chk(polIn, polOut)
         _check(lib().rh_ring_automorphism_ntt(self._h, self.level, polIn.ptr, int(gen), polOut.ptr, polIn.npoly, 0))
 
     def AutomorphismNTTThenAddLazy(self, polIn, gen, polOut):
+        self._chk(polIn, polOut)
         _check(lib().rh_ring_automorphism_ntt(self._h, self.level, polIn.ptr, int(gen), polOut.ptr, polIn.npoly, 1))
 
     def Automorphism(self, polIn, gen, polOut):
+        self._chk(polIn, polOut)
         _check(lib().rh_ring_automorphism(self._h, self.level, polIn.ptr, int(gen), polOut.ptr, polIn.npoly))
 
     # ---- rescale (ring/scaling.go).  Output poly may have level+1 or fewer limbs, like the reference -----------

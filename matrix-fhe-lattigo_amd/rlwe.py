@@ -61,10 +61,21 @@ class Evaluator:
             p = self._pool[key] = DevicePoly(ring, npoly, limbs)
         return p
 
+    @staticmethod
+    def _rows(level, *polys):
+        """device blocks are strided by level+1 rows per poly (ringhip.h): a batch allocated with more limbs than the level
+        it is used at would be read with the wrong stride -- refuse it (a single poly's leading limbs are contiguous)"""
+        for p in polys:
+            if p is None:
+                continue
+            if p.limbs < level + 1 or (p.limbs != level + 1 and p.npoly > 1):
+                raise RingHipError("batch of %d polys with %d limbs used at level %d: allocate it at that level" % (p.npoly, p.limbs, level))
+
     # ---- core/rlwe/evaluator_gadget_product.go ---------------------------------------------------------------
     def GadgetProduct(self, levelQ, cx, gadgetCt, ct):
         """ct = (<decomp(cx), gadget[0]>, <decomp(cx), gadget[1]>) / P mod Q (:16-30); cx and ct in the NTT domain"""
         levelQ = min(levelQ, gadgetCt.LevelQ())
+        self._rows(levelQ, cx, ct.Value[0], ct.Value[1])
         _check(lib().rh_bext_gadget_product(self.be._h, levelQ, gadgetCt.LevelP(), cx.ptr, gadgetCt.Q.ptr, gadgetCt.P.ptr,
                                             gadgetCt.digits, ct.Value[0].ptr, ct.Value[1].ptr, cx.npoly))
 
@@ -72,6 +83,7 @@ class Evaluator:
         """ct[c] = add_c + GadgetProduct(cx)[c] (ring.Add, canonical) -- the Add the callers below issue right after the
         product, folded into ModDown's tile epilogue.  add0 / add1: DevicePoly or None; they may be ct.Value[c] themselves."""
         levelQ = min(levelQ, gadgetCt.LevelQ())
+        self._rows(levelQ, cx, add0, add1, ct.Value[0], ct.Value[1])
         _check(lib().rh_bext_gadget_product_then_add(self.be._h, levelQ, gadgetCt.LevelP(), cx.ptr, gadgetCt.Q.ptr, gadgetCt.P.ptr,
                                                      gadgetCt.digits, add0.ptr if add0 is not None else None,
                                                      add1.ptr if add1 is not None else None, ct.Value[0].ptr, ct.Value[1].ptr, cx.npoly))
@@ -83,6 +95,7 @@ class Evaluator:
         """(:431-453) -> (decompQ, decompP): digit i of poly k is row i*npoly + k of each block"""
         beta = self.BaseRNSDecompositionVectorSize(levelQ, levelP)
         rq, rp = self.ringQ.AtLevel(levelQ), self.ringP.AtLevel(levelP)
+        self._rows(levelQ, c2)
         dq, dp = DevicePoly(rq, beta * c2.npoly, levelQ + 1), DevicePoly(rp, beta * c2.npoly, levelP + 1)
         _check(lib().rh_bext_decompose_ntt(self.be._h, levelQ, levelP, c2.ptr, 1 if c2IsNTT else 0, dq.ptr, dp.ptr, c2.npoly))
         return dq, dp
@@ -91,6 +104,7 @@ class Evaluator:
         """(:326-349) on the output of DecomposeNTT"""
         dq, dp = decompQP
         npoly = ct.Value[0].npoly
+        self._rows(levelQ, dq, ct.Value[0], ct.Value[1])
         _check(lib().rh_bext_gadget_product_hoisted(self.be._h, levelQ, gadgetCt.LevelP(), dq.ptr, dp.ptr, gadgetCt.Q.ptr,
                                                     gadgetCt.P.ptr, gadgetCt.digits, ct.Value[0].ptr, ct.Value[1].ptr, npoly))
 
@@ -164,6 +178,7 @@ class Evaluator:
         npoly = ctIn.Value[1].npoly
         tmp = Ciphertext([self.buffer("auto0", ringQ, npoly, level + 1), self.buffer("auto1", ringQ, npoly, level + 1)], is_ntt=True)
         dq, dp = c1DecompQP
+        self._rows(level, dq, ctIn.Value[0], opOut.Value[0], opOut.Value[1])
         _check(lib().rh_bext_gadget_product_hoisted_then_add(self.be._h, level, evk.LevelP(), dq.ptr, dp.ptr, evk.Q.ptr, evk.P.ptr, evk.digits,
                                                              ctIn.Value[0].ptr, None, tmp.Value[0].ptr, tmp.Value[1].ptr, npoly))   # product + Add (:88-89)
         ringQ.AutomorphismNTT(tmp.Value[0], galEl, opOut.Value[0])

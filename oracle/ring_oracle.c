@@ -917,3 +917,54 @@ double orc_time_ntt_forward(int N, int nlimbs, const u64* moduli, int reps, int 
   free(roots); free(data); free(qinv); free(bred);
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* The same work spread over `threads` host threads by (poly, limb) unit: npolys independent polys of nlimbs limbs, each
+ * unit with its own data, units dealt round-robin.  What a goroutine-per-(poly, limb) caller of the reference could reach on
+ * the cores this process may use.  Returns seconds for reps passes over all units. */
+typedef struct { int N, nlimbs, nunits, reps, tid, nthreads; const u64* moduli; u64** roots; u64** data; u64* qinv; u64 (*bred)[2]; } twp_t;
+static void* time_worker_polys(void* arg) {
+  twp_t* w = (twp_t*)arg;
+  for (int r = 0; r < w->reps; r++)
+    for (int u = w->tid; u < w->nunits; u += w->nthreads) {
+      const int l = u % w->nlimbs;
+      orc_ntt_standard(w->data[u], w->data[u], w->N, w->moduli[l], w->qinv[l], w->bred[l], w->roots[l]);
+    }
+  return NULL;
+}
+double orc_time_ntt_forward_polys(int N, int nlimbs, const u64* moduli, int npolys, int reps, int threads) {
+  if (npolys < 1 || nlimbs < 1) return -1.0;
+  const int nunits = npolys * nlimbs;
+  u64** roots = (u64**)calloc((size_t)nlimbs, sizeof(u64*));
+  u64** data = (u64**)calloc((size_t)nunits, sizeof(u64*));
+  u64* qinv = (u64*)calloc((size_t)nlimbs, 8);
+  u64 (*bred)[2] = (u64(*)[2])calloc((size_t)nlimbs, 16);
+  u64* rb = (u64*)malloc((size_t)N * 8);
+  for (int l = 0; l < nlimbs; l++) {
+    roots[l] = (u64*)malloc((size_t)N * 8);
+    u64 ninv;
+    if (orc_gen_ntt_tables(moduli[l], (u64)2 * N, roots[l], rb, &ninv, NULL)) return -1.0;
+    qinv[l] = orc_gen_mred_constant(moduli[l]); orc_gen_bred_constant(moduli[l], bred[l]);
+  }
+  for (int u = 0; u < nunits; u++) {
+    data[u] = (u64*)malloc((size_t)N * 8);
+    u64 s = 0x5eed + (u64)u;
+    for (int i = 0; i < N; i++) { s += 0x9e3779b97f4a7c15ull; u64 z = s; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; z ^= z >> 31; data[u][i] = z % moduli[u % nlimbs]; }
+  }
+  free(rb);
+  if (threads < 1) threads = 1;
+  if (threads > 1024) threads = 1024;
+  pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+  twp_t* args = (twp_t*)calloc((size_t)threads, sizeof(twp_t));
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int t = 0; t < threads; t++) {
+    args[t] = (twp_t){N, nlimbs, nunits, reps, t, threads, moduli, roots, data, qinv, bred};
+    pthread_create(&th[t], NULL, time_worker_polys, &args[t]);
+  }
+  for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  for (int l = 0; l < nlimbs; l++) free(roots[l]);
+  for (int u = 0; u < nunits; u++) free(data[u]);
+  free(roots); free(data); free(qinv); free(bred); free(th); free(args);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -122,6 +122,7 @@ int  orc_ntt3n_backward_fast(const uint64_t* p1, uint64_t* p2, int N, uint64_t q
 
 /* ---- timing helper for bench.py's cpu_baseline leg: runs `reps` forward NTTs of `nlimbs` limbs, returns seconds */
 double orc_time_ntt_forward(int N, int nlimbs, const uint64_t* moduli, int reps, int threads);
+double orc_time_ntt_forward_polys(int N, int nlimbs, const uint64_t* moduli, int npolys, int reps, int threads);
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,29 @@ def test_levels_use_leading_limbs(rh, oracle):
     ring.close()
 
 
+def test_at_level_on_a_batch_with_more_limbs(rh, oracle):
+    # ring.AtLevel(level) on max-level polys (ring/ring.go:192-213): the C ABI strides blocks by level+1 rows, so a single
+    # poly with more limbs works (leading limbs contiguous, the others untouched) and a BATCH is refused instead of being
+    # read with the wrong stride
+    N, mods = 4096, QI60[:4]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(11)
+    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(2)])
+    one = rh.DevicePoly.from_numpy(ring, a[:1])
+    ring.AtLevel(1).NTT(one, one)
+    got = one.numpy()[0]
+    srs = [oracle.SubRingConsts(N, q) for q in mods[:2]]
+    assert np.array_equal(got[:2], np.stack([oracle.ntt(a[0, i], srs[i]) for i in range(2)]))
+    assert np.array_equal(got[2:], a[0, 2:])
+    two = rh.DevicePoly.from_numpy(ring, a)
+    with pytest.raises(rh.RingHipError):
+        ring.AtLevel(1).NTT(two, two)
+    with pytest.raises(rh.RingHipError):
+        ring.AtLevel(1).Add(two, two, two)
+    assert np.array_equal(two.numpy(), a)
+    ring.close()
+
+
 def test_metric_size_properties(rh, oracle):
     # BASELINE metric size: N = 2^16, 16 limbs, batch of 4.  Full-size checks through size-independent properties:
     # (1) INTT(NTT(a)) == a, (2) linearity NTT(a+b) == NTT(a)+NTT(b) mod q, (3) one limb of one poly against the oracle,
