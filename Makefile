@@ -16,7 +16,7 @@ $(LIB): $(SRCS) $(HDRS) $(CSRC)/ntt_tile_asm.inc
 	@mkdir -p $(PKG)/lib
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -mllvm -pragma-unroll-threshold=131072 -fPIC -shared -Iinclude $(SRCS) -o $@
 
-tests/cpp/test_ring_cpp: tests/cpp/test_ring_cpp.cpp include/ringhip.hpp include/ringhip.h $(LIB)
+tests/cpp/test_ring_cpp: tests/cpp/test_ring_cpp.cpp tests/cpp/golden_vectors.inc include/ringhip.hpp include/ringhip.h $(LIB)
 	g++ -O2 -std=c++17 -Iinclude $< -L$(PKG)/lib -lringhip -Wl,-rpath,'$$ORIGIN/../../$(PKG)/lib' -o $@
 
 oracle: oracle/libring_oracle.so

@@ -54,7 +54,6 @@ def parse():
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed region's output")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--lds-pad", type=int, default=0, help="experiment: extra dynamic LDS bytes per workgroup of the fused launch (occupancy sensitivity)")
     ap.add_argument("--asm-cols", type=int, default=-1, help="hand-scheduled column stages (default on)")
     ap.add_argument("--asm", type=int, default=-1, help="1/0: hand-scheduled vs C++ tile kernels; -1 = engine default")
     ap.add_argument("--tune", action="append", default=[], help="key=value for rh_ring_set_tuning (repeatable)")
@@ -190,8 +189,6 @@ def run_ntt(args):
         ring.set_tuning("chunk_polys", args.chunk)
     if args.asm >= 0:
         ring.set_tuning("asm_tile", args.asm)
-    if args.lds_pad > 0:
-        ring.set_tuning("dbg_lds_pad", args.lds_pad)
     if args.asm_cols >= 0:
         ring.set_tuning("asm_cols", args.asm_cols)
     for kv in args.tune:

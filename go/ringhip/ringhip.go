@@ -3,7 +3,9 @@
 // NthRoot) (ring/ring.go:314-356) and NewSubRingWithCustomNTT (ring/subring.go:74-111).
 //
 // NOT COMPILED IN THIS REPOSITORY'S CI: the build image has no Go toolchain (SURVEY F2).  It is the binding a
-// maintainer adds on a machine with Go >= 1.21 (runtime.Pinner) and ROCm; see INTEGRATION.md.
+// maintainer adds on a machine with Go >= 1.21 and ROCm; see INTEGRATION.md.  The same constructors exist, compiled
+// and tested, in the C++ mirror include/ringhip.hpp (tests/cpp/test_ring_cpp.cpp runs all three ring types through the
+// constants handoff these factories use).
 package ringhip
 
 /*
@@ -15,39 +17,109 @@ import "C"
 
 import (
 	"fmt"
+	"runtime"
 	"sync"
 	"unsafe"
 
 	"github.com/tuneinsight/lattigo/v6/ring"
 )
 
-// Transformer implements ring.NumberTheoreticTransformer (ring/ntt.go:17-22) for one SubRing (one modulus).
+// Transformer implements ring.NumberTheoreticTransformer (ring/ntt.go:17-22) for one SubRing (one modulus) of any of the
+// three ring types: Standard (X^N+1), ConjugateInvariant (Z[X+X^-1]/(X^2N+1)) and Matrix (the 3N ring X^N-X^(N/2)+1).
 // The engine handle is created lazily on the first call because the SubRing's NTTTable is filled by
 // generateNTTConstants AFTER the factory runs (SURVEY 3.5, ring/ring.go:385-400).
+//
+// Concurrency: like the reference's transformers a Transformer is immutable after the lazy init and may be called from
+// any number of goroutines (ring/ring.go:192-194): every rh_ntt_* call takes a (stream, scratch) slot of its own inside
+// the engine.  rh_last_error() is thread-local, so the call and the error read are pinned to one OS thread.
 type Transformer struct {
 	s      *ring.SubRing
 	n      int
 	device int
+	kind   C.int
+	omega  uint64 // Matrix rings: the primitive 3N-th root this transformer evaluates at (ring/ntt_3n.go:24 psi3N)
 	once   sync.Once
 	h      *C.rh_ring
 }
 
-// Factory returns the function to pass to ring.NewRingWithCustomNTT.
+// Factory returns the function to pass to ring.NewRingWithCustomNTT for a Standard ring (NthRoot = 2N),
+// replacing ring.NewNumberTheoreticTransformerStandard (ring/ntt.go:46-56).
 func Factory(device int) func(*ring.SubRing, int) ring.NumberTheoreticTransformer {
 	return func(s *ring.SubRing, n int) ring.NumberTheoreticTransformer {
-		return &Transformer{s: s, n: n, device: device}
+		return &Transformer{s: s, n: n, device: device, kind: C.RH_RING_STANDARD}
 	}
 }
 
+// FactoryCI replaces ring.NewNumberTheoreticTransformerConjugateInvariant (ring/ntt.go:80-124): pass it to
+// ring.NewRingWithCustomNTT(N, moduli, FactoryCI(dev), 4*N) (ring/ring.go:282-284).  The SubRing's tables then hold
+// NthRoot/2 = 2N roots of the 4N-th root of unity (ring/subring.go:186-205); the engine receives them as they are.
+//
+// One caveat of staying outside package ring: SubRing.Type() recognises the conjugate-invariant ring by a type switch
+// on the reference's own transformer type (ring/subring.go:114-123) and reports Standard for any other transformer.
+// Callers that branch on Ring.Type() (ring/automorphism.go:113-176, the ckks encoder) need the one-line patch shown in
+// INTEGRATION.md (a `case interface{ IsConjugateInvariant() bool }` arm) or the in-package placement of this file.
+func FactoryCI(device int) func(*ring.SubRing, int) ring.NumberTheoreticTransformer {
+	return func(s *ring.SubRing, n int) ring.NumberTheoreticTransformer {
+		return &Transformer{s: s, n: n, device: device, kind: C.RH_RING_CI}
+	}
+}
+
+// IsConjugateInvariant lets a patched SubRing.Type() recognise the ring type without importing this package.
+func (t *Transformer) IsConjugateInvariant() bool { return t.kind == C.RH_RING_CI }
+
+// Factory3N replaces ring.NewNumberTheoreticTransformer3N (ring/ntt_3n.go:35-79): pass it to
+// ring.NewRingWithCustomNTT(N, moduli, Factory3N(dev), 3*N) -- what ring.NewRing does for N divisible by 3
+// (ring/ring.go:264-272) -- or with NthRoot = N for ring.Matrix (ring/ring.go:299-304).
+//
+// omega: the reference's constructor draws a primitive 3N-th root AT RANDOM (FindPrimitiveRootOfUnity,
+// ring/primes_3n.go:127-149, crypto/rand) and keeps it in the unexported field psi3N (ring/ntt_3n.go:24, :39), so two
+// rings over the same modulus do not share evaluation points.  This factory does exactly the same -- the exported
+// ring.FindPrimitiveRootOfUnity(q, 3N) -- and hands the root to the engine (rh_ring_create's omega3n), which never
+// re-derives it.  The ring's NTT domain is therefore self-consistent, as in the reference.  Omega() reports the root.
+func Factory3N(device int) func(*ring.SubRing, int) ring.NumberTheoreticTransformer {
+	return func(s *ring.SubRing, n int) ring.NumberTheoreticTransformer {
+		om, err := ring.FindPrimitiveRootOfUnity(s.Modulus, uint64(3*n))
+		if err != nil { // same panic as ring/ntt_3n.go:40-42
+			panic(fmt.Sprintf("failed to find primitive 3N-th root: %v", err))
+		}
+		return &Transformer{s: s, n: n, device: device, kind: C.RH_RING_3N, omega: om}
+	}
+}
+
+// Factory3NLike mirrors an EXISTING reference transformer: same omega, hence bit-identical outputs to that CPU
+// transformer (for cross-checks and for rings whose NTT-domain data must stay valid).  psi3N is unexported, but the
+// reference stores it in the transformer's own NTTTable.NthRoot (ring/ntt_3n.go:58-59), and NTTTable's fields are
+// promoted through the embedded base (ring/ntt.go:24-30), so it is readable from outside the package:
+//
+//	ref := ring.NewNumberTheoreticTransformer3N(s, n).(*ring.NumberTheoreticTransformer3N)
+//	omega := ref.NthRoot
+func Factory3NLike(device int, omegaOf func(s *ring.SubRing, n int) uint64) func(*ring.SubRing, int) ring.NumberTheoreticTransformer {
+	return func(s *ring.SubRing, n int) ring.NumberTheoreticTransformer {
+		return &Transformer{s: s, n: n, device: device, kind: C.RH_RING_3N, omega: omegaOf(s, n)}
+	}
+}
+
+// Omega returns the primitive 3N-th root of a Matrix-ring transformer (0 for the other ring types).
+func (t *Transformer) Omega() uint64 { return t.omega }
+
 func (t *Transformer) init() {
 	t.once.Do(func() {
+		runtime.LockOSThread() // rh_last_error() is thread-local
+		defer runtime.UnlockOSThread()
 		s := t.s
 		q := C.uint64_t(s.Modulus)
 		mred := C.uint64_t(s.MRedConstant)
 		bred := [2]C.uint64_t{C.uint64_t(s.BRedConstant[0]), C.uint64_t(s.BRedConstant[1])}
-		ninv := C.uint64_t(s.NInv)
-		rc := C.rh_ring_create(&t.h, C.int(t.device), C.RH_RING_STANDARD, C.int(t.n), 1, &q, &mred, &bred[0], &ninv,
-			(*C.uint64_t)(unsafe.Pointer(&s.RootsForward[0])), (*C.uint64_t)(unsafe.Pointer(&s.RootsBackward[0])), nil)
+		var rc C.int
+		if t.kind == C.RH_RING_3N {
+			om := C.uint64_t(t.omega)
+			rc = C.rh_ring_create(&t.h, C.int(t.device), t.kind, C.int(t.n), 1, &q, &mred, &bred[0], nil, nil, nil, &om)
+		} else {
+			// RootsForward / RootsBackward hold NthRoot/2 words: N for Standard, 2N for ConjugateInvariant
+			ninv := C.uint64_t(s.NInv)
+			rc = C.rh_ring_create(&t.h, C.int(t.device), t.kind, C.int(t.n), 1, &q, &mred, &bred[0], &ninv,
+				(*C.uint64_t)(unsafe.Pointer(&s.RootsForward[0])), (*C.uint64_t)(unsafe.Pointer(&s.RootsBackward[0])), nil)
+		}
 		if rc != 0 {
 			panic(fmt.Sprintf("ringhip: rh_ring_create: %s", C.GoString(C.rh_last_error())))
 		}
@@ -55,14 +127,18 @@ func (t *Transformer) init() {
 }
 
 func (t *Transformer) call(f func(*C.rh_ring, C.int, *C.uint64_t, *C.uint64_t) C.int, p1, p2 []uint64) {
-	if len(p1) < t.n || len(p2) < t.n { // same contract as ring/ntt.go:212-214
+	if len(p1) < t.n || len(p2) < t.n { // same contract as ring/ntt.go:212-214, ring/ntt_3n.go:85-87
 		panic(fmt.Sprintf("cannot NTT: ensure that len(p1)=%d, len(p2)=%d >= N=%d", len(p1), len(p2), t.n))
 	}
 	t.init()
+	// rh_last_error() is thread-local and goroutines migrate between OS threads: pin for the call and the error read
+	// (nanoseconds next to the PCIe round trip of a host-limb transform).
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
 	// p1/p2 are Go slices of plain uint64: passing &p[0] for the duration of the call is allowed by the cgo rules;
-	// the engine copies H2D/D2H inside the call and retains nothing.
+	// the engine copies H2D/D2H inside the call and retains nothing.  p1 and p2 may alias (ring/ntt_3n.go:90-96).
 	if rc := f(t.h, 0, (*C.uint64_t)(unsafe.Pointer(&p1[0])), (*C.uint64_t)(unsafe.Pointer(&p2[0]))); rc != 0 {
-		panic(fmt.Sprintf("ringhip: %s", C.GoString(C.rh_last_error())))
+		panic(fmt.Sprintf("ringhip: status %d: %s", int(rc), C.GoString(C.rh_last_error())))
 	}
 }
 
@@ -79,9 +155,36 @@ func (t *Transformer) BackwardLazy(p1, p2 []uint64) {
 	t.call(func(h *C.rh_ring, l C.int, a, b *C.uint64_t) C.int { return C.rh_ntt_backward_lazy(h, l, a, b) }, p1, p2)
 }
 
-// NewRing is the drop-in for ring.NewRing on power-of-two rings: same Ring type, same methods, NTTs on the GPU.
+// NewRing is the drop-in for ring.NewRing (ring/ring.go:264-272): same Ring type, same methods, NTTs on the GPU.
+// Like the reference it picks the 3N transformer when N is divisible by 3, the standard one otherwise.
 func NewRing(N int, moduli []uint64, device int) (*ring.Ring, error) {
+	if N%3 == 0 {
+		return ring.NewRingWithCustomNTT(N, moduli, Factory3N(device), 3*N)
+	}
 	return ring.NewRingWithCustomNTT(N, moduli, Factory(device), 2*N)
+}
+
+// NewRingConjugateInvariant is the drop-in for ring.NewRingConjugateInvariant (ring/ring.go:282-284).
+func NewRingConjugateInvariant(N int, moduli []uint64, device int) (*ring.Ring, error) {
+	return ring.NewRingWithCustomNTT(N, moduli, FactoryCI(device), 4*N)
+}
+
+// NewRingFromType is the drop-in for ring.NewRingFromType (ring/ring.go:286-308), including its choice of NthRoot = N
+// for ring.Matrix (SURVEY appendix A: the transformer derives everything from 3N itself).
+func NewRingFromType(N int, moduli []uint64, ringType ring.Type, device int) (*ring.Ring, error) {
+	switch ringType {
+	case ring.Standard:
+		return ring.NewRingWithCustomNTT(N, moduli, Factory(device), 2*N)
+	case ring.ConjugateInvariant:
+		return ring.NewRingWithCustomNTT(N, moduli, FactoryCI(device), 4*N)
+	case ring.Matrix:
+		if N%3 != 0 {
+			return nil, fmt.Errorf("matrix ring type requires N to satisfy 3N = 2^a * 3^{b+1} condition, got N=%d", N)
+		}
+		return ring.NewRingWithCustomNTT(N, moduli, Factory3N(device), N)
+	default:
+		return nil, fmt.Errorf("invalid ring type")
+	}
 }
 
 // DeviceRing is the throughput path: a whole ring.Ring (all SubRings at once) mirrored on the device, operating on
@@ -93,25 +196,57 @@ type DeviceRing struct {
 	L int
 }
 
+// NewDeviceRing mirrors a ring.Ring of any type on the device.  For Matrix (3N) rings built with Factory3N the roots are
+// taken from the ring's own transformers so that host-limb and device-batched transforms agree bit for bit; pass the
+// SubRing-to-omega lookup explicitly when the ring was built another way.
 func NewDeviceRing(r *ring.Ring, device int) (*DeviceRing, error) {
+	return NewDeviceRingWithOmega(r, device, nil)
+}
+
+func NewDeviceRingWithOmega(r *ring.Ring, device int, omega []uint64) (*DeviceRing, error) {
 	L := r.ModuliChainLength()
 	N := r.N()
+	kind := C.int(C.RH_RING_STANDARD)
+	tn := N // table words per limb = NthRoot/2
+	switch {
+	case N%3 == 0:
+		kind = C.RH_RING_3N
+	case r.NthRoot() == uint64(4*N):
+		kind, tn = C.RH_RING_CI, 2*N
+	}
 	mod := make([]C.uint64_t, L)
 	mred := make([]C.uint64_t, L)
 	bred := make([]C.uint64_t, 2*L)
-	ninv := make([]C.uint64_t, L)
-	rf := make([]C.uint64_t, L*N)
-	rb := make([]C.uint64_t, L*N)
 	for i, s := range r.SubRings {
-		mod[i], mred[i], ninv[i] = C.uint64_t(s.Modulus), C.uint64_t(s.MRedConstant), C.uint64_t(s.NInv)
+		mod[i], mred[i] = C.uint64_t(s.Modulus), C.uint64_t(s.MRedConstant)
 		bred[2*i], bred[2*i+1] = C.uint64_t(s.BRedConstant[0]), C.uint64_t(s.BRedConstant[1])
-		for j := 0; j < N; j++ {
-			rf[i*N+j], rb[i*N+j] = C.uint64_t(s.RootsForward[j]), C.uint64_t(s.RootsBackward[j])
-		}
 	}
 	d := &DeviceRing{N: N, L: L}
-	if rc := C.rh_ring_create(&d.h, C.int(device), C.RH_RING_STANDARD, C.int(N), C.int(L), &mod[0], &mred[0], &bred[0],
-		&ninv[0], &rf[0], &rb[0], nil); rc != 0 {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	var rc C.int
+	if kind == C.RH_RING_3N {
+		if len(omega) != L {
+			return nil, fmt.Errorf("ringhip: a 3N device ring needs one primitive 3N-th root per modulus (Transformer.Omega())")
+		}
+		om := make([]C.uint64_t, L)
+		for i := range om {
+			om[i] = C.uint64_t(omega[i])
+		}
+		rc = C.rh_ring_create(&d.h, C.int(device), kind, C.int(N), C.int(L), &mod[0], &mred[0], &bred[0], nil, nil, nil, &om[0])
+	} else {
+		ninv := make([]C.uint64_t, L)
+		rf := make([]C.uint64_t, L*tn)
+		rb := make([]C.uint64_t, L*tn)
+		for i, s := range r.SubRings {
+			ninv[i] = C.uint64_t(s.NInv)
+			for j := 0; j < tn; j++ {
+				rf[i*tn+j], rb[i*tn+j] = C.uint64_t(s.RootsForward[j]), C.uint64_t(s.RootsBackward[j])
+			}
+		}
+		rc = C.rh_ring_create(&d.h, C.int(device), kind, C.int(N), C.int(L), &mod[0], &mred[0], &bred[0], &ninv[0], &rf[0], &rb[0], nil)
+	}
+	if rc != 0 {
 		return nil, fmt.Errorf("ringhip: %s", C.GoString(C.rh_last_error()))
 	}
 	return d, nil
@@ -158,9 +293,12 @@ func (d *DeviceRing) MForm(p1, p2 *DevPoly) {
 	d.must(C.rh_ring_vec_op(d.h, C.RH_OP_MFORM, p1.ptr, nil, p2.ptr, C.int(p2.npoly), C.int(p2.limbs-1), nil, nil))
 }
 func (d *DeviceRing) Sync() { d.must(C.rh_ring_sync(d.h)) }
+
+// must turns a non-zero status into the panic the reference raises.  The message is thread-local in the engine; device-ring
+// callers that want the text (not just the status) wrap their call sequence in runtime.LockOSThread.
 func (d *DeviceRing) must(rc C.int) {
 	if rc != 0 {
-		panic(fmt.Sprintf("ringhip: %s", C.GoString(C.rh_last_error())))
+		panic(fmt.Sprintf("ringhip: status %d: %s", int(rc), C.GoString(C.rh_last_error())))
 	}
 }
 

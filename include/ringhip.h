@@ -30,7 +30,9 @@ typedef enum rh_status {
 } rh_status;
 
 typedef enum rh_ring_kind {
-  RH_RING_STANDARD = 0,   /* Z_q[X]/(X^N+1), NumberTheoreticTransformerStandard (ring/ntt.go:31-78)                    */
+  RH_RING_STANDARD = 0,   /* Z_q[X]/(X^N+1), NumberTheoreticTransformerStandard (ring/ntt.go:31-78); N = 2^k, 8 <= N <=
+                             2^17 (MinimumRingDegreeForLoopUnrolledOperations = 8, ring/ring.go:21-23, :318); for N < 16
+                             BackwardLazy returns the reference's non-canonical values in [0, 2q) (ring/ntt.go:197-202) */
   RH_RING_CI = 1,         /* Z_q[X+X^-1]/(X^2N+1), NumberTheoreticTransformerConjugateInvariant (ring/ntt.go:80-124,
                              716-1311); NthRoot = 4N: root tables have 2N entries per limb; ForwardLazy returns the
                              canonical residues (inside the documented range, congruent)                             */
@@ -67,6 +69,22 @@ int rh_ring_get_constants(const rh_ring* r, uint64_t* moduli, uint64_t* mred, ui
 /* all device work of this ring is enqueued on `hip_stream` (a hipStream_t; NULL = the null stream) */
 int rh_ring_set_stream(rh_ring* r, void* hip_stream);
 int rh_ring_sync(rh_ring* r);
+/* Optional: pre-sizes every lazily grown scratch of the ring (rescale, 3N transform) for batches of up to npoly polys of all
+ * limbs, so that no later call allocates (hipMalloc / hipFree synchronise the device and cannot be captured in a HIP graph). */
+int rh_ring_reserve(rh_ring* r, int npoly);
+
+/* ---- concurrency (ring/ring.go:192-194: transformers are immutable, AtLevel views are concurrency-safe) ------------------
+ * A ring handle may be used by any number of OS threads at once (goroutines migrate between threads):
+ *   - rh_ntt_forward/_lazy/backward/_lazy: every call runs on a (stream, scratch) slot of its own taken from a pool in the
+ *     handle; calls on the same or different limbs proceed in parallel and never share device memory;
+ *   - the device-batched entry points only ENQUEUE on the ring's stream: concurrent callers are serialised in stream order;
+ *     the few that use lazily built shared state (rescale, the 3N transform's workspace) take a lock for the enqueue;
+ *   - tables and twiddles are read-only after creation; rh_ring_set_stream / rh_ring_set_tuning configure the handle and are
+ *     not meant to race with calls.
+ * rh_bext / rh_kshard objects carry scratch and plans like the reference's BasisExtender (one ShallowCopy per goroutine,
+ * ring/basis_extension.go:166-183): one object per thread is the intended use; their entry points still lock the object,
+ * so sharing one is safe, merely serial.  Several such objects may share the same rings.
+ * rh_last_error() is thread-local: read it on the thread that got the status (the cgo wrapper locks the OS thread). */
 
 /* ---- device memory (plain hipMalloc'd words; any device pointer from another allocator, e.g. torch, is accepted) */
 int rh_dev_alloc(rh_ring* r, size_t words, uint64_t** dptr);
@@ -93,15 +111,14 @@ int rh_ring_intt(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npol
 /* profiling aid: phase 0 = whole transform, 1 = column kernel only, 2 = tile kernel only (N >= 8192) */
 int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int inverse, int phase);
 /* Tuning knobs: performance only, never results (each non-default setting is covered by a parity test).  Unknown keys
- * return RH_ERR_ARG.  Defaults are the measured optimum on MI355X.
+ * return RH_ERR_ARG.  Defaults are the measured optimum on MI355X.  Set them before the handle is
+ * shared between threads: they are plain fields read by every call.
  *   chunk_polys     polys per span of the fused (column + tile) pipeline: -1 auto (auto_span_rows), 0 = two launches per batch
  *   auto_span_rows  span size of the auto rule in (poly, limb) rows (2048)
  *   asm_tile / asm_cols   1: generated hand-scheduled bodies (default), 0: the C++ kernels
  *   fuse_submul     1: ModDown / rescale subtract-multiply in the forward tile kernel's epilogue (default)
  *   fuse3n          1: 3N rings, split + radix-3 layer fused with the sub-transforms' column stages (default)
- *   perm_inv_shape  3N inverse permutation tile: 32 / 64 (default) / 128 words per block-order run
- *   experiments, off by default: cluster, cluster_wgs_per_cu, cluster_dbg, persistent, group_polys, persist_grid,
- *   persist_unsafe_timing, prefetch, order_mix, cols2, dbg_lds_pad (what did not work) */
+ *   perm_inv_shape  3N inverse permutation tile: 32 / 64 (default) / 128 words per block-order run */
 int rh_ring_set_tuning(rh_ring* r, const char* key, long value);
 
 /* ---- element-wise family (ring/vec_ops.go via ring/operations.go loops): p3 = op(p1, p2 [, p3]) on npoly polys of
@@ -139,6 +156,8 @@ int rh_ring_automorphism(rh_ring* r, int level, const uint64_t* in_dev, uint64_t
 typedef struct rh_bext rh_bext;
 int rh_bext_create(rh_bext** out, rh_ring* ringQ, rh_ring* ringP);
 void rh_bext_destroy(rh_bext* be);
+/* Optional: pre-sizes the extender's scratch for key switches / ModDowns of up to npoly polys at the rings' top levels. */
+int rh_bext_reserve(rh_bext* be, int npoly);
 int rh_bext_modup_q_to_p(rh_bext* be, int levelQ, int levelP, const uint64_t* polQ, uint64_t* polP, int npoly);   /* :188-200 */
 int rh_bext_modup_p_to_q(rh_bext* be, int levelP, int levelQ, const uint64_t* polP, uint64_t* polQ, int npoly);   /* :205-217 */
 int rh_bext_moddown_qp_to_q(rh_bext* be, int levelQ, int levelP, const uint64_t* p1Q, const uint64_t* p1P,

@@ -65,16 +65,46 @@ class SubRing {
   rh_ring* h_; int idx_;
 };
 
+// what a SubRing holds per modulus (ring/subring.go:35-55, NTTTable ring/ntt.go:38-44), concatenated over the limbs:
+// roots_* have N words per limb (Standard) or 2N (ConjugateInvariant, NthRoot = 4N); omega3n is the 3N transformer's psi3N
+struct Constants { std::vector<uint64_t> mred, bred, ninv, roots_fwd, roots_bwd, omega3n; };
+
 class Ring {
  public:
-  // NewRing / NewRingFromType (ring/ring.go:264-308): constants generated with the reference's rules
+  // NewRing / NewRingConjugateInvariant / NewRingFromType(.., Matrix) (ring/ring.go:264-308): constants generated with the
+  // reference's rules.  Type::Matrix: omega3n (one primitive 3N-th root per modulus) may be given, as the Go transformer draws
+  // its own at random (ring/ntt_3n.go:39, primes_3n.go:127-149); default g^((q-1)/3N).
   Ring(int N, const std::vector<uint64_t>& moduli, Type type = Type::Standard, int device = 0, const std::vector<uint64_t>* omega3n = nullptr)
-      : N_(N), moduli_(moduli), level_((int)moduli.size() - 1) {
+      : N_(N), type_(type), moduli_(moduli), level_((int)moduli.size() - 1) {
     rh_ring* h = nullptr;
     check(rh_ring_create_auto(&h, device, (int)type, N, (int)moduli.size(), moduli.data(), omega3n ? omega3n->data() : nullptr));
-    h_.reset(h, rh_ring_destroy);
-    for (int i = 0; i < (int)moduli.size(); ++i) SubRings.emplace_back(h, i, N, moduli[i]);
+    adopt(h);
   }
+  // NewRingWithCustomNTT (ring/ring.go:314-356): the constants handoff -- the engine receives what the host side generated and
+  // never re-derives a root (this is the constructor the cgo factories Factory / FactoryCI / Factory3N use, go/ringhip)
+  Ring(int N, const std::vector<uint64_t>& moduli, Type type, const Constants& c, int device = 0)
+      : N_(N), type_(type), moduli_(moduli), level_((int)moduli.size() - 1) {
+    rh_ring* h = nullptr;
+    auto ptr = [](const std::vector<uint64_t>& v) { return v.empty() ? nullptr : v.data(); };
+    check(rh_ring_create(&h, device, (int)type, N, (int)moduli.size(), moduli.data(), ptr(c.mred), ptr(c.bred), ptr(c.ninv), ptr(c.roots_fwd),
+                         ptr(c.roots_bwd), ptr(c.omega3n)));
+    adopt(h);
+  }
+  Type GetType() const { return type_; }
+  Constants GetConstants() const {
+    const size_t L = moduli_.size(), TN = type_ == Type::ConjugateInvariant ? (size_t)2 * N_ : (size_t)N_;
+    Constants c;
+    c.mred.resize(L); c.bred.resize(2 * L); c.ninv.resize(L);
+    if (type_ == Type::Matrix) {
+      c.omega3n.resize(L);
+      check(rh_ring_get_constants(h_.get(), nullptr, c.mred.data(), c.bred.data(), nullptr, nullptr, nullptr, c.omega3n.data()));
+    } else {
+      c.roots_fwd.resize(L * TN); c.roots_bwd.resize(L * TN);
+      check(rh_ring_get_constants(h_.get(), nullptr, c.mred.data(), c.bred.data(), c.ninv.data(), c.roots_fwd.data(), c.roots_bwd.data(), nullptr));
+    }
+    return c;
+  }
+  void Reserve(int npoly) const { check(rh_ring_reserve(h_.get(), npoly)); }
   int N() const { return N_; }
   int Level() const { return level_; }
   int ModuliChainLength() const { return (int)moduli_.size(); }
@@ -125,7 +155,11 @@ class Ring {
 
   std::vector<SubRing> SubRings;
  private:
-  int N_; std::vector<uint64_t> moduli_; int level_;
+  void adopt(rh_ring* h) {
+    h_.reset(h, rh_ring_destroy);
+    for (int i = 0; i < (int)moduli_.size(); ++i) SubRings.emplace_back(h, i, N_, moduli_[i]);
+  }
+  int N_; Type type_; std::vector<uint64_t> moduli_; int level_;
   std::shared_ptr<rh_ring> h_;
 };
 
@@ -148,6 +182,7 @@ inline std::vector<uint64_t> Poly::download() const {
 class BasisExtender {
  public:
   BasisExtender(const Ring& q, const Ring& p) { rh_bext* h = nullptr; check(rh_bext_create(&h, q.handle(), p.handle())); h_.reset(h, rh_bext_destroy); }
+  void Reserve(int npoly) const { check(rh_bext_reserve(h_.get(), npoly)); }
   void ModUpQtoP(int lq, int lp, const Poly& polQ, Poly& polP) const { check(rh_bext_modup_q_to_p(h_.get(), lq, lp, polQ.data(), polP.data(), polQ.npoly())); }
   void ModUpPtoQ(int lp, int lq, const Poly& polP, Poly& polQ) const { check(rh_bext_modup_p_to_q(h_.get(), lp, lq, polP.data(), polQ.data(), polP.npoly())); }
   void ModDownQPtoQ(int lq, int lp, const Poly& q1, const Poly& p1, Poly& q2) const { check(rh_bext_moddown_qp_to_q(h_.get(), lq, lp, q1.data(), p1.data(), q2.data(), q1.npoly())); }

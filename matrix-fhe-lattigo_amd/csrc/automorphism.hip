@@ -57,7 +57,7 @@ extern "C" int rh_ring_automorphism_ntt(rh_ring* r, int level, const uint64_t* i
   const unsigned rows = (unsigned)npoly * (level + 1);
   if (!rows) return RH_OK;
   unsigned chunks = ((unsigned)r->N + 1023) / 1024; if (chunks > 64) chunks = 64;
-  automorphism_ntt_kernel<<<dim3(rows, chunks), 256, 0, r->stream>>>(in, out, r->logN, (u32)(gen & (2 * (u64)r->N - 1)), add_lazy ? 1 : 0);
+  automorphism_ntt_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(in, out, r->logN, (u32)(gen & (2 * (u64)r->N - 1)), add_lazy ? 1 : 0);
   return done("automorphism_ntt_kernel");
 }
 extern "C" int rh_ring_automorphism(rh_ring* r, int level, const uint64_t* in, uint64_t gen, uint64_t* out, int npoly) {
@@ -65,6 +65,6 @@ extern "C" int rh_ring_automorphism(rh_ring* r, int level, const uint64_t* in, u
   const unsigned rows = (unsigned)npoly * (level + 1);
   if (!rows) return RH_OK;
   unsigned chunks = ((unsigned)r->N + 1023) / 1024; if (chunks > 64) chunks = 64;
-  automorphism_coeff_kernel<<<dim3(rows, chunks), 256, 0, r->stream>>>(in, out, r->logN, gen, r->d_consts, level + 1);
+  automorphism_coeff_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(in, out, r->logN, gen, r->d_consts, level + 1);
   return done("automorphism_coeff_kernel");
 }

@@ -173,6 +173,7 @@ struct rh_bext {
   rh_ring* Q = nullptr; rh_ring* P = nullptr;
   std::map<std::array<int, 5>, BextPlan> plans;
   u64* buf[9] = {}; size_t buf_words[9] = {};      // 0,1: ModDownNTT buffers; 2..8: gadget product (keyswitch.hip)
+  std::recursive_mutex mu;
 };
 
 template <class T>
@@ -252,6 +253,18 @@ static int ensure_buf(rh_bext* be, int which, size_t words) {
   return 0;
 }
 
+std::recursive_mutex& rh_bext_mutex(rh_bext* be) { return be->mu; }
+// Pre-sizes the extender's scratch for key switches / ModDowns of up to npoly polys at the rings' top levels
+extern "C" int rh_bext_reserve(rh_bext* be, int npoly) {
+  if (!be || npoly < 0) return rh_fail(RH_ERR_ARG, "rh_bext_reserve: bad argument");
+  RhBextGuard guard(be);
+  (void)hipSetDevice(be->Q->device);
+  const size_t N = be->Q->N, wq = (size_t)npoly * be->Q->L * N, wp = be->P ? (size_t)npoly * be->P->L * N : 0;
+  const size_t beta = be->P ? (size_t)(be->Q->L + be->P->L - 1) / be->P->L : 1;
+  const size_t need[9] = {2 * wq, 2 * wp, wq, beta * wq, beta * wp, 2 * wp, 0, wq, wq};
+  for (int i = 0; i < 9; ++i) if (need[i]) if (int rc = ensure_buf(be, i, need[i])) return rc;
+  return RH_OK;
+}
 rh_ring* rh_bext_ringQ(rh_bext* be) { return be->Q; }
 rh_ring* rh_bext_ringP(rh_bext* be) { return be->P; }
 int rh_bext_scratch(rh_bext* be, int which, size_t words, u64** out) {
@@ -294,7 +307,7 @@ static int launch_plan(rh_bext* be, const BextPlan& p, const u64* in, int in_row
   if (npoly <= 0) return RH_OK;
   dim3 grid((N + 255) / 256, npoly);
   (void)hipGetLastError();
-  bext_dispatch(grid, R->stream, p, in, in_rows, src_limb0, out0, out0_rows, out1, out1_rows, other, other_rows, N, add_mode);
+  bext_dispatch(grid, rh_stream(R), p, in, in_rows, src_limb0, out0, out0_rows, out1, out1_rows, other, other_rows, N, add_mode);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "bext_kernel launch failed: %s", hipGetErrorString(e));
   return RH_OK;
@@ -309,26 +322,33 @@ static int check_levels(rh_bext* be, int levelQ, int levelP, bool needP) {
   }
   if (levelQ + 1 > 32 || (needP && levelP + 1 > 32)) return rh_fail(RH_ERR_ARG, "basis extension supports at most 32 source limbs (ring/basis_extension.go:285)");
   (void)hipSetDevice(be->Q->device);
-  if (be->P) be->P->stream = be->Q->stream;
   return 0;
 }
 
 extern "C" int rh_bext_modup_q_to_p(rh_bext* be, int levelQ, int levelP, const uint64_t* polQ, uint64_t* polP, int npoly) {
+  if (!be) return rh_fail(RH_ERR_ARG, "null basis extender");
+  RhBextGuard guard(be);
   if (int rc = check_levels(be, levelQ, levelP, true)) return rc;
   BextPlan* p; if (int rc = get_modup_plan(be, 0, 0, levelQ, levelP, &p)) return rc;
   return launch_plan(be, *p, polQ, levelQ + 1, 0, polP, levelP + 1, nullptr, 0, nullptr, 0, npoly, BEXT_ADD_CRED);
 }
 extern "C" int rh_bext_modup_p_to_q(rh_bext* be, int levelP, int levelQ, const uint64_t* polP, uint64_t* polQ, int npoly) {
+  if (!be) return rh_fail(RH_ERR_ARG, "null basis extender");
+  RhBextGuard guard(be);
   if (int rc = check_levels(be, levelQ, levelP, true)) return rc;
   BextPlan* p; if (int rc = get_modup_plan(be, 0, 1, levelP, levelQ, &p)) return rc;
   return launch_plan(be, *p, polP, levelP + 1, 0, polQ, levelQ + 1, nullptr, 0, nullptr, 0, npoly, BEXT_ADD_CRED);
 }
 extern "C" int rh_bext_moddown_qp_to_q(rh_bext* be, int levelQ, int levelP, const uint64_t* p1Q, const uint64_t* p1P, uint64_t* p2Q, int npoly) {
+  if (!be) return rh_fail(RH_ERR_ARG, "null basis extender");
+  RhBextGuard guard(be);
   if (int rc = check_levels(be, levelQ, levelP, true)) return rc;
   BextPlan* p; if (int rc = get_modup_plan(be, 1, 1, levelP, levelQ, &p)) return rc;
   return launch_plan(be, *p, p1P, levelP + 1, 0, p2Q, levelQ + 1, nullptr, 0, p1Q, levelQ + 1, npoly, BEXT_ADD_CRED);
 }
 extern "C" int rh_bext_moddown_qp_to_p(rh_bext* be, int levelQ, int levelP, const uint64_t* p1Q, const uint64_t* p1P, uint64_t* p2P, int npoly) {
+  if (!be) return rh_fail(RH_ERR_ARG, "null basis extender");
+  RhBextGuard guard(be);
   if (int rc = check_levels(be, levelQ, levelP, true)) return rc;
   BextPlan* p; if (int rc = get_modup_plan(be, 1, 0, levelQ, levelP, &p)) return rc;
   return launch_plan(be, *p, p1Q, levelQ + 1, 0, p2P, levelP + 1, nullptr, 0, p1P, levelP + 1, npoly, BEXT_ADD_CRED);
@@ -339,6 +359,8 @@ extern "C" int rh_bext_moddown_qp_to_q_ntt(rh_bext* be, int levelQ, int levelP, 
   return rh_bext_moddown_ntt_add(be, levelQ, levelP, p1Q, p1P, p2Q, npoly, nullptr);
 }
 int rh_bext_moddown_ntt_add(rh_bext* be, int levelQ, int levelP, const u64* p1Q, const u64* p1P, u64* p2Q, int npoly, const u64* addend) {
+  if (!be) return rh_fail(RH_ERR_ARG, "null basis extender");
+  RhBextGuard guard(be);
   if (int rc = check_levels(be, levelQ, levelP, true)) return rc;
   if (be->Q->kind != RH_RING_STANDARD || be->P->kind != RH_RING_STANDARD) return rh_fail(RH_ERR_UNSUPPORTED, "ModDownQPtoQNTT needs standard rings");
   const size_t N = be->Q->N;
@@ -366,6 +388,8 @@ int rh_bext_moddown_ntt_add(rh_bext* be, int levelQ, int levelP, const u64* p1Q,
 // p1P holds both P parts back to back ([2][npoly][levelP+1][N]); Q parts, outputs and addends are separate blocks.
 int rh_bext_moddown_ntt_pair(rh_bext* be, int levelQ, int levelP, const u64* q0, const u64* q1, const u64* p1P, u64* out0, u64* out1,
                              int npoly, const u64* add0, const u64* add1) {
+  if (!be) return rh_fail(RH_ERR_ARG, "null basis extender");
+  RhBextGuard guard(be);
   if (int rc = check_levels(be, levelQ, levelP, true)) return rc;
   const size_t N = be->Q->N, wq = (size_t)npoly * (levelQ + 1) * N, wp = (size_t)npoly * (levelP + 1) * N;
   if (!rh_can_fuse_submul(be->Q) || be->P->kind != RH_RING_STANDARD) {          // small rings: component by component
@@ -389,6 +413,8 @@ int rh_bext_moddown_ntt_pair(rh_bext* be, int levelQ, int levelP, const u64* q0,
 // DecomposeAndSplit (:381-502)
 extern "C" int rh_bext_decompose_and_split(rh_bext* be, int levelQ, int levelP, int nbPi, int digit, const uint64_t* p0Q,
                                            uint64_t* p1Q, uint64_t* p1P, int npoly) {
+  if (!be) return rh_fail(RH_ERR_ARG, "null basis extender");
+  RhBextGuard guard(be);
   if (int rc = check_levels(be, levelQ, levelP, be && be->P != nullptr)) return rc;
   if (nbPi < 1 || digit < 0) return rh_fail(RH_ERR_ARG, "DecomposeAndSplit: bad nbPi/digit");
   rh_ring* RQ = be->Q; rh_ring* RP = be->P;
@@ -442,7 +468,7 @@ extern "C" int rh_bext_decompose_and_split(rh_bext* be, int levelQ, int levelP, 
   if (decompLvl < 0) {
     dim3 grid((N + 255) / 256, npoly);
     (void)hipGetLastError();
-    bext_sign_copy_kernel<<<grid, 256, 0, RQ->stream>>>(p0Q, levelQ + 1, st, p.qd, p.ntgt, p.d_sign, p1Q, levelQ + 1, p1P, nP, N);
+    bext_sign_copy_kernel<<<grid, 256, 0, rh_stream(RQ)>>>(p0Q, levelQ + 1, st, p.qd, p.ntgt, p.d_sign, p1Q, levelQ + 1, p1P, nP, N);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "bext_sign_copy_kernel launch failed: %s", hipGetErrorString(e));
     return RH_OK;

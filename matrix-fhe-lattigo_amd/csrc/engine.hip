@@ -23,6 +23,19 @@ int rh_fail(int code, const char* fmt, ...) {
   return code;
 }
 extern "C" const char* rh_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------ per-call context
+static thread_local hipStream_t tl_stream = nullptr;
+static thread_local bool tl_has_stream = false;
+static thread_local u64* tl_ws = nullptr;
+static thread_local size_t tl_ws_words = 0;
+hipStream_t rh_stream(const rh_ring* r) { return tl_has_stream ? tl_stream : rh_stream(r); }
+u64* rh_ws_override(size_t words) { return (tl_ws && tl_ws_words >= words) ? tl_ws : nullptr; }
+RhCallScope::RhCallScope(hipStream_t st, u64* ws, size_t ws_words) : prev_st(tl_stream), prev_has(tl_has_stream), prev_ws(tl_ws), prev_words(tl_ws_words) {
+  tl_stream = st; tl_has_stream = true;
+  if (ws) { tl_ws = ws; tl_ws_words = ws_words; }
+}
+RhCallScope::~RhCallScope() { tl_stream = prev_st; tl_has_stream = prev_has; tl_ws = prev_ws; tl_ws_words = prev_words; }
 extern "C" int rh_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
 // ------------------------------------------------------------------------------------------------ table layout
@@ -84,7 +97,8 @@ int rh_upload_consts(rh_ring* r, const std::vector<LimbConsts>& hc) { return upl
 // ------------------------------------------------------------------------------------------------ ring construction
 static int validate_degree(int kind, int N) {
   if (kind == RH_RING_STANDARD || kind == RH_RING_CI) {
-    if (N < 16 || (N & (N - 1)) != 0 || N > (1 << 17)) return rh_fail(RH_ERR_ARG, "invalid ring degree: N=%d must be a power of two in [16, 2^17]", N);
+    // MinimumRingDegreeForLoopUnrolledOperations = 8 (ring/ring.go:21-23, :318)
+    if (N < 8 || (N & (N - 1)) != 0 || N > (1 << 17)) return rh_fail(RH_ERR_ARG, "invalid ring degree: must be a power of 2 greater than 8 (and at most 2^17), got N=%d", N);
     return 0;
   }
   if (kind == RH_RING_3N) {
@@ -156,6 +170,15 @@ extern "C" int rh_ring_create(rh_ring** out, int device, int kind, int N, int L,
       }
     }
     if (!rc) rc = rh_std_upload_tables(r, fs, is, &mont, lastw);
+    if (!rc && N < 16) {
+      std::vector<u64> bm((size_t)L * N);
+      for (int i = 0; i < L; ++i) for (int j = 0; j < N; ++j) {
+        size_t src = (size_t)j;
+        if (kind == RH_RING_CI && j > 0) { int hb = 31 - __builtin_clz((unsigned)j); src = (size_t)j + ((size_t)1 << hb); }
+        bm[(size_t)i * N + j] = roots_bwd[(size_t)i * TN + src];
+      }
+      rc = upload(&r->d_tw_inv_mont, bm);
+    }
     if (!rc && kind == RH_RING_CI) rc = upload(&r->d_cifold, fold);
   } else {
     if (!omega3n) { delete r; return rh_fail(RH_ERR_ARG, "rh_ring_create: 3N ring needs omega3n"); }
@@ -163,7 +186,6 @@ extern "C" int rh_ring_create(rh_ring** out, int device, int kind, int N, int L,
     rc = rh_ring3n_setup(r, hc);
   }
   if (!rc) rc = upload(&r->d_consts, hc);
-  if (!rc && hipMalloc((void**)&r->d_scratch, (size_t)2 * N * sizeof(u64)) != hipSuccess) rc = rh_fail(RH_ERR_NOMEM, "hipMalloc scratch failed");
   if (rc) { rh_ring_destroy(r); return rc; }
   r->hconsts = hc;
   *out = r;
@@ -199,8 +221,13 @@ extern "C" int rh_ring_create_auto(rh_ring** out, int device, int kind, int N, i
 extern "C" void rh_ring_destroy(rh_ring* r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
-  void* ptrs[] = {r->d_cifold, r->d_consts, r->d_tw_fwd, r->d_tw_inv, r->d_tw_fwd_mont, r->d_twk_fwd, r->d_twk_inv, r->d_twk_fwd_mont, r->d_lastw, r->d_scratch, r->d_rowcnt, r->d_cl};
+  void* ptrs[] = {r->d_cifold, r->d_consts, r->d_tw_fwd, r->d_tw_inv, r->d_tw_fwd_mont, r->d_twk_fwd, r->d_twk_inv, r->d_twk_fwd_mont, r->d_lastw, r->d_tw_inv_mont};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (RhHostSlot* sl : r->all_slots) {
+    if (sl->buf) (void)hipFree(sl->buf);
+    if (sl->stream) (void)hipStreamDestroy(sl->stream);
+    delete sl;
+  }
   rh_rescale_teardown(r);
   for (int i = 0; i < 2; ++i) if (r->d_rs[i]) (void)hipFree(r->d_rs[i]);
   rh_ring3n_teardown(r);
@@ -223,22 +250,8 @@ extern "C" int rh_ring_get_constants(const rh_ring* r, uint64_t* moduli, uint64_
 extern "C" int rh_ring_set_stream(rh_ring* r, void* s) { if (!r) return rh_fail(RH_ERR_ARG, "null ring"); r->stream = (hipStream_t)s; return RH_OK; }
 extern "C" int rh_ring_sync(rh_ring* r) {
   if (!r) return rh_fail(RH_ERR_ARG, "null ring");
-  hipError_t e = hipStreamSynchronize(r->stream);
+  hipError_t e = hipStreamSynchronize(rh_stream(r));
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "hipStreamSynchronize: %s", hipGetErrorString(e));
-  if (r->d_cl) {                          // single-pass transform: bounded hand-off waits report here
-    unsigned flag = 0;
-    if (hipMemcpy(&flag, r->d_cl + 8, sizeof(flag), hipMemcpyDeviceToHost) == hipSuccess && flag) {
-      (void)hipMemset(r->d_cl + 8, 0, sizeof(flag));
-      return rh_fail(RH_ERR_DEVICE, "single-pass NTT: a hand-off wait timed out (results of the last batch are invalid)");
-    }
-  }
-  if (r->d_rowcnt) {                      // the persistent pipeline's bounded waits report here
-    unsigned flag = 0;
-    if (hipMemcpy(&flag, r->d_rowcnt + r->err_index, sizeof(flag), hipMemcpyDeviceToHost) == hipSuccess && flag) {
-      (void)hipMemset(r->d_rowcnt + r->err_index, 0, sizeof(flag));
-      return rh_fail(RH_ERR_DEVICE, "persistent NTT pipeline: a hand-off wait timed out (results of the last batch are invalid)");
-    }
-  }
   return RH_OK;
 }
 
@@ -252,15 +265,15 @@ extern "C" int rh_dev_alloc(rh_ring* r, size_t words, uint64_t** dptr) {
 extern "C" int rh_dev_free(rh_ring* /*r: unused, may already be destroyed*/, uint64_t* dptr) { if (dptr) (void)hipFree(dptr); return RH_OK; }
 extern "C" int rh_dev_upload(rh_ring* r, uint64_t* dst, const uint64_t* src, size_t words) {
   if (!r || !dst || !src) return rh_fail(RH_ERR_ARG, "rh_dev_upload: null argument");
-  hipError_t e = hipMemcpyAsync(dst, src, words * 8, hipMemcpyHostToDevice, r->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+  hipError_t e = hipMemcpyAsync(dst, src, words * 8, hipMemcpyHostToDevice, rh_stream(r));
+  if (e == hipSuccess) e = hipStreamSynchronize(rh_stream(r));
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "upload: %s", hipGetErrorString(e));
   return RH_OK;
 }
 extern "C" int rh_dev_download(rh_ring* r, uint64_t* dst, const uint64_t* src, size_t words) {
   if (!r || !dst || !src) return rh_fail(RH_ERR_ARG, "rh_dev_download: null argument");
-  hipError_t e = hipMemcpyAsync(dst, src, words * 8, hipMemcpyDeviceToHost, r->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+  hipError_t e = hipMemcpyAsync(dst, src, words * 8, hipMemcpyDeviceToHost, rh_stream(r));
+  if (e == hipSuccess) e = hipStreamSynchronize(rh_stream(r));
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "download: %s", hipGetErrorString(e));
   return RH_OK;
 }
@@ -272,17 +285,6 @@ static int check_launch(const char* what) {
   return RH_OK;
 }
 
-template <class P>
-static void launch_fwd_cols2(int S1, dim3 grid, hipStream_t st, const u64* in, u64* out, const typename P::tw_t* tw,
-                             const LimbConsts* c, int L, int logN) {
-  switch (S1) {
-    case 1: ntt_fwd_cols2<P, 1><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
-    case 2: ntt_fwd_cols2<P, 2><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
-    case 3: ntt_fwd_cols2<P, 3><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
-    case 4: ntt_fwd_cols2<P, 4><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN); break;
-    case 5: ntt_fwd_cols<P, 5><<<dim3(grid.x * 2), 256, 0, st>>>(in, out, tw, c, L, logN, 0); break;   // 64 coefficients/thread: keep one column
-  }
-}
 template <class P>
 static void launch_fwd_cols(int S1, dim3 grid, hipStream_t st, const u64* in, u64* out, const typename P::tw_t* tw,
                             const LimbConsts* c, int L, int logN, int Ls = 0) {
@@ -313,13 +315,15 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
   const int logN = r->logN, N = r->N;
   const size_t toff = (size_t)limb0 * N;
   const LimbConsts* c = r->d_consts + limb0;
-  hipStream_t st = r->stream;
+  hipStream_t st = rh_stream(r);
   const unsigned rows = (unsigned)npoly * (unsigned)Lrows;
   if (rows == 0) return RH_OK;
   if (logN < LT) {
     if (!inverse) {
       if (lazy) ntt_fwd_small<MontPolicy><<<rows, 256, 0, st>>>(in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN, 0);
       else      ntt_fwd_small<ShoupPolicy><<<rows, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, logN, 1);
+    } else if (lazy && logN < 4 && r->d_tw_inv_mont && r->kind == RH_RING_STANDARD) {
+      ntt_inv_small_lazy_mont<<<rows, 64, 0, st>>>(in, out, r->d_tw_inv_mont + toff, c, Lrows, logN);   // N = 8: BackwardLazy is not canonical
     } else {
       ntt_inv_small<<<rows, 256, 0, st>>>(in, out, r->d_tw_inv + toff, c, Lrows, logN, r->inv_scale ? 1 : 0);
     }
@@ -333,7 +337,6 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
       dim3 g1(rows * 16);
       if (phase != 2) {
         if (lazy) launch_fwd_cols<MontPolicy>(S1, g1, st, in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN, Ls);
-        else if (r->cols2) launch_fwd_cols2<ShoupPolicy>(S1, dim3(rows * 8), st, in, out, r->d_tw_fwd + toff, c, Lrows, logN);
         else if (S1 == 4 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<4><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
         else if (S1 == 3 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<3><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
         else if (S1 == 2 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<2><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
@@ -367,15 +370,14 @@ template <int S1>
 static void launch_fused(rh_ring* r, const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n2, int npoly2,
                          size_t toff, const LimbConsts* c, int Lrows) {
   const unsigned grid = n1 > n2 ? n1 : n2;
-  if (r->asm_tile && r->prefetch)
-    ntt_fwd_fused_pre<S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN);
-  else if (r->asm_tile && S1 >= 2 && S1 <= 4 && r->asm_cols)
-    ntt_fwd_fused_asm<S1, true><<<grid, 256, (size_t)r->dbg_lds_pad, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN, r->order_mix);
+  hipStream_t st = rh_stream(r);
+  if (r->asm_tile && S1 >= 2 && S1 <= 4 && r->asm_cols)
+    ntt_fwd_fused_asm<S1, true><<<grid, 256, 0, st>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN);
   else if (r->asm_tile)
-    ntt_fwd_fused_asm<S1, false><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN, r->order_mix);
+    ntt_fwd_fused_asm<S1, false><<<grid, 256, 0, st>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN);
   else
-    ntt_fwd_fused<ShoupPolicy, S1><<<grid, 256, 0, r->stream>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff,
-                                                             c, Lrows, r->logN, 1);
+    ntt_fwd_fused<ShoupPolicy, S1><<<grid, 256, 0, st>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff,
+                                                      c, Lrows, r->logN, 1);
 }
 
 // Forward canonical transform of a large batch: software pipeline over spans of `chunk` polys in ONE stream; launch j
@@ -402,43 +404,15 @@ static int std_ntt_fwd_pipelined(rh_ring* r, const u64* in, u64* out, int npoly,
   return check_launch("ntt_fwd_fused");
 }
 
-// Single-launch persistent pipeline (ntt_fwd_persistent).  Grid = number of workgroups that are resident at once.
-template <int S1>
-static int launch_persistent(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, size_t toff, const LimbConsts* c) {
-  if (r->persist_grid == 0) {
-    int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ntt_fwd_persistent<S1>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r->device) != hipSuccess || cus < 1) cus = 1;
-    if (per_cu > 4) per_cu = 4;                     // LDS (34 KiB) and 125 VGPRs admit 4; never ask for more
-    r->persist_grid = per_cu * cus;
-  }
-  const size_t rows = (size_t)npoly * Lrows;
-  if (r->rowcnt_words < rows + 1) {
-    if (r->d_rowcnt) (void)hipFree(r->d_rowcnt);
-    r->d_rowcnt = nullptr; r->rowcnt_words = 0;
-    if (hipMalloc((void**)&r->d_rowcnt, (rows + 1) * sizeof(unsigned)) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc(row counters) failed");
-    r->rowcnt_words = rows + 1;
-    (void)hipMemsetAsync(r->d_rowcnt + rows, 0, sizeof(unsigned), r->stream);       // error word lives behind the counters
-    r->err_index = rows;
-  }
-  (void)hipMemsetAsync(r->d_rowcnt, 0, rows * sizeof(unsigned), r->stream);
-  unsigned grid = (unsigned)r->persist_grid;
-  const size_t items = rows * 16;
-  if (items < grid) grid = (unsigned)items;
-  ntt_fwd_persistent<S1><<<grid, 256, 0, r->stream>>>(in, out, npoly, r->group_polys, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows,
-                                                      r->logN, r->d_rowcnt, r->d_rowcnt + r->err_index, r->persist_unsafe);
-  return check_launch("ntt_fwd_persistent");
-}
-
 template <int S1>
 static void launch_inv_fused(rh_ring* r, const u64* in1, u64* out1, unsigned n1, int npoly1, u64* data2, unsigned n2,
                              size_t toff, int limb0, const LimbConsts* c, int Lrows) {
   const unsigned grid = n1 > n2 ? n1 : n2;
   if (S1 >= 2 && S1 <= 4 && r->asm_cols)
-    ntt_inv_fused_asm<S1, true><<<grid, 256, 0, r->stream>>>(in1, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff,
+    ntt_inv_fused_asm<S1, true><<<grid, 256, 0, rh_stream(r)>>>(in1, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff,
                                                              r->d_lastw + limb0, c, Lrows, r->logN);
   else
-    ntt_inv_fused_asm<S1, false><<<grid, 256, 0, r->stream>>>(in1, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff,
+    ntt_inv_fused_asm<S1, false><<<grid, 256, 0, rh_stream(r)>>>(in1, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff,
                                                               r->d_lastw + limb0, c, Lrows, r->logN);
 }
 // Inverse transform of a large batch: launch j = tile stages of span j fused with column stages (+ N^-1) of span j-1.
@@ -464,51 +438,7 @@ static int std_ntt_inv_pipelined(rh_ring* r, const u64* in, u64* out, int npoly,
   return check_launch("ntt_inv_fused_asm");
 }
 
-// Single-pass forward transform (ntt_fwd_cluster).  Counters: [0,8) per-XCD ticket heads, [8] error word, [16, 16+rows) row counters.
-template <int S1>
-static int launch_cluster(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, size_t toff, const LimbConsts* c) {
-  const size_t rows = (size_t)npoly * Lrows;
-  if (r->cl_words < rows + 16) {
-    if (r->d_cl) (void)hipFree(r->d_cl);
-    r->d_cl = nullptr; r->cl_words = 0;
-    if (hipMalloc((void**)&r->d_cl, (rows + 16) * sizeof(unsigned)) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc(cluster counters) failed");
-    r->cl_words = rows + 16;
-  }
-  (void)hipMemsetAsync(r->d_cl, 0, (rows + 16) * sizeof(unsigned), r->stream);
-  int cus = 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r->device) != hipSuccess || cus < 1) cus = 256;
-  unsigned grid = (unsigned)(cus * (r->cluster_wgs_per_cu > 0 ? r->cluster_wgs_per_cu : 4));
-  if (grid < 128) grid = 128;                      // >= 16 workgroups per XCD (progress condition)
-  ntt_fwd_cluster<S1><<<grid, 256, 0, r->stream>>>(in, out, (unsigned)rows, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN,
-                                                   r->d_cl, r->d_cl + 16, r->d_cl + 8, r->cluster_dbg);
-  return check_launch("ntt_fwd_cluster");
-}
-
 int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase) {
-  if (r->cluster && r->logN > LT && phase == 0 && !inverse && !lazy && npoly >= 1) {
-    (void)hipGetLastError();
-    const size_t toff = (size_t)limb0 * r->N;
-    const LimbConsts* c = r->d_consts + limb0;
-    switch (r->logN - LT) {
-      case 1: return launch_cluster<1>(r, in, out, npoly, Lrows, toff, c);
-      case 2: return launch_cluster<2>(r, in, out, npoly, Lrows, toff, c);
-      case 3: return launch_cluster<3>(r, in, out, npoly, Lrows, toff, c);
-      case 4: return launch_cluster<4>(r, in, out, npoly, Lrows, toff, c);
-      case 5: return launch_cluster<5>(r, in, out, npoly, Lrows, toff, c);
-    }
-  }
-  if (r->persistent && r->logN > LT && phase == 0 && !inverse && !lazy && npoly >= 1) {
-    (void)hipGetLastError();
-    const size_t toff = (size_t)limb0 * r->N;
-    const LimbConsts* c = r->d_consts + limb0;
-    switch (r->logN - LT) {
-      case 1: return launch_persistent<1>(r, in, out, npoly, Lrows, toff, c);
-      case 2: return launch_persistent<2>(r, in, out, npoly, Lrows, toff, c);
-      case 3: return launch_persistent<3>(r, in, out, npoly, Lrows, toff, c);
-      case 4: return launch_persistent<4>(r, in, out, npoly, Lrows, toff, c);
-      case 5: return launch_persistent<5>(r, in, out, npoly, Lrows, toff, c);
-    }
-  }
   int chunk = r->chunk_polys;
   if (chunk < 0) {                                  // auto: pipeline batches of more than ~2048 limb rows in spans of ~2048 rows
     const int c = r->auto_span_rows / (Lrows > 0 ? Lrows : 1) > 0 ? r->auto_span_rows / Lrows : 1;   // 128 polys at 16 limbs (measured optimum: 64..128)
@@ -524,14 +454,11 @@ int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows,
 
 // Forward canonical transform, in place, of limbs [limb0, limb0 + Lrows) of each poly of a block that has Ls >= Lrows
 // rows per poly (`data` points at row limb0 of poly 0): lets a caller skip rows it will overwrite anyway (the digit's own
-// limbs in DecomposeSingleNTT).  N >= 4096 standard rings; cols2 / cluster / pipeline variants are not involved.
+// limbs in DecomposeSingleNTT).  N >= 4096 standard rings; the pipelined launches are not involved.
 int rh_std_ntt_fwd_strided(rh_ring* r, u64* data, int npoly, int Lrows, int limb0, int Ls) {
   if (r->logN < LT || Ls < Lrows) return rh_fail(RH_ERR_ARG, "strided transform needs N >= 4096 and a row stride >= the row count");
   if (Lrows <= 0 || npoly <= 0) return RH_OK;
-  const int saved = r->cols2; r->cols2 = 0;
-  const int rc = std_ntt_launch_span(r, data, data, npoly, Lrows, limb0, false, false, 0, Ls);
-  r->cols2 = saved;
-  return rc;
+  return std_ntt_launch_span(r, data, data, npoly, Lrows, limb0, false, false, 0, Ls);
 }
 
 bool rh_can_fuse_submul(const rh_ring* r) { return r->kind == RH_RING_STANDARD && r->logN >= LT && r->fuse_submul; }
@@ -547,11 +474,11 @@ int rh_std_ntt_expand_cols_launch(rh_ring* r, const u64* tmp, u64* buf, int npol
   const RescaleLimb* T = (const RescaleLimb*)table_dev;
   const dim3 g(rows * 16);
   switch (S1) {
-    case 1: ntt_fwd_cols_expand<1><<<g, 256, 0, r->stream>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;
-    case 2: ntt_fwd_cols_expand<2><<<g, 256, 0, r->stream>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;
-    case 3: ntt_fwd_cols_expand<3><<<g, 256, 0, r->stream>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;
-    case 4: ntt_fwd_cols_expand<4><<<g, 256, 0, r->stream>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;
-    case 5: ntt_fwd_cols_expand<5><<<dim3(rows * 16), 256, 0, r->stream>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;
+    case 1: ntt_fwd_cols_expand<1><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;
+    case 2: ntt_fwd_cols_expand<2><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;
+    case 3: ntt_fwd_cols_expand<3><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;
+    case 4: ntt_fwd_cols_expand<4><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;
+    case 5: ntt_fwd_cols_expand<5><<<dim3(rows * 16), 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;
   }
   return check_launch("ntt_fwd_cols_expand");
 }
@@ -567,7 +494,7 @@ int rh_std_ntt_submul_launch(rh_ring* r, u64* buf, int npoly, int Lrows, int lim
   (void)hipGetLastError();
   LimbScalars sc; memset(&sc, 0, sizeof(sc)); memcpy(sc.s, scalars_host, (size_t)Lrows * 8);
   const size_t toff = (size_t)limb0 * r->N;
-  ntt_fwd_tile_submul<<<rows << S1, 256, 0, r->stream>>>(buf, r->d_twk_fwd + toff, r->d_consts + limb0, Lrows, r->logN, npoly, y, y_rows,
+  ntt_fwd_tile_submul<<<rows << S1, 256, 0, rh_stream(r)>>>(buf, r->d_twk_fwd + toff, r->d_consts + limb0, Lrows, r->logN, npoly, y, y_rows,
                                                          out, out_rows, sc, z, z_rows);
   return check_launch("ntt_fwd_tile_submul");
 }
@@ -605,11 +532,11 @@ static int ci_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
   unsigned chunks = ((unsigned)r->N / 2 + 256) / 256; if (chunks > 64) chunks = 64;
   (void)hipGetLastError();
   if (!inverse) {
-    ci_fold_kernel<<<dim3(rows, chunks), 256, 0, r->stream>>>(in, out, r->logN, r->d_cifold + limb0, r->d_consts + limb0, Lrows, 0);
+    ci_fold_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(in, out, r->logN, r->d_cifold + limb0, r->d_consts + limb0, Lrows, 0);
     return rh_std_ntt_launch(r, out, out, npoly, Lrows, limb0, false, false, 0);
   }
   if (int rc = rh_std_ntt_launch(r, in, out, npoly, Lrows, limb0, true, false, 0)) return rc;
-  ci_fold_kernel<<<dim3(rows, chunks), 256, 0, r->stream>>>(out, out, r->logN, r->d_cifold + limb0, r->d_consts + limb0, Lrows, 1);
+  ci_fold_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(out, out, r->logN, r->d_cifold + limb0, r->d_consts + limb0, Lrows, 1);
   return check_launch("ci_fold_kernel");
 }
 
@@ -618,7 +545,10 @@ static int ntt_batch(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, i
   if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "ntt: level %d out of range [0,%d)", level, r->L);
   if (npoly < 0) return rh_fail(RH_ERR_ARG, "ntt: npoly < 0");
   (void)hipSetDevice(r->device);
-  if (r->kind == RH_RING_3N) return rh_ring3n_ntt_launch(r, in, out, npoly, level + 1, 0, inverse);
+  if (r->kind == RH_RING_3N) {
+    std::lock_guard<std::recursive_mutex> lk(r->mu);          // the 3N workspace is shared and grows lazily
+    return rh_ring3n_ntt_launch(r, in, out, npoly, level + 1, 0, inverse);
+  }
   if (r->kind == RH_RING_CI) return ci_ntt_launch(r, in, out, npoly, level + 1, 0, inverse);
   return rh_std_ntt_launch(r, in, out, npoly, level + 1, 0, inverse, lazy, phase);
 }
@@ -629,46 +559,75 @@ extern "C" int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in, uint64_t* out, 
   return ntt_batch(r, in, out, npoly, level, inverse != 0, false, phase);
 }
 
+// Pre-sizes every lazily grown scratch of the ring for batches of up to npoly polys (all limbs): afterwards no entry point of
+// the ring allocates.  Optional: without it scratch grows on first use.
+extern "C" int rh_ring_reserve(rh_ring* r, int npoly) {
+  if (!r || npoly < 0) return rh_fail(RH_ERR_ARG, "rh_ring_reserve: bad argument");
+  (void)hipSetDevice(r->device);
+  std::lock_guard<std::recursive_mutex> lk(r->mu);
+  if (r->kind == RH_RING_3N) return rh_ring3n_reserve(r, npoly);
+  return rh_rescale_reserve(r, npoly);
+}
+
 extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
   if (!r || !key) return rh_fail(RH_ERR_ARG, "set_tuning: null argument");
   if (!strcmp(key, "chunk_polys")) { r->chunk_polys = (int)value; return RH_OK; }
   if (!strcmp(key, "asm_tile")) { r->asm_tile = value != 0; return RH_OK; }
   if (!strcmp(key, "auto_span_rows")) { if (value < 1) return rh_fail(RH_ERR_ARG, "auto_span_rows must be >= 1"); r->auto_span_rows = (int)value; return RH_OK; }
-  if (!strcmp(key, "dbg_lds_pad")) { r->dbg_lds_pad = (int)value; return RH_OK; }    // occupancy experiments: extra dynamic LDS per workgroup
   if (!strcmp(key, "fuse_submul")) { r->fuse_submul = (int)value; return RH_OK; }
   if (!strcmp(key, "perm_inv_shape")) { r->perm_inv_shape = (int)value; return RH_OK; }
   if (!strcmp(key, "fuse3n")) { r->fuse3n = (int)value; return RH_OK; }
   if (!strcmp(key, "asm_cols")) { r->asm_cols = (int)value; return RH_OK; }
-  if (!strcmp(key, "prefetch")) { r->prefetch = (int)value; return RH_OK; }
-  if (!strcmp(key, "order_mix")) { r->order_mix = (int)value; return RH_OK; }
-  if (!strcmp(key, "cols2")) { r->cols2 = (int)value; return RH_OK; }
-  if (!strcmp(key, "persistent")) { r->persistent = value != 0; return RH_OK; }
-  if (!strcmp(key, "cluster")) { r->cluster = value != 0; return RH_OK; }
-  if (!strcmp(key, "cluster_dbg")) { r->cluster_dbg = (int)value; return RH_OK; }
-  if (!strcmp(key, "cluster_wgs_per_cu")) { r->cluster_wgs_per_cu = (int)value; return RH_OK; }
-  if (!strcmp(key, "group_polys")) { if (value < 1) return rh_fail(RH_ERR_ARG, "group_polys must be >= 1"); r->group_polys = (int)value; return RH_OK; }
-  if (!strcmp(key, "persist_grid")) { r->persist_grid = (int)value; return RH_OK; }
-  if (!strcmp(key, "persist_unsafe_timing")) { r->persist_unsafe = (int)value; return RH_OK; }   // timing experiments only
   return rh_fail(RH_ERR_ARG, "set_tuning: unknown key %s", key);
 }
 
-// one limb, host pointers: the NumberTheoreticTransformer interface
+// ---- one limb, host pointers: the NumberTheoreticTransformer interface -----------------------------------------------
+// Every call takes a (stream, scratch) slot of its own from the ring's pool, so any number of OS threads may call
+// Forward / Backward on one handle at once (ring/ring.go:192-194; goroutines migrate between threads).  A slot is created
+// the first time a caller finds the pool empty; steady state allocates nothing.
+static int slot_acquire(rh_ring* r, RhHostSlot** out) {
+  {
+    std::lock_guard<std::mutex> lk(r->slot_mu);
+    if (!r->free_slots.empty()) { *out = r->free_slots.back(); r->free_slots.pop_back(); return RH_OK; }
+  }
+  RhHostSlot* sl = new (std::nothrow) RhHostSlot();
+  if (!sl) return rh_fail(RH_ERR_NOMEM, "out of host memory");
+  sl->words = (size_t)r->N * (r->kind == RH_RING_3N ? 2 : 1);                    // the limb + the 3N transform's workspace for one row
+  if (hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking) != hipSuccess) { delete sl; return rh_fail(RH_ERR_DEVICE, "hipStreamCreate failed"); }
+  if (hipMalloc((void**)&sl->buf, sl->words * 8) != hipSuccess) { (void)hipStreamDestroy(sl->stream); delete sl; return rh_fail(RH_ERR_NOMEM, "hipMalloc(host-limb scratch) failed"); }
+  std::lock_guard<std::mutex> lk(r->slot_mu);
+  r->all_slots.push_back(sl);
+  *out = sl;
+  return RH_OK;
+}
+static void slot_release(rh_ring* r, RhHostSlot* sl) {
+  std::lock_guard<std::mutex> lk(r->slot_mu);
+  r->free_slots.push_back(sl);
+}
 static int ntt_host_limb(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2, bool inverse, bool lazy) {
   if (!r) return rh_fail(RH_ERR_ARG, "null ring");
   if (!p1 || !p2) return rh_fail(RH_ERR_ARG, "cannot NTT: nil slice (len(p1), len(p2) must be >= N=%d)", r->N);
   if (limb < 0 || limb >= r->L) return rh_fail(RH_ERR_ARG, "limb %d out of range [0,%d)", limb, r->L);
   (void)hipSetDevice(r->device);
-  const size_t bytes = (size_t)r->N * 8;
-  hipError_t e = hipMemcpyAsync(r->d_scratch, p1, bytes, hipMemcpyHostToDevice, r->stream);
-  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "H2D: %s", hipGetErrorString(e));
-  int rc = (r->kind == RH_RING_3N) ? rh_ring3n_ntt_launch(r, r->d_scratch, r->d_scratch, 1, 1, limb, inverse)
-         : (r->kind == RH_RING_CI) ? ci_ntt_launch(r, r->d_scratch, r->d_scratch, 1, 1, limb, inverse)
-                                   : rh_std_ntt_launch(r, r->d_scratch, r->d_scratch, 1, 1, limb, inverse, lazy, 0);
-  if (rc) return rc;
-  e = hipMemcpyAsync(p2, r->d_scratch, bytes, hipMemcpyDeviceToHost, r->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
-  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "D2H: %s", hipGetErrorString(e));
-  return RH_OK;
+  RhHostSlot* sl;
+  if (int rc = slot_acquire(r, &sl)) return rc;
+  int rc = RH_OK;
+  {
+    RhCallScope scope(sl->stream, r->kind == RH_RING_3N ? sl->buf + r->N : nullptr, (size_t)r->N);
+    const size_t bytes = (size_t)r->N * 8;
+    hipError_t e = hipMemcpyAsync(sl->buf, p1, bytes, hipMemcpyHostToDevice, sl->stream);
+    if (e != hipSuccess) rc = rh_fail(RH_ERR_DEVICE, "H2D: %s", hipGetErrorString(e));
+    if (!rc) rc = (r->kind == RH_RING_3N) ? rh_ring3n_ntt_launch(r, sl->buf, sl->buf, 1, 1, limb, inverse)
+                : (r->kind == RH_RING_CI) ? ci_ntt_launch(r, sl->buf, sl->buf, 1, 1, limb, inverse)
+                                          : rh_std_ntt_launch(r, sl->buf, sl->buf, 1, 1, limb, inverse, lazy, 0);
+    if (!rc) {
+      e = hipMemcpyAsync(p2, sl->buf, bytes, hipMemcpyDeviceToHost, sl->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(sl->stream);
+      if (e != hipSuccess) rc = rh_fail(RH_ERR_DEVICE, "D2H: %s", hipGetErrorString(e));
+    } else (void)hipStreamSynchronize(sl->stream);
+  }
+  slot_release(r, sl);
+  return rc;
 }
 extern "C" int rh_ntt_forward(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2) { return ntt_host_limb(r, limb, p1, p2, false, false); }
 extern "C" int rh_ntt_forward_lazy(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2) { return ntt_host_limb(r, limb, p1, p2, false, true); }
@@ -722,7 +681,7 @@ int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3,
   unsigned chunks = (n / 2 + 256 * 4 - 1) / (256 * 4);
   if (chunks < 1) chunks = 1;
   if (chunks > 64) chunks = 64;
-  hipLaunchKernelGGL(table[opcode], dim3(rows, chunks), dim3(256), 0, r->stream, p1, p2, p3, n, a, b, r->d_consts + limb0, Lrows);
+  hipLaunchKernelGGL(table[opcode], dim3(rows, chunks), dim3(256), 0, rh_stream(r), p1, p2, p3, n, a, b, r->d_consts + limb0, Lrows);
   return check_launch("vec_op");
 }
 
@@ -764,7 +723,7 @@ extern "C" int rh_ring_tensor_degree1(rh_ring* r, const uint64_t* a0, const uint
   (void)hipSetDevice(r->device);
   (void)hipGetLastError();
   unsigned chunks = (n / 2 + 1023) / 1024; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
-  tensor_degree1_kernel<<<dim3(rows, chunks), 256, 0, r->stream>>>(a0, a1, b0, b1, c0, c1, c2, n, r->d_consts, level + 1, mform_first);
+  tensor_degree1_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(a0, a1, b0, b1, c0, c1, c2, n, r->d_consts, level + 1, mform_first);
   return check_launch("tensor_degree1");
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>
+#include <mutex>
 #include <cstdint>
 #include "../../include/ringhip.h"
 #include "ring_types.cuh"
@@ -27,33 +28,43 @@ struct rh_ring {
   tw2* d_twk_fwd = nullptr;       // kernel order (logN >= 12)
   tw2* d_twk_inv = nullptr;
   u64* d_twk_fwd_mont = nullptr;
+  u64* d_tw_inv_mont = nullptr;   // N < 16 only: RootsBackward as given, for the non-canonical BackwardLazy of tiny rings
   CiFold* d_cifold = nullptr;     // conjugate-invariant rings only
   tw2* d_lastw = nullptr;         // psi_bwd[1] * N^-1 per limb
-  u64* d_scratch = nullptr;       // 2N words for the host-pointer single-limb path
+  // host-pointer single-limb path (rh_ntt_*): a pool of (stream, scratch) slots, one per concurrent caller
+  std::mutex slot_mu;
+  std::vector<struct RhHostSlot*> free_slots, all_slots;
+  // serialises the HOST side of the entry points that touch lazily built shared state (rescale tables / scratch, the 3N
+  // transform's scratch); device work stays stream-ordered.  Tables, twiddles and tuning are read-only after creation.
+  std::recursive_mutex mu;
   rh_ring3n_state* s3n = nullptr;
   std::vector<void*> rescale_tables;      // per level, rescale.hip
   u64* d_rs[2] = {nullptr, nullptr}; size_t rs_words[2] = {0, 0};
-  bool cluster = false;           // single-pass forward transform through the XCD L2 (ntt_fwd_cluster)
-  int cluster_wgs_per_cu = 4;
-  int cluster_dbg = 0;            // debugging: bit 0 skips the column stages, bit 1 the tile stages
-  unsigned* d_cl = nullptr; size_t cl_words = 0;
-  bool persistent = false;        // single-launch pipelined forward transform (ntt_fwd_persistent)
-  int group_polys = 8;            // polys per pipeline group of the persistent kernel
-  int persist_unsafe = 0;         // timing experiments only: plain stores and no acquire in the hand-off
-  int persist_grid = 0;           // resident workgroups (0 = query)
-  unsigned* d_rowcnt = nullptr; size_t rowcnt_words = 0, err_index = 0;
-  int cols2 = 0;                  // column kernel: two adjacent columns per thread (16 B per lane)
-  int dbg_lds_pad = 0;            // experiments: extra dynamic LDS of the fused forward launch (lowers workgroups per CU)
   int fuse_submul = 1;            // ModDown / rescale: subtract-multiply fused into the forward tile kernel's epilogue
   int perm_inv_shape = 64;        // 3N inverse permutation tile: words per block-order run (32 / 64 / 128)
   int fuse3n = 1;                 // 3N rings, b = 1: split + radix-3 layer fused with the sub-transforms' column stages
   int asm_cols = 1;               // N = 2^16: hand-scheduled column stages (fwd_cols16_asm_body) in place of the C++ body
-  int prefetch = 0;               // fused forward launch: issue the tile loads ahead of the column stages (ntt_fwd_fused_pre); measured: no gain
-  int order_mix = 0;              // fused forward launch: alternate (cols, tile) / (tile, cols) order between CU slots
   bool asm_tile = true;           // forward tile kernel: hand-scheduled body (ntt_kernels_asm.cuh) vs the C++ one
   bool inv_scale = true;          // false: inverse leaves values < 4q without the N^-1 factor (3N sub-transform)
   int auto_span_rows = 2048;      // chunk_polys = -1: span size of the fused pipeline in (poly, limb) rows
   int chunk_polys = -1;           // -1 = auto (128-poly spans for batches >= 256), 0 = whole batch in two launches, >0 = polys per span
+};
+
+// ---- per-call context of the calling thread -----------------------------------------------------------------------
+// A handle is shared by concurrent callers (ring/ring.go:192-194: transformers immutable, AtLevel views concurrency-safe), so
+// nothing a call needs may live in the handle as mutable state.  The stream a launch goes to and the 3N transform's workspace
+// are resolved through thread-local overrides: the host-limb path installs its slot's stream + scratch, a basis extender
+// pins both of its rings to ringQ's stream for the duration of the call.
+struct RhHostSlot { hipStream_t stream = nullptr; u64* buf = nullptr; size_t words = 0; };
+hipStream_t rh_stream(const rh_ring* r);                     // the calling thread's override, else the ring's stream
+u64* rh_ws_override(size_t words);                           // workspace of the calling thread's slot (nullptr: none installed)
+struct RhCallScope {                                         // installs (stream [, workspace]) for the calling thread; restores on exit
+  RhCallScope(hipStream_t st, u64* ws = nullptr, size_t ws_words = 0);
+  ~RhCallScope();
+  RhCallScope(const RhCallScope&) = delete;
+  RhCallScope& operator=(const RhCallScope&) = delete;
+ private:
+  hipStream_t prev_st; bool prev_has; u64* prev_ws; size_t prev_words;
 };
 
 int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase = 0);
@@ -68,6 +79,8 @@ int rh_std_upload_tables(rh_ring* r, const std::vector<tw2>& fs, const std::vect
                          const std::vector<tw2>& lastw);
 int rh_upload_consts(rh_ring* r, const std::vector<LimbConsts>& hc);
 void rh_rescale_teardown(rh_ring* r);
+int rh_rescale_reserve(rh_ring* r, int npoly);
+int rh_ring3n_reserve(rh_ring* r, int npoly);
 // 3N-cyclotomic transform (ntt3n.hip)
 int rh_ring3n_setup(rh_ring* r, std::vector<LimbConsts>& hc);
 void rh_ring3n_teardown(rh_ring* r);
@@ -78,6 +91,13 @@ struct rh_bext;
 rh_ring* rh_bext_ringQ(rh_bext* be);
 rh_ring* rh_bext_ringP(rh_bext* be);
 int rh_bext_scratch(rh_bext* be, int which, size_t words, u64** out);
+std::recursive_mutex& rh_bext_mutex(rh_bext* be);
+// A basis extender carries scratch and lazily built plans, like the reference's (ring/basis_extension.go:166-183: one ShallowCopy
+// per goroutine); its entry points still serialise their host side on the object, and pin both rings to ringQ's stream.
+struct RhBextGuard {
+  std::unique_lock<std::recursive_mutex> lk; RhCallScope sc;
+  explicit RhBextGuard(rh_bext* be) : lk(rh_bext_mutex(be)), sc(rh_stream(rh_bext_ringQ(be))) {}
+};
 // ModDownQPtoQNTT with an optional addend: p2Q = [addend +] (p1Q - ext(p1P)) / P   (addend: the ring.Add that follows a key switch)
 int rh_bext_moddown_ntt_add(rh_bext* be, int levelQ, int levelP, const u64* p1Q, const u64* p1P, u64* p2Q, int npoly, const u64* addend);
 int rh_bext_moddown_ntt_pair(rh_bext* be, int levelQ, int levelP, const u64* q0, const u64* q1, const u64* p1P, u64* out0, u64* out1,

@@ -39,7 +39,7 @@ gadget_mac_kernel(const u64* c2, const u64* __restrict__ evk0, const u64* __rest
 int rh_gadget_mac(rh_ring* r, const u64* c2, const u64* e0, const u64* e1, u64* a0, u64* a1, int npoly, int L, int first) {
   const unsigned rows = (unsigned)npoly * L, n = (unsigned)r->N;
   unsigned chunks = (n / 2 + 1023) / 1024; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
-  gadget_mac_kernel<<<dim3(rows, chunks), 256, 0, r->stream>>>(c2, e0, e1, a0, a1, n, r->d_consts, L, first);
+  gadget_mac_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(c2, e0, e1, a0, a1, n, r->d_consts, L, first);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_mac_kernel launch failed: %s", hipGetErrorString(e));
   return RH_OK;
@@ -86,7 +86,7 @@ static int mac_all(rh_ring* r, const u64* c2, size_t digit_stride, const u64* ev
                    const u64* cx = nullptr, int digit_limbs = 1) {
   const unsigned n = (unsigned)r->N;
   unsigned chunks = (n / 2 + 1023) / 1024; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
-  gadget_mac_all_kernel<<<dim3((unsigned)npoly * L, chunks), 256, 0, r->stream>>>(c2, digit_stride, evk, (size_t)r->L * n, beta, overf, a0, a1, n,
+  gadget_mac_all_kernel<<<dim3((unsigned)npoly * L, chunks), 256, 0, rh_stream(r)>>>(c2, digit_stride, evk, (size_t)r->L * n, beta, overf, a0, a1, n,
                                                                                  r->d_consts, L, npoly, cx, digit_limbs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_mac_all_kernel launch failed: %s", hipGetErrorString(e));
@@ -111,7 +111,7 @@ static int decompose_single_ntt(rh_bext* be, int levelQ, int levelP, int i, cons
     if (int rc = rh_std_ntt_fwd_strided(RQ, c2Q + (size_t)ed * N, npoly, LQ - ed, ed, LQ)) return rc;
   } else if (int rc = rh_std_ntt_launch(RQ, c2Q, c2Q, npoly, LQ, 0, false, false, 0)) return rc;
   if (copy_digit && hipMemcpy2DAsync(c2Q + (size_t)st * N, (size_t)LQ * N * 8, cx + (size_t)st * N, (size_t)LQ * N * 8, (size_t)(ed - st) * N * 8, npoly,
-                                     hipMemcpyDeviceToDevice, RQ->stream) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_product: digit copy failed");
+                                     hipMemcpyDeviceToDevice, rh_stream(RQ)) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_product: digit copy failed");
   return rh_std_ntt_launch(RP, c2P, c2P, npoly, LP, 0, false, false, 0);
 }
 
@@ -130,14 +130,14 @@ static int ks_check(rh_bext* be, int levelQ, int levelP, int beta_key, const cha
   *beta = (levelQ + levelP + 1) / (levelP + 1);                    // BaseRNSDecompositionVectorSize, params.go:635-642
   if (beta_key >= 0 && *beta > beta_key) return rh_fail(RH_ERR_ARG, "%s: key has %d digits, level needs %d", who, beta_key, *beta);
   (void)hipSetDevice(RQ->device);
-  RP->stream = RQ->stream;
   return RH_OK;
 }
 
 // Evaluator.DecomposeNTT (:431-453): decompQ [beta][npoly][levelQ+1][N], decompP [beta][npoly][levelP+1][N], NTT domain
 extern "C" int rh_bext_decompose_ntt(rh_bext* be, int levelQ, int levelP, const uint64_t* c2, int c2_is_ntt, uint64_t* decompQ,
                                      uint64_t* decompP, int npoly) {
-  if (!c2 || !decompQ || !decompP) return rh_fail(RH_ERR_ARG, "decompose_ntt: null argument");
+  if (!be || !c2 || !decompQ || !decompP) return rh_fail(RH_ERR_ARG, "decompose_ntt: null argument");
+  RhBextGuard guard(be);
   int beta; if (int rc = ks_check(be, levelQ, levelP, -1, "decompose_ntt", &beta)) return rc;
   if (npoly <= 0) return RH_OK;
   rh_ring* RQ = rh_bext_ringQ(be);
@@ -162,7 +162,8 @@ static int hoisted_tail(rh_bext* be, int levelQ, int levelP, const uint64_t* dec
   // ct0 / ct1 hold the Q-part accumulators; results go to out_c (default: ct_c itself) as [add_c +] ModDown(ct_c, P part)
   if (!out0) out0 = ct0;
   if (!out1) out1 = ct1;
-  if (!decompQ || !decompP || !evkQ || !evkP || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "gadget_product_hoisted: null argument");
+  if (!be || !decompQ || !decompP || !evkQ || !evkP || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "gadget_product_hoisted: null argument");
+  RhBextGuard guard(be);
   int beta; if (int rc = ks_check(be, levelQ, levelP, beta_key, "gadget_product_hoisted", &beta)) return rc;
   if (npoly <= 0) return RH_OK;
   rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
@@ -187,6 +188,7 @@ extern "C" int rh_bext_gadget_product_hoisted_then_add(rh_bext* be, int levelQ, 
                                                        const uint64_t* add1, uint64_t* ct0, uint64_t* ct1, int npoly) {
   if (!add0 && !add1) return hoisted_tail(be, levelQ, levelP, decompQ, decompP, evkQ, evkP, beta_key, ct0, ct1, npoly, nullptr);
   if (!be || npoly <= 0) return npoly == 0 && be ? RH_OK : rh_fail(RH_ERR_ARG, "gadget_product_hoisted_then_add: bad argument");
+  RhBextGuard guard(be);
   rh_ring* RQ = rh_bext_ringQ(be);
   if (levelQ < 0 || levelQ >= RQ->L) return rh_fail(RH_ERR_ARG, "gadget_product_hoisted_then_add: levelQ out of range");
   const size_t wq = (size_t)npoly * (levelQ + 1) * RQ->N;
@@ -198,7 +200,8 @@ extern "C" int rh_bext_gadget_product_hoisted_then_add(rh_bext* be, int levelQ, 
 
 static int gadget_product_impl(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, const uint64_t* evkQ, const uint64_t* evkP,
                                int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly, const uint64_t* add0, const uint64_t* add1) {
-  if (!cx || !evkQ || !evkP || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "gadget_product: null argument");
+  if (!be || !cx || !evkQ || !evkP || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "gadget_product: null argument");
+  RhBextGuard guard(be);
   int beta; if (int rc = ks_check(be, levelQ, levelP, beta_key, "gadget_product", &beta)) return rc;
   if (npoly <= 0) return RH_OK;
   rh_ring* RQ = rh_bext_ringQ(be);

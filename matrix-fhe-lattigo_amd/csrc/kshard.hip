@@ -29,6 +29,7 @@ struct rh_kshard {
   std::vector<u64> md_scalars;                           // q_k - (P^-1 mod q_k) Montgomery form, per owned Q limb
   u64* buf[3] = {nullptr, nullptr, nullptr}; size_t buf_words[3] = {0, 0, 0};   // c2Q, c2P, buffQ
   int reduce = 0, QiOverF = 1, PiOverF = 1;
+  std::recursive_mutex mu;                               // one key switch at a time per handle (digits are fed in order)
 };
 
 static int ks_buf(rh_kshard* ks, int which, size_t words, u64** out) {
@@ -147,7 +148,8 @@ extern "C" int rh_kshard_digit(rh_kshard* ks, int digit, const uint64_t* src, co
   if (npoly <= 0) return RH_OK;
   rh_ring* RQ = ks->Q; rh_ring* RP = ks->P;
   (void)hipSetDevice(RQ->device);
-  if (RP) RP->stream = RQ->stream;
+  std::lock_guard<std::recursive_mutex> lk(ks->mu);
+  RhCallScope scope(rh_stream(RQ));                        // both local rings launch into ringQ's stream
   const int N = RQ->N, nQ = RQ->L, nP = RP ? RP->L : 0;
   int st, ed; (void)rh_kshard_digit_range(ks, digit, &st, &ed);
   u64 *c2Q, *c2P = nullptr;
@@ -155,13 +157,13 @@ extern "C" int rh_kshard_digit(rh_kshard* ks, int digit, const uint64_t* src, co
   if (nP) if (int rc = ks_buf(ks, 1, (size_t)npoly * nP * N, &c2P)) return rc;
   BextPlan* p; bool single;
   if (int rc = digit_plan(ks, digit, &p, &single)) return rc;
-  if (single) { if (int rc = rh_bext_launch_sign(RQ->stream, N, *p, src, ed - st, 0, c2Q, nQ, c2P, nP, npoly)) return rc; }
-  else if (int rc = rh_bext_launch_raw(RQ->stream, N, *p, src, ed - st, 0, c2Q, nQ, c2P, nP, nullptr, 0, npoly, BEXT_ADD_RAW)) return rc;
+  if (single) { if (int rc = rh_bext_launch_sign(rh_stream(RQ), N, *p, src, ed - st, 0, c2Q, nQ, c2P, nP, npoly)) return rc; }
+  else if (int rc = rh_bext_launch_raw(rh_stream(RQ), N, *p, src, ed - st, 0, c2Q, nQ, c2P, nP, nullptr, 0, npoly, BEXT_ADD_RAW)) return rc;
   if (int rc = rh_std_ntt_launch(RQ, c2Q, c2Q, npoly, nQ, 0, false, false, 0)) return rc;
   for (int k = 0; k < nQ; ++k) {
     if (ks->ownQ[k] < st || ks->ownQ[k] >= ed) continue;
     if (hipMemcpy2DAsync(c2Q + (size_t)k * N, (size_t)nQ * N * 8, cx_loc + (size_t)k * N, (size_t)nQ * N * 8, (size_t)N * 8, npoly,
-                         hipMemcpyDeviceToDevice, RQ->stream) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "rh_kshard_digit: digit copy failed");
+                         hipMemcpyDeviceToDevice, rh_stream(RQ)) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "rh_kshard_digit: digit copy failed");
   }
   if (nP) if (int rc = rh_std_ntt_launch(RP, c2P, c2P, npoly, nP, 0, false, false, 0)) return rc;
   const size_t evq = (size_t)nQ * N, evp = (size_t)nP * N;
@@ -185,6 +187,8 @@ extern "C" int rh_kshard_moddown(rh_kshard* ks, const uint64_t* srcP, const uint
   if (npoly <= 0) return RH_OK;
   rh_ring* RQ = ks->Q;
   (void)hipSetDevice(RQ->device);
+  std::lock_guard<std::recursive_mutex> lk(ks->mu);
+  RhCallScope scope(rh_stream(RQ));
   const int N = RQ->N, nQ = RQ->L, LP = ks->levelP + 1;
   if (!ks->have_md) {
     std::vector<u64> tg(RQ->moduli.begin(), RQ->moduli.end()), qsi, coef, vt;
@@ -201,7 +205,7 @@ extern "C" int rh_kshard_moddown(rh_kshard* ks, const uint64_t* srcP, const uint
   }
   u64* buffQ;
   if (int rc = ks_buf(ks, 2, (size_t)npoly * nQ * N, &buffQ)) return rc;
-  if (int rc = rh_bext_launch_raw(RQ->stream, N, ks->md_plan, srcP, LP, 0, buffQ, nQ, nullptr, 0, nullptr, 0, npoly, BEXT_ADD_CRED)) return rc;
+  if (int rc = rh_bext_launch_raw(rh_stream(RQ), N, ks->md_plan, srcP, LP, 0, buffQ, nQ, nullptr, 0, nullptr, 0, npoly, BEXT_ADD_CRED)) return rc;
   if (rh_can_fuse_submul(RQ)) return rh_std_ntt_submul_launch(RQ, buffQ, npoly, nQ, 0, ctQ_in, nQ, ctQ_out, nQ, ks->md_scalars.data());
   if (int rc = rh_std_ntt_launch(RQ, buffQ, buffQ, npoly, nQ, 0, false, false, 0)) return rc;
   return rh_vec_launch(RQ, RH_OP_SUB_THEN_MUL_SCALAR_MONT_TWO_MODULUS, buffQ, ctQ_in, ctQ_out, npoly, nQ, 0, ks->md_scalars.data(), nullptr);

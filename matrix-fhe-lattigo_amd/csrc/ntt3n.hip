@@ -508,16 +508,16 @@ int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
   const int N = r->N, nb = s->nb;
   const unsigned rows = (unsigned)npoly * (unsigned)Lrows;
   if (rows == 0) return RH_OK;
-  if (int rc = ensure_tmp(s, (size_t)rows * N)) return rc;
+  u64* tmp = rh_ws_override((size_t)rows * N);            // the host-limb path brings its own workspace (one row)
+  if (!tmp) { if (int rc = ensure_tmp(s, (size_t)rows * N)) return rc; tmp = s->d_tmp; }
   (void)hipGetLastError();
-  hipStream_t st = r->stream;
+  hipStream_t st = rh_stream(r);
+  RhCallScope scope(st);                                  // the sub-ring's launches go to the same stream
   const LimbConsts* c = r->d_consts + limb0;
   const Limb3N* l3 = s->d_l3 + limb0;
   const tw2* r3f = s->d_r3_fwd + (size_t)limb0 * s->r3_stride;
   const tw2* r3i = s->d_r3_inv + (size_t)limb0 * s->r3_stride;
   auto chunks = [](int work) { int g = (work + 255) / 256; return g < 1 ? 1 : (g > 64 ? 64 : g); };
-  u64* tmp = s->d_tmp;
-  if (s->sub) s->sub->stream = st;
   const bool tiled = s->log_n2 >= 2 * PT && nb <= 6;     // LDS: 32*(32*nb+1)*8 bytes = 48 KiB at nb = 6
   const size_t perm_lds = (size_t)32 * (32 * nb + 1) * 8;
   const dim3 pgrid(rows, 1u << (s->log_n2 >= 2 * PT ? s->log_n2 - 2 * PT : 0));
@@ -575,3 +575,5 @@ int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "3N transform launch failed: %s", hipGetErrorString(e));
   return RH_OK;
 }
+
+int rh_ring3n_reserve(rh_ring* r, int npoly) { return ensure_tmp(r->s3n, (size_t)npoly * r->L * r->N); }

@@ -272,8 +272,7 @@ ntt_inv_tile(const u64* in, u64* out, const tw2* __restrict__ twk,
 // K1 forward: first S1 stages, R = 2^S1 coefficients per thread at stride 4096.  twn: natural-order table
 // (RootsForward index), entries [1, R) are used and are wave-uniform.
 // ---------------------------------------------------------------------------------------------------------------
-// WT: write-through (sc1) stores, for the in-launch hand-off of the persistent pipeline (ntt_kernels_asm.cuh)
-template <class P, int S1, bool WT = false>
+template <class P, int S1>
 RH_DEV void fwd_cols_body(const u32 b, const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
                           const LimbConsts* __restrict__ consts, int L, int logN, int Ls = 0) {
   if (Ls == 0) Ls = L;                     // rows per poly of the block (>= L)
@@ -300,10 +299,7 @@ RH_DEV void fwd_cols_body(const u32 b, const u64* in, u64* out, const typename P
     }
   }
 #pragma unroll
-  for (int k = 0; k < R; ++k) {
-    if (WT) __hip_atomic_store(&out[base + ((size_t)k << LT)], x[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else out[base + ((size_t)k << LT)] = x[k];
-  }
+  for (int k = 0; k < R; ++k) out[base + ((size_t)k << LT)] = x[k];
 }
 template <class P, int S1>
 __global__ void __launch_bounds__(256)
@@ -350,50 +346,6 @@ ntt_fwd_cols_expand(const u64* tmp, u64* out, const tw2* __restrict__ twn, const
   for (int k = 0; k < R; ++k) out[base + ((size_t)k << LT)] = x[k];
 }
 
-// two adjacent columns per thread: every global access is 16 B per lane (1 KiB per wave instruction)
-template <class P, int S1>
-RH_DEV void fwd_cols2_body(const u32 b, const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
-                           const LimbConsts* __restrict__ consts, int L, int logN) {
-  constexpr int R = 1 << S1;
-  const u32 limb = b % (u32)L;
-  const u32 r = b / (u32)L;
-  const u32 cb = r & 7;             // 8 blocks of 512 columns per limb
-  const u32 poly = r >> 3;
-  const size_t base = (((size_t)poly * L + limb) << logN) + cb * 512 + 2 * threadIdx.x;
-  const typename P::tw_t* tw = twn + ((size_t)limb << logN);
-  P p; p.init(consts[limb]);
-  u64 x[R], y[R];
-#pragma unroll
-  for (int k = 0; k < R; ++k) {
-    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(in + base + ((size_t)k << LT));
-    x[k] = v.x; y[k] = v.y;
-  }
-#pragma unroll
-  for (int s = 0; s < S1; ++s) {
-    const int h = R >> (s + 1);
-    const bool red = ref_reduce(s, logN);
-#pragma unroll
-    for (int g = 0; g < (1 << s); ++g) {
-      typename P::tw_t w = tw[(1 << s) + g];
-#pragma unroll
-      for (int e = 0; e < h; ++e) {
-        p.fwd(x[g * 2 * h + e], x[g * 2 * h + e + h], w, red);
-        p.fwd(y[g * 2 * h + e], y[g * 2 * h + e + h], w, red);
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < R; ++k) {
-    ulonglong2 v; v.x = x[k]; v.y = y[k];
-    *reinterpret_cast<ulonglong2*>(out + base + ((size_t)k << LT)) = v;
-  }
-}
-template <class P, int S1>
-__global__ void __launch_bounds__(256)
-ntt_fwd_cols2(const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
-              const LimbConsts* __restrict__ consts, int L, int logN) {
-  fwd_cols2_body<P, S1>(blockIdx.x, in, out, twn, consts, L, logN);
-}
 // Fused launch of a software pipeline over spans of polys: the workgroup first runs the (HBM-bound) column stages of
 // one unit of span j, then the (VALU-bound) tile stages of one tile of span j-1, so that on every CU memory-phase and
 // compute-phase workgroups are co-resident.  n1/n2 = number of column units / tiles in this launch.
@@ -518,4 +470,31 @@ ntt_inv_small(const u64* in, u64* out, const tw2* __restrict__ twn,
   }
   for (int j = threadIdx.x; j < N; j += blockDim.x)
     out[base + j] = scale ? canon4(shoup_mul(lds[j], c.ninv_w, c.ninv_wp, c.nq), c.q) : lds[j];
+}
+
+// N < 16 (the reference accepts N = 8, ring/ring.go:318): BackwardLazy is NOT canonical there -- inttCoreLazy followed by
+// MRedLazy(x, NInv) (ring/ntt.go:197-202), values in [0, 2q).  Reproduced with the reference's own Montgomery butterfly so the
+// representatives are bit-identical.  twm: RootsBackward as handed over (Montgomery form), natural order.
+__global__ void __launch_bounds__(64)
+ntt_inv_small_lazy_mont(const u64* in, u64* out, const u64* __restrict__ twm, const LimbConsts* __restrict__ consts, int L, int logN) {
+  __shared__ u64 lds[16];
+  const int N = 1 << logN;
+  const u32 limb = blockIdx.x % (u32)L;
+  const size_t base = (size_t)blockIdx.x << logN;
+  const u64* tw = twm + ((size_t)limb << logN);
+  const LimbConsts c = consts[limb];
+  MontPolicy p; p.init(c);
+  if ((int)threadIdx.x < N) lds[threadIdx.x] = in[base + threadIdx.x];
+  __syncthreads();
+  for (int lt = 0; lt < logN; ++lt) {
+    const int h = N >> (lt + 1);
+    if ((int)threadIdx.x < (N >> 1)) {
+      const int bf = threadIdx.x, i = bf >> lt, j = (i << (lt + 1)) + (bf & ((1 << lt) - 1));
+      u64 U = lds[j], V = lds[j + (1 << lt)];
+      p.inv(U, V, tw[h + i]);
+      lds[j] = U; lds[j + (1 << lt)] = V;
+    }
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < N) out[base + threadIdx.x] = mred_lazy(lds[threadIdx.x], c.ninv_mont, c.q, c.qinv);
 }

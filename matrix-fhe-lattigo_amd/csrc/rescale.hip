@@ -112,6 +112,14 @@ static int check_args(rh_ring* r, int level, int nb, const void* p0, const void*
   (void)hipGetLastError();
   return 0;
 }
+// npoly blocks of `limbs` leading limbs from a (poly, src_rows) block to a (poly, dst_rows) block: one strided copy
+static int copy_leading_limbs(rh_ring* r, u64* dst, int dst_rows, const u64* src, int src_rows, int limbs, int npoly) {
+  const size_t N = (size_t)r->N;
+  if (limbs <= 0 || npoly <= 0) return RH_OK;
+  if (hipMemcpy2DAsync(dst, (size_t)dst_rows * N * 8, src, (size_t)src_rows * N * 8, (size_t)limbs * N * 8, (size_t)npoly, hipMemcpyDeviceToDevice,
+                       rh_stream(r)) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "rescale: strided copy failed");
+  return RH_OK;
+}
 static int launched(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "%s launch failed: %s", what, hipGetErrorString(e));
@@ -123,19 +131,16 @@ static int launched(const char* what) {
 extern "C" int rh_ring_div_by_last_modulus_many(rh_ring* r, int round, int level, int nb, uint64_t* p0, uint64_t* p1, int p1_rows, int npoly) {
   if (int rc = check_args(r, level, nb, p0, p1, npoly, p1_rows)) return rc;
   if (npoly == 0) return RH_OK;
+  std::lock_guard<std::recursive_mutex> lk(r->mu);          // lazily built per-level tables and shared scratch
   const int N = r->N;
   dim3 grid((N + 255) / 256, npoly);
-  if (nb == 0) {
-    for (int p = 0; p < npoly; ++p)
-      (void)hipMemcpyAsync(p1 + (size_t)p * p1_rows * N, p0 + (size_t)p * (level + 1) * N, (size_t)(level + 1) * N * 8, hipMemcpyDeviceToDevice, r->stream);
-    return RH_OK;
-  }
+  if (nb == 0) return copy_leading_limbs(r, p1, p1_rows, p0, level + 1, level + 1, npoly);
   // steps 0..nb-2 run in place on p0 (as the reference does on buff), the last one writes p1
   for (int j = 0; j < nb; ++j) {
     const int lv = level - j;
     RescaleLimb* T; if (int rc = rescale_table(r, lv, &T)) return rc;
     const bool last = j == nb - 1;
-    rescale_step_kernel<<<grid, 256, 0, r->stream>>>(round ? 1 : 0, p0, level + 1, last ? p1 : p0, last ? p1_rows : level + 1, lv, N, r->moduli[lv], T);
+    rescale_step_kernel<<<grid, 256, 0, rh_stream(r)>>>(round ? 1 : 0, p0, level + 1, last ? p1 : p0, last ? p1_rows : level + 1, lv, N, r->moduli[lv], T);
   }
   return launched("rescale_step_kernel");
 }
@@ -144,32 +149,29 @@ extern "C" int rh_ring_div_by_last_modulus_many(rh_ring* r, int round, int level
 extern "C" int rh_ring_div_by_last_modulus_many_ntt(rh_ring* r, int round, int level, int nb, const uint64_t* p0, uint64_t* p1, int p1_rows, int npoly) {
   if (int rc = check_args(r, level, nb, p0, p1, npoly, p1_rows)) return rc;
   if (npoly == 0) return RH_OK;
+  std::lock_guard<std::recursive_mutex> lk(r->mu);          // lazily built per-level tables and shared scratch
   const int N = r->N;
   dim3 grid((N + 255) / 256, npoly);
-  if (nb == 0) {
-    for (int p = 0; p < npoly; ++p)
-      (void)hipMemcpyAsync(p1 + (size_t)p * p1_rows * N, p0 + (size_t)p * (level + 1) * N, (size_t)(level + 1) * N * 8, hipMemcpyDeviceToDevice, r->stream);
-    return RH_OK;
-  }
+  if (nb == 0) return copy_leading_limbs(r, p1, p1_rows, p0, level + 1, level + 1, npoly);
   if (nb == 1) {
     // INTT of the last limb only, re-expansion under every remaining modulus, NTT, fused subtract-multiply
     if (int rc = ensure_scratch(r, 0, (size_t)npoly * N)) return rc;
     if (int rc = ensure_scratch(r, 1, (size_t)npoly * level * N)) return rc;
     RescaleLimb* T; if (int rc = rescale_table(r, level, &T)) return rc;
     u64* tmp = r->d_rs[0]; u64* buff = r->d_rs[1];
-    gather_limb_kernel<<<grid, 256, 0, r->stream>>>(p0, level + 1, level, tmp, N);
+    gather_limb_kernel<<<grid, 256, 0, rh_stream(r)>>>(p0, level + 1, level, tmp, N);
     if (int rc = rh_std_ntt_launch(r, tmp, tmp, npoly, 1, level, true, true, 0)) return rc;
     if (level > 0 && rh_can_fuse_submul(r)) {          // p1 = MRed(2q - p0 + NTT(buff), c_i) in the tile kernel's epilogue (:120-124)
       std::vector<u64> sc(level);
       for (int i = 0; i < level; ++i) sc[i] = rh::mform(r->moduli[i] - rh::invmod_prime(r->moduli[level] % r->moduli[i], r->moduli[i]), r->moduli[i]);
       const bool fuse_expand = r->logN > 12 && r->logN <= 17;       // the re-expansion feeds the column stages directly
       if (fuse_expand) { if (int rc = rh_std_ntt_expand_cols_launch(r, tmp, buff, npoly, level, T, round ? 1 : 0, r->moduli[level])) return rc; }
-      else rescale_expand_kernel<<<grid, 256, 0, r->stream>>>(round ? 1 : 0, tmp, buff, level, level, N, r->moduli[level], T);
+      else rescale_expand_kernel<<<grid, 256, 0, rh_stream(r)>>>(round ? 1 : 0, tmp, buff, level, level, N, r->moduli[level], T);
       return rh_std_ntt_submul_launch(r, buff, npoly, level, 0, p0, level + 1, p1, p1_rows, sc.data(), fuse_expand);
     }
-    rescale_expand_kernel<<<grid, 256, 0, r->stream>>>(round ? 1 : 0, tmp, buff, level, level, N, r->moduli[level], T);
+    rescale_expand_kernel<<<grid, 256, 0, rh_stream(r)>>>(round ? 1 : 0, tmp, buff, level, level, N, r->moduli[level], T);
     if (level > 0) if (int rc = rh_std_ntt_launch(r, buff, buff, npoly, level, 0, false, false, 0)) return rc;
-    rescale_finish_kernel<<<grid, 256, 0, r->stream>>>(buff, level, p0, level + 1, p1, p1_rows, level, N, T);
+    rescale_finish_kernel<<<grid, 256, 0, rh_stream(r)>>>(buff, level, p0, level + 1, p1, p1_rows, level, N, T);
     return launched("rescale (NTT domain)");
   }
   // nb > 1: INTT everything, divide nb times in the coefficient domain, NTT what is left (:44-51, :142-150)
@@ -179,20 +181,24 @@ extern "C" int rh_ring_div_by_last_modulus_many_ntt(rh_ring* r, int round, int l
   for (int j = 0; j < nb; ++j) {
     const int lv = level - j;
     RescaleLimb* T; if (int rc = rescale_table(r, lv, &T)) return rc;
-    rescale_step_kernel<<<grid, 256, 0, r->stream>>>(round ? 1 : 0, buff, level + 1, buff, level + 1, lv, N, r->moduli[lv], T);
+    rescale_step_kernel<<<grid, 256, 0, rh_stream(r)>>>(round ? 1 : 0, buff, level + 1, buff, level + 1, lv, N, r->moduli[lv], T);
   }
   const int out_limbs = level + 1 - nb;
-  // forward transform of limbs 0..level-nb of each poly: rows are strided by level+1 in buff, so go poly by poly
-  // when the strides differ, else in one batch
-  if (p1_rows == level + 1) {
-    // transform in place over all level+1 rows is wasteful; compact copy first
-  }
+  // forward transform of limbs 0..level-nb of each poly: rows are strided by level+1 in buff -> compact, transform, scatter
   if (int rc = ensure_scratch(r, 0, (size_t)npoly * out_limbs * N)) return rc;
   u64* cmp = r->d_rs[0];
-  for (int p = 0; p < npoly; ++p)
-    (void)hipMemcpyAsync(cmp + (size_t)p * out_limbs * N, buff + (size_t)p * (level + 1) * N, (size_t)out_limbs * N * 8, hipMemcpyDeviceToDevice, r->stream);
+  if (int rc = copy_leading_limbs(r, cmp, out_limbs, buff, level + 1, out_limbs, npoly)) return rc;
   if (int rc = rh_std_ntt_launch(r, cmp, cmp, npoly, out_limbs, 0, false, false, 0)) return rc;
-  for (int p = 0; p < npoly; ++p)
-    (void)hipMemcpyAsync(p1 + (size_t)p * p1_rows * N, cmp + (size_t)p * out_limbs * N, (size_t)out_limbs * N * 8, hipMemcpyDeviceToDevice, r->stream);
+  if (int rc = copy_leading_limbs(r, p1, p1_rows, cmp, out_limbs, out_limbs, npoly)) return rc;
   return launched("rescale many (NTT domain)");
+}
+
+// rh_ring_reserve, standard rings: the rescale scratch for batches of up to npoly polys and the per-level constant tables, so
+// that no later call allocates (hipMalloc / hipFree synchronise the device and cannot be captured in a HIP graph)
+int rh_rescale_reserve(rh_ring* r, int npoly) {
+  if (r->kind != RH_RING_STANDARD) return RH_OK;
+  if (int rc = ensure_scratch(r, 0, (size_t)npoly * r->L * r->N)) return rc;
+  if (int rc = ensure_scratch(r, 1, (size_t)npoly * r->L * r->N)) return rc;
+  for (int lv = 1; lv < r->L; ++lv) { RescaleLimb* T; if (int rc = rescale_table(r, lv, &T)) return rc; }
+  return RH_OK;
 }

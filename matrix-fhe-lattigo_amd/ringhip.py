@@ -80,7 +80,7 @@ def lib():
         "rh_ring_destroy": (None, [vp]),
         "rh_ring_n": (i, [vp]), "rh_ring_limbs": (i, [vp]),
         "rh_ring_get_constants": (i, [vp, U64P, U64P, U64P, U64P, U64P, U64P, U64P]),
-        "rh_ring_set_stream": (i, [vp, vp]), "rh_ring_sync": (i, [vp]),
+        "rh_ring_set_stream": (i, [vp, vp]), "rh_ring_sync": (i, [vp]), "rh_ring_reserve": (i, [vp, i]),
         "rh_dev_alloc": (i, [vp, sz, C.POINTER(vp)]), "rh_dev_free": (i, [vp, vp]),
         "rh_dev_upload": (i, [vp, vp, U64P, sz]), "rh_dev_download": (i, [vp, U64P, vp, sz]),
         "rh_ntt_forward": (i, [vp, i, U64P, U64P]), "rh_ntt_forward_lazy": (i, [vp, i, U64P, U64P]),
@@ -94,7 +94,7 @@ def lib():
         "rh_ring_automorphism_ntt": (i, [vp, i, vp, C.c_uint64, vp, i, i]),
         "rh_ring_automorphism": (i, [vp, i, vp, C.c_uint64, vp, i]),
         "rh_ring_tensor_degree1": (i, [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i]),
-        "rh_bext_create": (i, [C.POINTER(vp), vp, vp]), "rh_bext_destroy": (None, [vp]),
+        "rh_bext_create": (i, [C.POINTER(vp), vp, vp]), "rh_bext_destroy": (None, [vp]), "rh_bext_reserve": (i, [vp, i]),
         "rh_bext_modup_q_to_p": (i, [vp, i, i, vp, vp, i]), "rh_bext_modup_p_to_q": (i, [vp, i, i, vp, vp, i]),
         "rh_bext_moddown_qp_to_q": (i, [vp, i, i, vp, vp, vp, i]),
         "rh_bext_moddown_qp_to_q_ntt": (i, [vp, i, i, vp, vp, vp, i]),
@@ -272,6 +272,10 @@ class Ring:
     def sync(self):
         _check(lib().rh_ring_sync(self._h))
 
+    def reserve(self, npoly):
+        """pre-size the ring's lazily grown scratch (rescale, 3N workspace) for batches of npoly polys: no allocation afterwards"""
+        _check(lib().rh_ring_reserve(self._h, int(npoly)))
+
     def close(self):
         if getattr(self, "_h", None) and not getattr(self, "_view", False):
             lib().rh_ring_destroy(self._h)
@@ -393,6 +397,9 @@ class BasisExtender:
         h = C.c_void_p()
         _check(lib().rh_bext_create(C.byref(h), ringQ._h, ringP._h))
         self._h = h
+
+    def reserve(self, npoly):
+        _check(lib().rh_bext_reserve(self._h, int(npoly)))
 
     def ModUpQtoP(self, levelQ, levelP, polQ, polP):
         _check(lib().rh_bext_modup_q_to_p(self._h, levelQ, levelP, polQ.ptr, polP.ptr, polQ.npoly))

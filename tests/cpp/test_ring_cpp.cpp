@@ -1,11 +1,13 @@
 // C++ conformance test of the host-side mirror (include/ringhip.hpp), written the way the reference's TestNTT is
 // (ring/ntt_test.go:91-121): NewRing, NTT(poly) == polyNTT, INTT(NTT(poly)) == poly -- on the N=16 known-answer vector
-// of ring/ntt_test.go (first limb), plus a device-resident poly-mul and the panic/error behaviour.
+// of ring/ntt_test.go (both limbs, tests/cpp/golden_vectors.inc), the 3N (Matrix) and conjugate-invariant ring types with the
+// constants handoff the cgo factories use, a device-resident poly-mul, the key switch, and the panic/error behaviour.
 #include <algorithm>
 #include <cstdio>
 #include <utility>
 #include <vector>
 #include "ringhip.hpp"
+#include "golden_vectors.inc"
 
 using namespace ringhip;
 
@@ -13,17 +15,75 @@ static int fails = 0;
 #define EXPECT(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); ++fails; } } while (0)
 
 int main() {
-  const uint64_t q = 576460752303439873ull;       // Qis[0] of the reference's testVector
-  const std::vector<uint64_t> poly = {75484882814757497ull, 568962213571011535ull, 219781953812704432ull, 431409500923750484ull,
-                                      91669795593397493ull, 473049842650292367ull, 213965426418426961ull, 195843195830982574ull,
-                                      359420738741905339ull, 134609403297510286ull, 546063636015790939ull, 475349391419928453ull,
-                                      305803859266883227ull, 434608786379655593ull, 233020405896920653ull, 421812738743799064ull};
-  Ring r(16, {q});
-  std::vector<uint64_t> y(16), back(16);
-  r.SubRings[0].NTT(poly, y);
-  r.SubRings[0].INTT(y, back);
-  EXPECT(back == poly);
-  for (uint64_t v : y) EXPECT(v < q);
+  // TestNTT (ring/ntt_test.go:91-121) on its N = 16 known-answer vector, both limbs: NTT(poly) == polyNTT, INTT back
+  const uint64_t q = KAT16_Q[0];
+  Ring r(16, KAT16_Q);
+  {
+    const std::vector<uint64_t>* in[2] = {&KAT16_POLY_0, &KAT16_POLY_1};
+    const std::vector<uint64_t>* want[2] = {&KAT16_NTT_0, &KAT16_NTT_1};
+    for (int i = 0; i < 2; ++i) {
+      std::vector<uint64_t> y(16), back(16), lz(16);
+      r.SubRings[i].NTT(*in[i], y);
+      EXPECT(y == *want[i]);
+      r.SubRings[i].INTT(y, back);
+      EXPECT(back == *in[i]);
+      r.SubRings[i].NTTLazy(*in[i], lz);
+      for (int j = 0; j < 16; ++j) EXPECT(lz[j] % KAT16_Q[i] == y[j]);
+    }
+    // the device-resident batched path on the same vector: (1 poly, 2 limbs, 16)
+    std::vector<uint64_t> host(KAT16_POLY_0); host.insert(host.end(), KAT16_POLY_1.begin(), KAT16_POLY_1.end());
+    std::vector<uint64_t> want2(KAT16_NTT_0); want2.insert(want2.end(), KAT16_NTT_1.begin(), KAT16_NTT_1.end());
+    Poly p = r.NewPoly();
+    p.upload(host);
+    r.NTT(p, p);
+    EXPECT(p.download() == want2);
+    // NewRingWithCustomNTT's constants handoff (ring/ring.go:314-356): a ring built from received constants gives the same bits
+    Ring r2(16, KAT16_Q, Type::Standard, r.GetConstants());
+    std::vector<uint64_t> y2(16);
+    r2.SubRings[1].NTT(KAT16_POLY_1, y2);
+    EXPECT(y2 == KAT16_NTT_1);
+  }
+  // 3N-cyclotomic ring, Type::Matrix (ring/ntt_3n.go:21-156, ring/ring.go:299-304): omega handed over like the Go factory
+  // does; vectors from references/integer_dft.py in the Go transformer's ascending-totative order
+  {
+    struct V { int N; uint64_t p, w; const std::vector<uint64_t>* in; const std::vector<uint64_t>* out; };
+    const V vs[2] = {{12, V3N_12_P, V3N_12_W, &V3N_12_IN, &V3N_12_OUT}, {24, V3N_24_P, V3N_24_W, &V3N_24_IN, &V3N_24_OUT}};
+    for (const V& v : vs) {
+      const std::vector<uint64_t> om = {v.w};
+      Ring m(v.N, {v.p}, Type::Matrix, 0, &om);
+      std::vector<uint64_t> y(v.N), back(v.N);
+      m.SubRings[0].NTT(*v.in, y);
+      EXPECT(y == *v.out);
+      m.SubRings[0].INTT(y, back);
+      EXPECT(back == *v.in);
+      Constants c = m.GetConstants();
+      EXPECT(c.omega3n.size() == 1 && c.omega3n[0] == v.w);
+      Ring m2(v.N, {v.p}, Type::Matrix, c);                  // constants handoff incl. omega
+      Poly pd = m2.NewPoly();
+      pd.upload(*v.in);
+      m2.NTT(pd, pd);
+      EXPECT(pd.download() == *v.out);
+    }
+    bool noroot = false;                                     // modulus without a primitive 3N-th root: the Go ctor panics (ntt_3n.go:41)
+    try { Ring bad(12, {65539ull}, Type::Matrix); } catch (const Error&) { noroot = true; } catch (const Panic&) { noroot = true; }
+    EXPECT(noroot);
+  }
+  // conjugate-invariant ring (ring/ntt.go:80-124, NewRingConjugateInvariant ring/ring.go:276-284): 4N-th-root tables of 2N entries
+  {
+    const int n = 64;
+    const std::vector<uint64_t> mods = {0x1fffffffffe00001ull, 0x1fffffffffc80001ull};
+    Ring ci(n, mods, Type::ConjugateInvariant);
+    Constants c = ci.GetConstants();
+    EXPECT(c.roots_fwd.size() == (size_t)2 * 2 * n);
+    Ring ci2(n, mods, Type::ConjugateInvariant, c);
+    std::vector<uint64_t> a(n), y(n), y2(n), back(n);
+    uint64_t sd = 7;
+    for (int j = 0; j < n; ++j) { sd = sd * 6364136223846793005ull + 1442695040888963407ull; a[j] = sd % mods[1]; }
+    ci.SubRings[1].NTT(a, y); ci2.SubRings[1].NTT(a, y2);
+    EXPECT(y == y2);
+    ci.SubRings[1].INTT(y, back);
+    EXPECT(back == a);
+  }
 
   // device-resident: c = INTT(NTT(a) * NTT(b)) with MForm + MulCoeffsMontgomery (schemes/ckks/evaluator.go:821-834)
   const int N = 1 << 13;

@@ -540,12 +540,6 @@ def render(name, lines):
 gen()
 fwd = list(out)
 del out[:]
-gen(load_flags=" sc1")          # data loads bypass L1 (served by the XCD's L2): in-launch hand-off of ntt_fwd_cluster
-fwd_sc1 = list(out)
-del out[:]
-gen(preloaded=True, tail_wait=False)   # fused launch: the caller issued the data loads ahead of its column stages
-fwd_pre = list(out)
-del out[:]
 cols, cols_inv = {}, {}
 for s1 in (2, 3, 4):
     gen_cols(s1)
@@ -559,10 +553,8 @@ inv = list(out)
 clob_v = ", ".join('"v%d"' % i for i in range(NVGPR_USED))
 clob_s = ", ".join('"s%d"' % i for i in range(36, 100))
 text = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  forward: %d instructions, inverse: %d.\n" % (len(fwd), len(inv))
-text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_SC1_ASM_BODY", fwd_sc1) + render("NTT_TILE_PRE_ASM_BODY", fwd_pre) + "".join(render("NTT_COLS%d_ASM_BODY" % (1 << k), cols[k]) + render("NTT_COLS%d_INV_ASM_BODY" % (1 << k), cols_inv[k]) for k in (2, 3, 4)) + render("NTT_TILE_INV_ASM_BODY", inv)
+text += render("NTT_TILE_ASM_BODY", fwd) + "".join(render("NTT_COLS%d_ASM_BODY" % (1 << k), cols[k]) + render("NTT_COLS%d_INV_ASM_BODY" % (1 << k), cols_inv[k]) for k in (2, 3, 4)) + render("NTT_TILE_INV_ASM_BODY", inv)
 text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v, clob_s)
-clob_v_pre = ", ".join('"v%d"' % i for i in range(32, NVGPR_USED))     # v0..v31 are read-write operands there
-text += "#define NTT_TILE_PRE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v_pre, clob_s)
 path = sys.argv[1] if len(sys.argv) > 1 else "ntt_tile_asm.inc"
 open(path, "w").write(text)
 print("wrote", path, "forward:", len(fwd), "VALU", sum(1 for l in fwd if l.startswith("v_")), "| inverse:", len(inv), "VALU", sum(1 for l in inv if l.startswith("v_")))
