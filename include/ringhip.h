@@ -108,6 +108,12 @@ int rh_ntt_backward_lazy(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2)
 int rh_ring_ntt(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int lazy);
 int rh_ring_intt(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int lazy);
 
+/* INTT of a pointwise product, NTT-domain inputs: out = INTT(a . b), the values of ring.MForm(a, t); ring.MulCoeffsMontgomery(t, b, c);
+ * ring.INTT(c, c) (the degree-0 part of ckks mulRelin, schemes/ckks/evaluator.go:821-834, and BASELINE config 3) -- canonical, hence
+ * bit-identical -- with the product formed on load by the inverse transform's first kernel: 24 bytes per coefficient less traffic
+ * than the three calls.  a, b: npoly polys of level+1 limbs, canonical or lazy (< 2q); out may alias either.  Standard rings. */
+int rh_ring_intt_mul(rh_ring* r, const uint64_t* a_dev, const uint64_t* b_dev, uint64_t* out_dev, int npoly, int level);
+
 /* profiling aid: phase 0 = whole transform, 1 = column kernel only, 2 = tile kernel only (N >= 8192) */
 int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int inverse, int phase);
 /* Tuning knobs: performance only, never results (each non-default setting is covered by a parity test).  Unknown keys

@@ -29,7 +29,7 @@ static thread_local hipStream_t tl_stream = nullptr;
 static thread_local bool tl_has_stream = false;
 static thread_local u64* tl_ws = nullptr;
 static thread_local size_t tl_ws_words = 0;
-hipStream_t rh_stream(const rh_ring* r) { return tl_has_stream ? tl_stream : rh_stream(r); }
+hipStream_t rh_stream(const rh_ring* r) { return tl_has_stream ? tl_stream : r->stream; }
 u64* rh_ws_override(size_t words) { return (tl_ws && tl_ws_words >= words) ? tl_ws : nullptr; }
 RhCallScope::RhCallScope(hipStream_t st, u64* ws, size_t ws_words) : prev_st(tl_stream), prev_has(tl_has_stream), prev_ws(tl_ws), prev_words(tl_ws_words) {
   tl_stream = st; tl_has_stream = true;
@@ -170,6 +170,17 @@ extern "C" int rh_ring_create(rh_ring** out, int device, int kind, int N, int L,
       }
     }
     if (!rc) rc = rh_std_upload_tables(r, fs, is, &mont, lastw);
+    if (!rc && kind == RH_RING_STANDARD) {          // N^-1 * 2^64 = NInv as handed over (Montgomery form): constants of rh_ring_intt_mul
+      std::vector<LimbConsts> hr(hc); std::vector<tw2> lr(L);
+      for (int i = 0; i < L; ++i) {
+        const u64 q = moduli[i], nr = ninv[i] % q;
+        hr[i].ninv_w = nr; hr[i].ninv_wp = rh::shoup_quotient(nr, q);
+        const u64 lw = rh::mulmod(is[(size_t)i * N + 1].w, nr, q);
+        lr[i] = tw2{lw, rh::shoup_quotient(lw, q)};
+      }
+      rc = upload(&r->d_consts_r, hr);
+      if (!rc) rc = upload(&r->d_lastw_r, lr);
+    }
     if (!rc && N < 16) {
       std::vector<u64> bm((size_t)L * N);
       for (int i = 0; i < L; ++i) for (int j = 0; j < N; ++j) {
@@ -221,7 +232,7 @@ extern "C" int rh_ring_create_auto(rh_ring** out, int device, int kind, int N, i
 extern "C" void rh_ring_destroy(rh_ring* r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
-  void* ptrs[] = {r->d_cifold, r->d_consts, r->d_tw_fwd, r->d_tw_inv, r->d_tw_fwd_mont, r->d_twk_fwd, r->d_twk_inv, r->d_twk_fwd_mont, r->d_lastw, r->d_tw_inv_mont};
+  void* ptrs[] = {r->d_cifold, r->d_consts, r->d_tw_fwd, r->d_tw_inv, r->d_tw_fwd_mont, r->d_twk_fwd, r->d_twk_inv, r->d_twk_fwd_mont, r->d_lastw, r->d_tw_inv_mont, r->d_consts_r, r->d_lastw_r};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (RhHostSlot* sl : r->all_slots) {
     if (sl->buf) (void)hipFree(sl->buf);
@@ -557,6 +568,39 @@ extern "C" int rh_ring_intt(rh_ring* r, const uint64_t* in, uint64_t* out, int n
 extern "C" int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, int inverse, int phase) {
   if (phase < 0 || phase > 2) return rh_fail(RH_ERR_ARG, "phase must be 0, 1 or 2");
   return ntt_batch(r, in, out, npoly, level, inverse != 0, false, phase);
+}
+
+// INTT(a . b) for NTT-domain blocks a, b (canonical or lazy < 2q): the values ring.MForm(a) -> ring.MulCoeffsMontgomery(., b) ->
+// ring.INTT produce (schemes/ckks/evaluator.go:821-834 + :INTT; BASELINE config 3), with the product formed on load by the inverse
+// tile kernel (MRedLazy) and the factor 2^64 restored by the N^-1 constants of the last inverse stage.  Outputs are canonical
+// residues of a*b*N^-1-transform, hence bit-identical to the three-call sequence.  out may alias a or b.
+static int std_intt_mul_launch(rh_ring* r, const u64* a, const u64* b, u64* out, int npoly, int Lrows) {
+  const int logN = r->logN;
+  const unsigned rows = (unsigned)npoly * (unsigned)Lrows;
+  if (rows == 0) return RH_OK;
+  hipStream_t st = rh_stream(r);
+  if (logN < LT) {                                   // small rings: the three calls as they are (not a throughput path)
+    if (int rc = rh_vec_launch(r, RH_OP_MFORM, a, nullptr, out, npoly, Lrows, 0, nullptr, nullptr)) return rc;
+    if (int rc = rh_vec_launch(r, RH_OP_MUL_MONT, out, b, out, npoly, Lrows, 0, nullptr, nullptr)) return rc;
+    return rh_std_ntt_launch(r, out, out, npoly, Lrows, 0, true, false, 0);
+  }
+  (void)hipGetLastError();
+  const int S1 = logN - LT;
+  ntt_inv_tile_mul<<<rows << S1, 256, 0, st>>>(a, b, out, r->d_twk_inv, r->d_consts_r, Lrows, logN, S1 == 0 ? 1 : 0, npoly);
+  if (S1 >= 2 && S1 <= 4 && r->asm_cols && r->asm_tile) {
+    if (S1 == 4) ntt_inv_cols_asm<4><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows);
+    else if (S1 == 3) ntt_inv_cols_asm<3><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows);
+    else ntt_inv_cols_asm<2><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows);
+  } else if (S1 > 0) launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows, logN, 1);
+  return check_launch("intt_mul");
+}
+extern "C" int rh_ring_intt_mul(rh_ring* r, const uint64_t* a, const uint64_t* b, uint64_t* out, int npoly, int level) {
+  if (!r || !a || !b || !out) return rh_fail(RH_ERR_ARG, "intt_mul: null argument");
+  if (r->kind != RH_RING_STANDARD) return rh_fail(RH_ERR_UNSUPPORTED, "intt_mul: standard rings only");
+  if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "intt_mul: level %d out of range [0,%d)", level, r->L);
+  if (npoly < 0) return rh_fail(RH_ERR_ARG, "intt_mul: npoly < 0");
+  (void)hipSetDevice(r->device);
+  return std_intt_mul_launch(r, a, b, out, npoly, level + 1);
 }
 
 // Pre-sizes every lazily grown scratch of the ring for batches of up to npoly polys (all limbs): afterwards no entry point of

@@ -31,6 +31,8 @@ struct rh_ring {
   u64* d_tw_inv_mont = nullptr;   // N < 16 only: RootsBackward as given, for the non-canonical BackwardLazy of tiny rings
   CiFold* d_cifold = nullptr;     // conjugate-invariant rings only
   tw2* d_lastw = nullptr;         // psi_bwd[1] * N^-1 per limb
+  LimbConsts* d_consts_r = nullptr;   // standard rings: d_consts with N^-1 replaced by N^-1 * 2^64 (rh_ring_intt_mul: the inverse
+  tw2* d_lastw_r = nullptr;           //   transform of a Montgomery product restores the factor in its last stage), and lastw likewise
   // host-pointer single-limb path (rh_ntt_*): a pool of (stream, scratch) slots, one per concurrent caller
   std::mutex slot_mu;
   std::vector<struct RhHostSlot*> free_slots, all_slots;

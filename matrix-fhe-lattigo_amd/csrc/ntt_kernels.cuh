@@ -222,15 +222,16 @@ ntt_fwd_tile_submul(const u64* in, const tw2* __restrict__ twk, const LimbConsts
 // K2 inverse: first 12 stages (t = 1..2048) on a 4096-tile.  If `last` (logN == 12) the N^-1 scaling and the
 // canonical reduction happen here, else values leave < 4q for K1 inverse.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-ntt_inv_tile(const u64* in, u64* out, const tw2* __restrict__ twk,
-             const LimbConsts* __restrict__ consts, int L, int logN, int last, int npoly) {
-  __shared__ u64 lds[LDS_WORDS];
+// MUL: the input is the pointwise product of two NTT-domain blocks, formed on load as MRedLazy(in, in2) = in*in2*2^-64 (< 2q for
+// inputs < 2q): INTT(a . b) without the element-wise passes of MForm + MulCoeffsMontgomery (schemes/ckks/evaluator.go:821-834
+// followed by INTT).  The missing factor 2^64 rides in the N^-1 constants of the LAST inverse stage (the caller passes the
+// 2^64-scaled constant sets: consts here when `last`, else to the column kernel), so the canonical result is the same residue.
+template <bool MUL>
+RH_DEV void inv_tile_body(u64* lds, const u32 b, const u64* in, const u64* in2, u64* out, const tw2* __restrict__ twk,
+                          const LimbConsts* __restrict__ consts, int L, int logN, int last, int npoly) {
   const int tid = threadIdx.x;
-  const u32 b = blockIdx.x;
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
-  const int S1 = logN - LT;
   // poly is the fast index: workgroups resident at the same time work on the SAME tile of different polys, so that
   // tile's twiddles (64 KiB per limb) are served by the XCD's L2 instead of being re-fetched per poly
   const u32 poly = r % (u32)npoly;
@@ -242,7 +243,11 @@ ntt_inv_tile(const u64* in, u64* out, const tw2* __restrict__ twk,
 
   u64 x[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) lds[LDS_PAD(tid + 256 * k)] = in[base + tid + 256 * k];
+  for (int k = 0; k < 16; ++k) {
+    u64 v = in[base + tid + 256 * k];
+    if (MUL) v = mred_lazy(v, in2[base + tid + 256 * k], c.q, c.qinv);
+    lds[LDS_PAD(tid + 256 * k)] = v;
+  }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 16; ++k) x[k] = lds[LDS_PAD(tid * 16 + k)];
@@ -266,6 +271,18 @@ ntt_inv_tile(const u64* in, u64* out, const tw2* __restrict__ twk,
   }
 #pragma unroll
   for (int k = 0; k < 16; ++k) out[base + tid + 256 * k] = x[k];
+}
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+ntt_inv_tile(const u64* in, u64* out, const tw2* __restrict__ twk,
+             const LimbConsts* __restrict__ consts, int L, int logN, int last, int npoly) {
+  __shared__ u64 lds[LDS_WORDS];
+  inv_tile_body<false>(lds, blockIdx.x, in, nullptr, out, twk, consts, L, logN, last, npoly);
+}
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+ntt_inv_tile_mul(const u64* in, const u64* in2, u64* out, const tw2* __restrict__ twk,
+                 const LimbConsts* __restrict__ consts, int L, int logN, int last, int npoly) {
+  __shared__ u64 lds[LDS_WORDS];
+  inv_tile_body<true>(lds, blockIdx.x, in, in2, out, twk, consts, L, logN, last, npoly);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

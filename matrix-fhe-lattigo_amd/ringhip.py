@@ -87,6 +87,7 @@ def lib():
         "rh_ntt_backward": (i, [vp, i, U64P, U64P]), "rh_ntt_backward_lazy": (i, [vp, i, U64P, U64P]),
         "rh_ring_ntt": (i, [vp, vp, vp, i, i, i]), "rh_ring_intt": (i, [vp, vp, vp, i, i, i]),
         "rh_ring_ntt_phase": (i, [vp, vp, vp, i, i, i, i]),
+        "rh_ring_intt_mul": (i, [vp, vp, vp, vp, i, i]),
         "rh_ring_set_tuning": (i, [vp, C.c_char_p, C.c_long]),
         "rh_ring_vec_op": (i, [vp, i, vp, vp, vp, i, i, U64P, U64P]),
         "rh_ring_div_by_last_modulus_many": (i, [vp, i, i, i, vp, vp, i, i]),
@@ -312,6 +313,11 @@ class Ring:
 
     def INTTLazy(self, p1, p2):
         self._chk(p1, p2); _check(lib().rh_ring_intt(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 1))
+
+    def INTTMul(self, p1, p2, p3):
+        """p3 = INTT(p1 . p2) for NTT-domain p1, p2: the values of MForm(p1, t); MulCoeffsMontgomery(t, p2, p3); INTT(p3, p3)
+        (schemes/ckks/evaluator.go:821-834 + INTT), with the product formed on load inside the inverse transform"""
+        self._chk(p1, p2, p3); _check(lib().rh_ring_intt_mul(self._h, p1.ptr, p2.ptr, p3.ptr, p1.npoly, self.level))
 
     # ---- automorphisms (ring/automorphism.go) ---------------------------------------------------------------
     def TensorDegree1(self, a0, a1, b0, b1, c0, c1, c2, mform_first=True):

@@ -80,11 +80,16 @@ def ckks_tensor_degree1(ringQ, ct0, ct1, c0, c1, c2, c00, c01):
     ringQ.MulCoeffsMontgomery(c01, ct1.Value[1], c2)
 
 
-def ckks_polymul(ringQ, a, b, c, tmp):
+def ckks_polymul(ringQ, a, b, c, tmp=None, fused=True):
     """BASELINE config 3: c = INTT(NTT(a) . NTT(b)) with MForm + MulCoeffsMontgomery as mulRelin sequences it
-    (schemes/ckks/evaluator.go:821-834).  a and b are transformed in place (they end in the NTT domain)."""
+    (schemes/ckks/evaluator.go:821-834).  a and b are transformed in place (they end in the NTT domain).
+    fused (default): MForm, MulCoeffsMontgomery and the inverse transform as ONE call (Ring.INTTMul: the product is formed on
+    load by the inverse transform's first kernel) -- same canonical values; fused=False: the five ring calls as written."""
     ringQ.NTT(a, a)
     ringQ.NTT(b, b)
+    if fused and ringQ.kind == 0:
+        ringQ.INTTMul(a, b, c)
+        return
     ringQ.MForm(a, tmp)
     ringQ.MulCoeffsMontgomery(tmp, b, c)
     ringQ.INTT(c, c)

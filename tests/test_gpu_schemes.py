@@ -166,3 +166,33 @@ def test_config3_polymul(rh, oracle):
     sr = oracle.SubRingConsts(N, mods[2])
     assert np.array_equal(pa.numpy()[2, 2], oracle.ntt(a[2, 2], sr))
     ring.close()
+
+
+@pytest.mark.parametrize("logN,L,B", [(6, 2, 2), (12, 3, 3), (13, 2, 3), (15, 16, 3), (16, 3, 2)])
+def test_intt_mul_equals_the_three_ring_calls(rh, oracle, logN, L, B):
+    # Ring.INTTMul (rh_ring_intt_mul): INTT(a . b) with the product formed on load == MForm; MulCoeffsMontgomery; INTT
+    # (schemes/ckks/evaluator.go:821-834 + INTT), and one limb against the oracle sequence; lazy inputs (< 2q) accepted
+    N, mods = 1 << logN, QI60[:L]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(logN * 7 + L)
+    mk = lambda: np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    a, b = mk(), mk()
+    a[0, :, 0] = 0; a[0, :, 1] = np.array(mods, dtype=np.uint64) - np.uint64(1); b[0, :, 1] = np.array(mods, dtype=np.uint64) - np.uint64(1)
+    pa, pb = rh.DevicePoly.from_numpy(ring, a), rh.DevicePoly.from_numpy(ring, b)
+    ref, tmp, got = ring.NewPoly(B), ring.NewPoly(B), ring.NewPoly(B)
+    ring.MForm(pa, tmp); ring.MulCoeffsMontgomery(tmp, pb, ref); ring.INTT(ref, ref)
+    ring.INTTMul(pa, pb, got)
+    assert np.array_equal(got.numpy(), ref.numpy())
+    assert np.array_equal(pa.numpy(), a) and np.array_equal(pb.numpy(), b)            # inputs untouched
+    i = L - 1
+    sr = oracle.SubRingConsts(N, mods[i])
+    z = np.zeros(N, dtype=np.uint64)
+    m = oracle.vec_op(rh.OPS["MFORM"], a[B - 1, i], None, z, 0, 0, mods[i])
+    e = oracle.intt(oracle.vec_op(rh.OPS["MUL_MONT"], m, b[B - 1, i], z, 0, 0, mods[i]), sr)
+    assert np.array_equal(got.numpy()[B - 1, i], e)
+    lazy = a.copy(); lazy[:, :, ::3] += np.array(mods, dtype=np.uint64)[None, :, None]   # representatives in [q, 2q)
+    ring.INTTMul(rh.DevicePoly.from_numpy(ring, lazy), pb, got)
+    assert np.array_equal(got.numpy(), ref.numpy())
+    ring.INTTMul(pa, pb, pa)                                                           # output aliases an input
+    assert np.array_equal(pa.numpy(), ref.numpy())
+    ring.close()

@@ -67,6 +67,12 @@ ms = timed(polymul, reps=5)
 e = entry("config3 poly-mul N=2^15 L=16 (NTT,NTT,MForm,MulCoeffsMontgomery,INTT)", ms, 88.0 * N * L * B, B, "polymul")
 e["frac_vs_fused_lower_bound_24NL"] = round(24.0 * N * L * B / (ms * 1e-3) / 1e9 / PEAK, 3)
 res.append(e)
+def polymul_fused():
+    ring.NTT(pa, pa); ring.NTT(pb, pb); ring.INTTMul(pa, pb, pa)
+ms = timed(polymul_fused, reps=5)
+e = entry("config3 poly-mul N=2^15 L=16, MForm + MulCoeffsMontgomery formed on load by the inverse transform (Ring.INTTMul)", ms, 88.0 * N * L * B, B, "polymul")
+e["frac_vs_fused_lower_bound_24NL"] = round(24.0 * N * L * B / (ms * 1e-3) / 1e9 / PEAK, 3)
+res.append(e)
 del pa, pb, a, b
 ring.close(); torch.cuda.empty_cache()
 
