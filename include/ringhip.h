@@ -114,6 +114,10 @@ int rh_ring_intt(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npol
  * than the three calls.  a, b: npoly polys of level+1 limbs, canonical or lazy (< 2q); out may alias either.  Standard rings. */
 int rh_ring_intt_mul(rh_ring* r, const uint64_t* a_dev, const uint64_t* b_dev, uint64_t* out_dev, int npoly, int level);
 
+/* 3N rings: NTT-domain blocks between the reference's ascending-totative order and block order (see ntt3n_block_order):
+ * to_reference = 1: block order -> reference order, 0: the reverse.  Out of place (in != out). */
+int rh_ring_ntt3n_reorder(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int to_reference);
+
 /* profiling aid: phase 0 = whole transform, 1 = column kernel only, 2 = tile kernel only (N >= 8192) */
 int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int inverse, int phase);
 /* Tuning knobs: performance only, never results (each non-default setting is covered by a parity test).  Unknown keys
@@ -124,7 +128,14 @@ int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int
  *   asm_tile / asm_cols   1: generated hand-scheduled bodies (default), 0: the C++ kernels
  *   fuse_submul     1: ModDown / rescale subtract-multiply in the forward tile kernel's epilogue (default)
  *   fuse3n          1: 3N rings, split + radix-3 layer fused with the sub-transforms' column stages (default)
- *   perm_inv_shape  3N inverse permutation tile: 32 / 64 (default) / 128 words per block-order run */
+ *   perm_inv_shape  3N inverse permutation tile: 32 / 64 (default) / 128 words per block-order run
+ * One key changes a LAYOUT, not a value (3N rings, N = 3*2^k >= 24576, default 0):
+ *   ntt3n_block_order  1: rh_ring_ntt / rh_ring_intt keep the NTT domain in "block order" (slot j of block c of the radix-2
+ *                   sub-transforms at word c*N/6 + j) instead of the Go transformer's ascending-totative order
+ *                   (ring/ntt_3n.go:82-109, :235-243).  Every NTT-domain operation of a ring is coefficient-wise, so NTT ->
+ *                   pointwise -> INTT chains (matrix_ckks.Evaluator.Mul) give the same coefficient-domain bits with one pass less
+ *                   per transform; NTT-domain data that crosses the host boundary is converted with rh_ring_ntt3n_reorder.  The
+ *                   per-limb host interface (rh_ntt_*) always speaks the reference order. */
 int rh_ring_set_tuning(rh_ring* r, const char* key, long value);
 
 /* ---- element-wise family (ring/vec_ops.go via ring/operations.go loops): p3 = op(p1, p2 [, p3]) on npoly polys of

@@ -353,7 +353,7 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
         else if (S1 == 2 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<2><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
       else      launch_fwd_cols<ShoupPolicy>(S1, g1, st, in, out, r->d_tw_fwd + toff, c, Lrows, logN, Ls);
       }
-      src = out;
+      if (phase != 2) src = out;                   // phase 2 (tile stages only): the caller's `in` holds the column stages' output
     }
     if (phase != 1) {
       const int ls = Ls ? Ls : Lrows;
@@ -416,34 +416,40 @@ static int std_ntt_fwd_pipelined(rh_ring* r, const u64* in, u64* out, int npoly,
 }
 
 template <int S1>
-static void launch_inv_fused(rh_ring* r, const u64* in1, u64* out1, unsigned n1, int npoly1, u64* data2, unsigned n2,
+static void launch_inv_fused(rh_ring* r, const u64* in1, const u64* in1b, u64* out1, unsigned n1, int npoly1, u64* data2, unsigned n2,
                              size_t toff, int limb0, const LimbConsts* c, int Lrows) {
   const unsigned grid = n1 > n2 ? n1 : n2;
-  if (S1 >= 2 && S1 <= 4 && r->asm_cols)
-    ntt_inv_fused_asm<S1, true><<<grid, 256, 0, rh_stream(r)>>>(in1, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff,
-                                                             r->d_lastw + limb0, c, Lrows, r->logN);
-  else
-    ntt_inv_fused_asm<S1, false><<<grid, 256, 0, rh_stream(r)>>>(in1, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff,
-                                                              r->d_lastw + limb0, c, Lrows, r->logN);
+  hipStream_t st = rh_stream(r);
+  const bool acols = S1 >= 2 && S1 <= 4 && r->asm_cols;
+  if (in1b) {                 // rh_ring_intt_mul: product on load, 2^64-scaled N^-1 constants (c = d_consts_r + limb0)
+    const tw2* lw = r->d_lastw_r + limb0;
+    if (acols) ntt_inv_fused_asm<S1, true, true><<<grid, 256, 0, st>>>(in1, in1b, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff, lw, c, Lrows, r->logN);
+    else ntt_inv_fused_asm<S1, false, true><<<grid, 256, 0, st>>>(in1, in1b, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff, lw, c, Lrows, r->logN);
+    return;
+  }
+  const tw2* lw = r->d_lastw + limb0;
+  if (acols) ntt_inv_fused_asm<S1, true, false><<<grid, 256, 0, st>>>(in1, nullptr, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff, lw, c, Lrows, r->logN);
+  else ntt_inv_fused_asm<S1, false, false><<<grid, 256, 0, st>>>(in1, nullptr, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff, lw, c, Lrows, r->logN);
 }
 // Inverse transform of a large batch: launch j = tile stages of span j fused with column stages (+ N^-1) of span j-1.
-static int std_ntt_inv_pipelined(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, int chunk) {
+static int std_ntt_inv_pipelined(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, int chunk, const u64* in_b = nullptr) {
   (void)hipGetLastError();
   const int N = r->N, S1 = r->logN - LT;
   const size_t toff = (size_t)limb0 * N, stride = (size_t)Lrows * N;
-  const LimbConsts* c = r->d_consts + limb0;
+  const LimbConsts* c = (in_b ? r->d_consts_r : r->d_consts) + limb0;
   const int nspans = (npoly + chunk - 1) / chunk;
   for (int j = 0; j <= nspans; ++j) {
     const int p1 = j * chunk, n1p = j < nspans ? ((npoly - p1 < chunk) ? npoly - p1 : chunk) : 0;
     const int p2 = (j - 1) * chunk, n2p = j >= 1 ? ((npoly - p2 < chunk) ? npoly - p2 : chunk) : 0;
     const unsigned n1 = ((unsigned)n1p * Lrows) << S1, n2 = (unsigned)n2p * Lrows * 16;
     const u64* i1 = in + (size_t)p1 * stride; u64* o1 = out + (size_t)p1 * stride; u64* d2 = out + (size_t)p2 * stride;
+    const u64* ib = in_b ? in_b + (size_t)p1 * stride : nullptr;
     switch (S1) {
-      case 1: launch_inv_fused<1>(r, i1, o1, n1, n1p, d2, n2, toff, limb0, c, Lrows); break;
-      case 2: launch_inv_fused<2>(r, i1, o1, n1, n1p, d2, n2, toff, limb0, c, Lrows); break;
-      case 3: launch_inv_fused<3>(r, i1, o1, n1, n1p, d2, n2, toff, limb0, c, Lrows); break;
-      case 4: launch_inv_fused<4>(r, i1, o1, n1, n1p, d2, n2, toff, limb0, c, Lrows); break;
-      case 5: launch_inv_fused<5>(r, i1, o1, n1, n1p, d2, n2, toff, limb0, c, Lrows); break;
+      case 1: launch_inv_fused<1>(r, i1, ib, o1, n1, n1p, d2, n2, toff, limb0, c, Lrows); break;
+      case 2: launch_inv_fused<2>(r, i1, ib, o1, n1, n1p, d2, n2, toff, limb0, c, Lrows); break;
+      case 3: launch_inv_fused<3>(r, i1, ib, o1, n1, n1p, d2, n2, toff, limb0, c, Lrows); break;
+      case 4: launch_inv_fused<4>(r, i1, ib, o1, n1, n1p, d2, n2, toff, limb0, c, Lrows); break;
+      case 5: launch_inv_fused<5>(r, i1, ib, o1, n1, n1p, d2, n2, toff, limb0, c, Lrows); break;
     }
   }
   return check_launch("ntt_inv_fused_asm");
@@ -558,7 +564,7 @@ static int ntt_batch(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, i
   (void)hipSetDevice(r->device);
   if (r->kind == RH_RING_3N) {
     std::lock_guard<std::recursive_mutex> lk(r->mu);          // the 3N workspace is shared and grows lazily
-    return rh_ring3n_ntt_launch(r, in, out, npoly, level + 1, 0, inverse);
+    return rh_ring3n_ntt_launch(r, in, out, npoly, level + 1, 0, inverse, r->block_order3n != 0);
   }
   if (r->kind == RH_RING_CI) return ci_ntt_launch(r, in, out, npoly, level + 1, 0, inverse);
   return rh_std_ntt_launch(r, in, out, npoly, level + 1, 0, inverse, lazy, phase);
@@ -586,6 +592,14 @@ static int std_intt_mul_launch(rh_ring* r, const u64* a, const u64* b, u64* out,
   }
   (void)hipGetLastError();
   const int S1 = logN - LT;
+  if (S1 > 0 && r->asm_tile) {
+    // large batches: the software pipeline of std_ntt_inv_pipelined (tile stages of span j with the column stages of span j-1).
+    // The output may alias an input: a span's tiles read (a, b) of that span only, before its column stages write them.
+    int chunk = r->chunk_polys;
+    if (chunk < 0) { const int c = r->auto_span_rows / Lrows > 0 ? r->auto_span_rows / Lrows : 1; chunk = npoly > c ? c : 0; }
+    if (chunk > 0 && npoly > chunk) return std_ntt_inv_pipelined(r, a, out, npoly, Lrows, 0, chunk, b);
+    ntt_inv_tile_mul_asm<<<rows << S1, 256, 0, st>>>(a, b, out, r->d_twk_inv, r->d_consts_r, Lrows, logN, npoly);
+  } else
   ntt_inv_tile_mul<<<rows << S1, 256, 0, st>>>(a, b, out, r->d_twk_inv, r->d_consts_r, Lrows, logN, S1 == 0 ? 1 : 0, npoly);
   if (S1 >= 2 && S1 <= 4 && r->asm_cols && r->asm_tile) {
     if (S1 == 4) ntt_inv_cols_asm<4><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows);
@@ -601,6 +615,15 @@ extern "C" int rh_ring_intt_mul(rh_ring* r, const uint64_t* a, const uint64_t* b
   if (npoly < 0) return rh_fail(RH_ERR_ARG, "intt_mul: npoly < 0");
   (void)hipSetDevice(r->device);
   return std_intt_mul_launch(r, a, b, out, npoly, level + 1);
+}
+
+extern "C" int rh_ring_ntt3n_reorder(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, int to_reference) {
+  if (!r || !in || !out) return rh_fail(RH_ERR_ARG, "ntt3n_reorder: null argument");
+  if (r->kind != RH_RING_3N) return rh_fail(RH_ERR_ARG, "ntt3n_reorder: not a 3N ring");
+  if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "ntt3n_reorder: level %d out of range [0,%d)", level, r->L);
+  if (npoly < 0) return rh_fail(RH_ERR_ARG, "ntt3n_reorder: npoly < 0");
+  (void)hipSetDevice(r->device);
+  return rh_ring3n_reorder_launch(r, in, out, npoly, level + 1, to_reference != 0);
 }
 
 // Pre-sizes every lazily grown scratch of the ring for batches of up to npoly polys (all limbs): afterwards no entry point of
@@ -621,6 +644,11 @@ extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
   if (!strcmp(key, "fuse_submul")) { r->fuse_submul = (int)value; return RH_OK; }
   if (!strcmp(key, "perm_inv_shape")) { r->perm_inv_shape = (int)value; return RH_OK; }
   if (!strcmp(key, "fuse3n")) { r->fuse3n = (int)value; return RH_OK; }
+  if (!strcmp(key, "ntt3n_block_order")) {
+    if (r->kind != RH_RING_3N) return rh_fail(RH_ERR_ARG, "ntt3n_block_order: not a 3N ring");
+    r->block_order3n = value != 0;
+    return RH_OK;
+  }
   if (!strcmp(key, "asm_cols")) { r->asm_cols = (int)value; return RH_OK; }
   return rh_fail(RH_ERR_ARG, "set_tuning: unknown key %s", key);
 }

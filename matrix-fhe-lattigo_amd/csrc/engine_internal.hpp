@@ -45,6 +45,7 @@ struct rh_ring {
   int fuse_submul = 1;            // ModDown / rescale: subtract-multiply fused into the forward tile kernel's epilogue
   int perm_inv_shape = 64;        // 3N inverse permutation tile: words per block-order run (32 / 64 / 128)
   int fuse3n = 1;                 // 3N rings, b = 1: split + radix-3 layer fused with the sub-transforms' column stages
+  int block_order3n = 0;          // 3N rings: device-batched NTT domain kept in block order (ntt3n.hip), no permutation pass
   int asm_cols = 1;               // N = 2^16: hand-scheduled column stages (fwd_cols16_asm_body) in place of the C++ body
   bool asm_tile = true;           // forward tile kernel: hand-scheduled body (ntt_kernels_asm.cuh) vs the C++ one
   bool inv_scale = true;          // false: inverse leaves values < 4q without the N^-1 factor (3N sub-transform)
@@ -86,7 +87,8 @@ int rh_ring3n_reserve(rh_ring* r, int npoly);
 // 3N-cyclotomic transform (ntt3n.hip)
 int rh_ring3n_setup(rh_ring* r, std::vector<LimbConsts>& hc);
 void rh_ring3n_teardown(rh_ring* r);
-int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse);
+int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool block_order = false);
+int rh_ring3n_reorder_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, bool to_reference);
 
 // basis extender internals shared with keyswitch.hip
 struct rh_bext;

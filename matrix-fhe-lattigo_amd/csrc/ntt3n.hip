@@ -503,7 +503,84 @@ static int ensure_tmp(rh_ring3n_state* s, size_t words) {
   return 0;
 }
 
-int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse) {
+// BLOCK ORDER (tuning key ntt3n_block_order, device-batched calls only): the NTT domain is kept in the layout the radix-2
+// sub-transforms produce -- slot j of block c at word c*n2 + j -- instead of the Go transformer's ascending-totative order
+// (ring/ntt_3n.go:82-109).  Every NTT-domain operation of the ring is coefficient-wise, so the layout is invisible to Add / Mul...
+// and to NTT -> pointwise -> INTT chains (matrix_ckks.Evaluator.Mul, config 4), and it removes the permutation pass: a 2-pass
+// (N = 3*2^k) transform needs a transposition SOMEWHERE (natural-order output of a column-first decomposition is a comb of
+// stride 2^S1 * nb words per tile), and the only place where it costs nothing is the host boundary.  rh_ring_ntt3n_reorder converts.
+// Supported for b = 1 rings with n2 >= 4096 (N >= 24576); the host-limb interface always speaks the reference order.
+static int ntt3n_block_order_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse) {
+  rh_ring3n_state* s = r->s3n;
+  const int N = r->N, nb = s->nb;
+  const unsigned rows = (unsigned)npoly * (unsigned)Lrows;
+  if (rows == 0) return RH_OK;
+  if (s->b != 1 || !s->sub || s->log_n2 < LT) return rh_fail(RH_ERR_UNSUPPORTED, "3N block order needs N = 3 * 2^k with k >= 13");
+  (void)hipGetLastError();
+  hipStream_t st = rh_stream(r);
+  RhCallScope scope(st);
+  const LimbConsts* c = r->d_consts + limb0;
+  const Limb3N* l3 = s->d_l3 + limb0;
+  const tw2* r3f = s->d_r3_fwd + (size_t)limb0 * s->r3_stride;
+  const tw2* r3i = s->d_r3_inv + (size_t)limb0 * s->r3_stride;
+  auto chunks = [](int work) { int g = (work + 255) / 256; return g < 1 ? 1 : (g > 64 ? 64 : g); };
+  const int S1sub = s->log_n2 - 12;
+  const bool fuse = r->fuse3n && S1sub >= 1 && S1sub <= 3;
+  const dim3 g(rows * 16);
+  // every layer kernel reads and writes the same index set per thread ({i + k N/6}, resp. {c n2 + col + 4096 k}): in place is safe
+  if (!inverse) {
+    if (fuse) {
+      const tw2* stw = s->sub->d_tw_fwd + ((size_t)limb0 * nb << s->log_n2);
+      if (S1sub == 1) ntt3n_pre_cols_fwd<1><<<g, 256, 0, st>>>(in, out, N, r3f + s->r3_off[1], s->r3_stride, l3, c, Lrows, stw, s->log_n2);
+      else if (S1sub == 2) ntt3n_pre_cols_fwd<2><<<g, 256, 0, st>>>(in, out, N, r3f + s->r3_off[1], s->r3_stride, l3, c, Lrows, stw, s->log_n2);
+      else ntt3n_pre_cols_fwd<3><<<g, 256, 0, st>>>(in, out, N, r3f + s->r3_off[1], s->r3_stride, l3, c, Lrows, stw, s->log_n2);
+      if (int rc = rh_std_ntt_launch(s->sub, out, out, npoly, Lrows * nb, limb0 * nb, false, false, 2)) return rc;      // tile stages
+    } else {
+      ntt3n_pre_b1_fwd<<<dim3(rows, chunks(N / 6)), 256, 0, st>>>(in, out, N, r3f + s->r3_off[1], s->r3_stride, l3, c, Lrows);
+      if (int rc = rh_std_ntt_launch(s->sub, out, out, npoly, Lrows * nb, limb0 * nb, false, false, 0)) return rc;
+    }
+  } else {
+    if (int rc = rh_std_ntt_launch(s->sub, in, out, npoly, Lrows * nb, limb0 * nb, true, false, fuse ? 2 : 0)) return rc;
+    if (fuse) {
+      const tw2* stw = s->sub->d_tw_inv + ((size_t)limb0 * nb << s->log_n2);
+      if (S1sub == 1) ntt3n_cols_post_inv<1><<<g, 256, 0, st>>>(out, out, N, r3i + s->r3_off[1], s->r3_stride, l3, c, Lrows, stw, s->log_n2);
+      else if (S1sub == 2) ntt3n_cols_post_inv<2><<<g, 256, 0, st>>>(out, out, N, r3i + s->r3_off[1], s->r3_stride, l3, c, Lrows, stw, s->log_n2);
+      else ntt3n_cols_post_inv<3><<<g, 256, 0, st>>>(out, out, N, r3i + s->r3_off[1], s->r3_stride, l3, c, Lrows, stw, s->log_n2);
+    } else {
+      ntt3n_post_b1_inv<<<dim3(rows, chunks(N / 6)), 256, 0, st>>>(out, out, N, r3i + s->r3_off[1], s->r3_stride, l3, c, Lrows);
+    }
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "3N transform (block order) launch failed: %s", hipGetErrorString(e));
+  return RH_OK;
+}
+
+// reference order <-> block order of NTT-domain data (never in place): the permutation pass on its own
+int rh_ring3n_reorder_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, bool to_reference) {
+  rh_ring3n_state* s = r->s3n;
+  const int N = r->N, nb = s->nb;
+  const unsigned rows = (unsigned)npoly * (unsigned)Lrows;
+  if (rows == 0) return RH_OK;
+  if (in == out) return rh_fail(RH_ERR_ARG, "3N reorder cannot run in place");
+  (void)hipGetLastError();
+  hipStream_t st = rh_stream(r);
+  auto chunks = [](int work) { int g = (work + 255) / 256; return g < 1 ? 1 : (g > 64 ? 64 : g); };
+  const bool tiled = s->log_n2 >= 2 * PT && nb <= 6;
+  const dim3 pgrid(rows, 1u << (s->log_n2 >= 2 * PT ? s->log_n2 - 2 * PT : 0));
+  if (to_reference) {
+    if (tiled) ntt3n_perm_tiled<true, 5, 5><<<pgrid, 256, (size_t)32 * (32 * nb + 1) * 8, st>>>(in, out, N, nb, s->log_n2, s->d_rank);
+    else ntt3n_perm_fwd<<<dim3(rows, chunks(N)), 256, 0, st>>>(in, out, N, nb, s->log_n2, s->d_block_of_rank, r->d_consts, Lrows, 0);
+  } else {
+    if (tiled) ntt3n_perm_tiled<false, 6, 4><<<pgrid, 256, (size_t)64 * (16 * nb + 1) * 8, st>>>(in, out, N, nb, s->log_n2, s->d_rank);
+    else ntt3n_perm_inv<<<dim3(rows, chunks(N)), 256, 0, st>>>(in, out, N, nb, s->log_n2, s->d_block_of_rank);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "3N reorder launch failed: %s", hipGetErrorString(e));
+  return RH_OK;
+}
+
+int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool block_order) {
+  if (block_order) return ntt3n_block_order_launch(r, in, out, npoly, Lrows, limb0, inverse);
   rh_ring3n_state* s = r->s3n;
   const int N = r->N, nb = s->nb;
   const unsigned rows = (unsigned)npoly * (unsigned)Lrows;

@@ -92,7 +92,9 @@ ntt_fwd_fused_asm(const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n
 
 // ---- inverse: first 12 stages (t = 1..2048) on a 4096-tile, values leave < 4q (N^-1 is applied by ntt_inv_cols).
 // Same contract as ntt_inv_tile(last = 0).  twk = kernel-order table built from RootsBackward.
-RH_DEV void inv_tile_asm_body(u64* lds, const u32 b, const u64* in, u64* out, const tw2* __restrict__ twk,
+// MUL: the tile's input is MRedLazy(in, in2) formed on load (rh_ring_intt_mul; same contract as inv_tile_body<true>)
+template <bool MUL = false>
+RH_DEV void inv_tile_asm_body(u64* lds, const u32 b, const u64* in, const u64* in2, u64* out, const tw2* __restrict__ twk,
                               const LimbConsts* __restrict__ consts, int L, int logN, int npoly) {
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
@@ -106,12 +108,24 @@ RH_DEV void inv_tile_asm_body(u64* lds, const u32 b, const u64* in, u64* out, co
   const u64 nq = (u64)0 - q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
   const u32 lds_off = uni32((u32)(size_t)lds);
   const u32 tid = threadIdx.x;
-  asm volatile(NTT_TILE_INV_ASM_BODY
-               :
-               : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw),
-                 [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)),
-                 [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4)
-               : NTT_TILE_ASM_CLOBBERS);
+  if constexpr (MUL) {
+    const u64 pin2 = uni64((u64)(size_t)(in2 + base));
+    const u64 qinv = uni64(consts[limb].qinv);
+    asm volatile(NTT_TILE_INV_MUL_ASM_BODY
+                 :
+                 : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pin2] "s"(pin2), [pout] "s"(pout), [tw] "s"(tw),
+                   [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)),
+                   [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4),
+                   [q] "s"(q), [q0] "s"((u32)q), [q1] "s"((u32)(q >> 32)), [qi0] "s"((u32)qinv), [qi1] "s"((u32)(qinv >> 32))
+                 : NTT_TILE_ASM_CLOBBERS);
+  } else {
+    asm volatile(NTT_TILE_INV_ASM_BODY
+                 :
+                 : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw),
+                   [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)),
+                   [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4)
+                 : NTT_TILE_ASM_CLOBBERS);
+  }
 }
 // inverse column stages with N^-1 folded in, S1 = 2..4: same contract as inv_cols_body<S1>(scale = 1)
 #define RH_COLS_INV_ASM(BODY)                                                                                                     \
@@ -148,12 +162,18 @@ __global__ void __launch_bounds__(256)
 ntt_inv_tile_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts,
                  int L, int logN, int npoly) {
   __shared__ u64 lds[LDS_WORDS];
-  inv_tile_asm_body(lds, blockIdx.x, in, out, twk, consts, L, logN, npoly);
+  inv_tile_asm_body<false>(lds, blockIdx.x, in, nullptr, out, twk, consts, L, logN, npoly);
+}
+__global__ void __launch_bounds__(256)
+ntt_inv_tile_mul_asm(const u64* in, const u64* in2, u64* out, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts,
+                     int L, int logN, int npoly) {
+  __shared__ u64 lds[LDS_WORDS];
+  inv_tile_asm_body<true>(lds, blockIdx.x, in, in2, out, twk, consts, L, logN, npoly);
 }
 // software-pipelined inverse: tile stages of span j (in -> out), then column stages + N^-1 of span j-1 (in place)
-template <int S1, bool ASMCOLS = false>
+template <int S1, bool ASMCOLS = false, bool MUL = false>
 __global__ void __launch_bounds__(256)
-ntt_inv_fused_asm(const u64* in1, u64* out1, unsigned n1, int npoly1, u64* data2, unsigned n2,
+ntt_inv_fused_asm(const u64* in1, const u64* in1b, u64* out1, unsigned n1, int npoly1, u64* data2, unsigned n2,
                   const tw2* __restrict__ twk, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
                   const LimbConsts* __restrict__ consts, int L, int logN) {
   __shared__ u64 lds[LDS_WORDS];
@@ -161,6 +181,6 @@ ntt_inv_fused_asm(const u64* in1, u64* out1, unsigned n1, int npoly1, u64* data2
     if constexpr (has_asm_cols(S1) && ASMCOLS) inv_cols_asm_body<S1>(blockIdx.x, data2, twn, lastw, consts, L);
     else inv_cols_body<S1>(blockIdx.x, data2, twn, lastw, consts, L, logN, 1);
   }
-  if (blockIdx.x < n1) inv_tile_asm_body(lds, blockIdx.x, in1, out1, twk, consts, L, logN, npoly1);
+  if (blockIdx.x < n1) inv_tile_asm_body<MUL>(lds, blockIdx.x, in1, in1b, out1, twk, consts, L, logN, npoly1);
 }
 

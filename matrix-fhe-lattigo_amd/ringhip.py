@@ -88,6 +88,7 @@ def lib():
         "rh_ring_ntt": (i, [vp, vp, vp, i, i, i]), "rh_ring_intt": (i, [vp, vp, vp, i, i, i]),
         "rh_ring_ntt_phase": (i, [vp, vp, vp, i, i, i, i]),
         "rh_ring_intt_mul": (i, [vp, vp, vp, vp, i, i]),
+        "rh_ring_ntt3n_reorder": (i, [vp, vp, vp, i, i, i]),
         "rh_ring_set_tuning": (i, [vp, C.c_char_p, C.c_long]),
         "rh_ring_vec_op": (i, [vp, i, vp, vp, vp, i, i, U64P, U64P]),
         "rh_ring_div_by_last_modulus_many": (i, [vp, i, i, i, vp, vp, i, i]),
@@ -313,6 +314,10 @@ class Ring:
 
     def INTTLazy(self, p1, p2):
         self._chk(p1, p2); _check(lib().rh_ring_intt(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 1))
+
+    def NTT3NReorder(self, p1, p2, to_reference=True):
+        """3N rings: NTT-domain block between block order (tuning ntt3n_block_order) and the Go transformer's order; out of place"""
+        self._chk(p1, p2); _check(lib().rh_ring_ntt3n_reorder(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 1 if to_reference else 0))
 
     def INTTMul(self, p1, p2, p3):
         """p3 = INTT(p1 . p2) for NTT-domain p1, p2: the values of MForm(p1, t); MulCoeffsMontgomery(t, p2, p3); INTT(p3, p3)

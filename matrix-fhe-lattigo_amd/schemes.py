@@ -26,9 +26,15 @@ class Ciphertext:
 class MatrixCKKSEvaluator:
     """schemes/matrix_ckks/evaluator.go: Evaluator over the 3N ring Z_Q[X]/(X^N - X^{N/2} + 1)."""
 
-    def __init__(self, ringQ):
+    def __init__(self, ringQ, block_order=False):
+        """block_order: keep the ring's device NTT domain in block order (rh_ring_set_tuning ntt3n_block_order): Mul is NTT ->
+        coefficient-wise products -> INTT, so its coefficient-domain output is bit-identical and every transform saves the
+        permutation pass.  It is a property of the RING handle: NTT-domain polys of this ring are then in block order for every
+        user of the handle (Ring.NTT3NReorder converts at the host boundary)."""
         self.ringQ = ringQ
         self.fused_tensor = True
+        if block_order:
+            ringQ.set_tuning("ntt3n_block_order", 1)
 
     def Mul(self, ct0, ct1, ctOut):
         """evaluator.go:114-192.  Reproduced as written, including its two side effects: inputs not yet in the NTT

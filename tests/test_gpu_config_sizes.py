@@ -190,4 +190,10 @@ def test_config4_ring_all_24_limbs(rh, oracle):
         c1 = oracle.vec_op(MULADD, A1, B0, oracle.vec_op(MUL, A0, B1, z, 0, 0, q), 0, 0, q)
         for c, e in ((0, c0), (1, c1), (2, c2)):
             assert np.array_equal(got[c][1, i], oracle.ntt3n_backward(e, q, w)), "Mul component %d limb %d" % (c, i)
+    # the same Mul with the ring's device NTT domain in block order (no permutation pass): identical coefficient-domain output
+    ev2 = rh.MatrixCKKSEvaluator(ring, block_order=True)
+    out2 = rh.Ciphertext([ring.NewPoly(B) for _ in range(3)])
+    ev2.Mul(rh.Ciphertext([dp(x0), dp(x1)]), rh.Ciphertext([dp(y0), dp(y1)]), out2)
+    for c in range(3):
+        assert np.array_equal(out2.Value[c].numpy(), got[c]), "block-order Mul component %d" % c
     ring.close()

@@ -144,3 +144,55 @@ def test_fused_pre_and_column_stages_identical(rh, oracle, logn2):
     ring.NTT(p, p); ring.INTT(p, p)                     # in place
     assert np.array_equal(p.numpy(), a)
     ring.close()
+
+
+@pytest.mark.parametrize("logn2,L,B", [(12, 2, 3), (13, 2, 2), (15, 3, 2)])
+def test_block_order_is_a_relayout_of_the_reference_order(rh, oracle, logn2, L, B):
+    # tuning ntt3n_block_order: the device NTT domain in the sub-transforms' (block, slot) layout, no permutation pass.
+    # (1) reorder(NTT_block(x)) == NTT_reference(x) == oracle; (2) INTT_block inverts NTT_block, in and out of place;
+    # (3) reorder is an involution pair; (4) the per-limb host interface keeps the reference order; (5) pointwise product chain
+    #     NTT -> MulCoeffsMontgomery -> INTT gives the same coefficient-domain bits in either layout
+    N = 6 << logn2
+    mods = []
+    q = find_prime_3n(N, 60)
+    while len(mods) < L:
+        if oracle.lib().orc_is_prime(q):
+            mods.append(q)
+        q += 3 * N
+    om = [omega_for(m, N) for m in mods]
+    ring = rh.Ring(N, mods, kind=rh.Matrix3N, omega3n=om)
+    rng = np.random.default_rng(logn2 * 5 + L)
+    mk = lambda: np.stack([np.stack([rng.integers(0, 1 << 62, size=N, dtype=np.uint64) % np.uint64(m) for m in mods]) for _ in range(B)])
+    a, b = mk(), mk()
+    pa, pb = rh.DevicePoly.from_numpy(ring, a), rh.DevicePoly.from_numpy(ring, b)
+    ref, blk, conv, back = (ring.NewPoly(B) for _ in range(4))
+    ring.NTT(pa, ref)
+    refn = ref.numpy()
+    assert np.array_equal(refn[B - 1, L - 1], oracle.ntt3n_forward(a[B - 1, L - 1], mods[L - 1], om[L - 1]))
+    prod_ref = ring.NewPoly(B)
+    nb_ref = ring.NewPoly(B)
+    ring.NTT(pb, nb_ref); ring.MulCoeffsMontgomery(ref, nb_ref, prod_ref); ring.INTT(prod_ref, prod_ref)
+    ring.set_tuning("ntt3n_block_order", 1)
+    ring.NTT(pa, blk)
+    assert not np.array_equal(blk.numpy(), refn)
+    ring.NTT3NReorder(blk, conv, to_reference=True)
+    assert np.array_equal(conv.numpy(), refn)
+    ring.NTT3NReorder(conv, back, to_reference=False)
+    assert np.array_equal(back.numpy(), blk.numpy())
+    ring.INTT(blk, back)
+    assert np.array_equal(back.numpy(), a)
+    ring.NTT(pa, pa); ring.INTT(pa, pa)                                  # in place, both directions
+    assert np.array_equal(pa.numpy(), a)
+    assert np.array_equal(ring.SubRings[0].NTT(a[0, 0]), refn[0, 0])     # host-limb interface: reference order regardless
+    nb_blk, prod_blk = ring.NewPoly(B), ring.NewPoly(B)
+    ring.NTT(pb, nb_blk); ring.MulCoeffsMontgomery(blk, nb_blk, prod_blk); ring.INTT(prod_blk, prod_blk)
+    assert np.array_equal(prod_blk.numpy(), prod_ref.numpy())
+    ring.set_tuning("ntt3n_block_order", 0)
+    ring.NTT(pa, conv)
+    assert np.array_equal(conv.numpy(), refn)
+    ring.close()
+    small = rh.Ring(96, [find_prime_3n(96, 60)], kind=rh.Matrix3N)
+    small.set_tuning("ntt3n_block_order", 1)
+    with pytest.raises(rh.RingHipError):                                 # block order needs N = 3 * 2^k >= 24576
+        small.NTT(small.NewPoly(1), small.NewPoly(1))
+    small.close()

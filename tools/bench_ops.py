@@ -147,6 +147,10 @@ for N, L, B in ((3 << 13, 1, 1024), (3 << 16, 24, 16)):
     px = rh.DevicePoly.from_torch(ring, x)
     res.append(entry("3N NTT N=%d L=%d" % (N, L), timed(lambda: ring.NTT(px, px), reps=5), 16.0 * N * L * B, B, "poly"))
     res.append(entry("3N INTT N=%d L=%d" % (N, L), timed(lambda: ring.INTT(px, px), reps=5), 16.0 * N * L * B, B, "poly"))
+    ring.set_tuning("ntt3n_block_order", 1)
+    res.append(entry("3N NTT N=%d L=%d, device NTT domain in block order (no permutation pass)" % (N, L), timed(lambda: ring.NTT(px, px), reps=5), 16.0 * N * L * B, B, "poly"))
+    res.append(entry("3N INTT N=%d L=%d, block order" % (N, L), timed(lambda: ring.INTT(px, px), reps=5), 16.0 * N * L * B, B, "poly"))
+    ring.set_tuning("ntt3n_block_order", 0)
     if L == 24:
         # config 4: matrix_ckks.Evaluator.Mul on degree-1 ciphertexts given in the coefficient domain
         # (schemes/matrix_ckks/evaluator.go:114-192): 4 NTT + 3 MulCoeffsMontgomery + 1 ...ThenAdd + 3 INTT
@@ -160,6 +164,10 @@ for N, L, B in ((3 << 13, 1, 1024), (3 << 16, 24, 16)):
             ev.Mul(ct0, ct1, out)
         res.append(entry("config4 matrix_ckks Mul N=%d L=%d (4 NTT, 3 MulCoeffsMontgomery, 1 ThenAdd, 3 INTT)" % (N, L),
                          timed(mul, reps=5), (7 * 16.0 + 3 * 24.0 + 32.0) * N * L * B, B, "ctmul"))
+        ring.set_tuning("ntt3n_block_order", 1)
+        res.append(entry("config4 matrix_ckks Mul N=%d L=%d, block-order NTT domain (same coefficient-domain output)" % (N, L),
+                         timed(mul, reps=5), (7 * 16.0 + 3 * 24.0 + 32.0) * N * L * B, B, "ctmul"))
+        ring.set_tuning("ntt3n_block_order", 0)
         del blocks, ct0, ct1, out
     del px, x
     ring.close(); torch.cuda.empty_cache()

@@ -134,6 +134,44 @@ def inv_butterfly_steps(u, v, w, t, sgpr_tw=None):
     ]
 
 
+def mred_lazy_steps(x, y, t):
+    """x <- MRedLazy(x, y) = x*y*2^-64 mod q, in [0, 2q) for x, y < 2q (ring/modular_reduction.go:90-95: ahi - hi64((alo*qinv)*q) + q);
+    x, y: data pairs; operands qi0/qi1 (MRedConstant), q0/q1 and the pair q.  16 slow + 10 fast."""
+    xl, xh, yl, yh = "v%d" % x, "v%d" % (x + 1), "v%d" % y, "v%d" % (y + 1)
+    R, S, Q, T, H, G = pair(t.R), pair(t.S), pair(t.Q), pair(t.T), pair(t.H), pair(t.G)
+    rl, rh_, sl, sh, ql, qh = "v%d" % t.R, "v%d" % (t.R + 1), "v%d" % t.S, "v%d" % (t.S + 1), "v%d" % t.Q, "v%d" % (t.Q + 1)
+    tl, th, hl, gl, m = "v%d" % t.T, "v%d" % (t.T + 1), "v%d" % t.H, "v%d" % t.G, "v%d" % t.M
+    return [
+        "v_mad_u64_u32 %s, %s, %s, %s, 0" % (R, DUMMY, xl, yl),            # x0*y0: p0 = R.lo
+        "v_mov_b32 %s, %s" % (hl, rh_),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (S, DUMMY, xl, yh, H),        # x0*y1 + carry
+        "v_mov_b32 %s, %s" % (gl, sl),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (Q, DUMMY, xh, yl, G),        # x1*y0 + ...: p1 = Q.lo
+        "v_mov_b32 %s, %s" % (hl, sh),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (T, DUMMY, xh, yh, H),        # x1*y1 + carry
+        "v_mov_b32 %s, %s" % (gl, qh),
+        "v_lshl_add_u64 %s, %s, 0, %s" % (T, T, G),                        # ahi = T
+        "v_mad_u64_u32 %s, %s, %s, %%[qi0], 0" % (S, DUMMY, rl),           # m = alo * qinv mod 2^64 -> S
+        "v_mul_lo_u32 %s, %s, %%[qi1]" % (m, rl),
+        "v_add_u32 %s, %s, %s" % (sh, sh, m),
+        "v_mul_lo_u32 %s, %s, %%[qi0]" % (m, ql),
+        "v_add_u32 %s, %s, %s" % (sh, sh, m),
+        "v_mad_u64_u32 %s, %s, %s, %%[q0], 0" % (R, DUMMY, sl),            # hi64(m * q) -> Q
+        "v_mov_b32 %s, %s" % (hl, rh_),
+        "v_mad_u64_u32 %s, %s, %s, %%[q1], %s" % (Q, DUMMY, sl, H),
+        "v_mov_b32 %s, %s" % (gl, ql),
+        "v_mad_u64_u32 %s, %s, %s, %%[q0], %s" % (R, DUMMY, sh, G),
+        "v_mov_b32 %s, %s" % (hl, qh),
+        "v_mad_u64_u32 %s, %s, %s, %%[q1], %s" % (Q, DUMMY, sh, H),
+        "v_mov_b32 %s, %s" % (gl, rh_),
+        "v_lshl_add_u64 %s, %s, 0, %s" % (Q, Q, G),
+        "v_sub_co_u32 %s, %s, %s, %s" % (xl, t.cc, tl, ql),
+        "@CARRY",
+        "v_subb_co_u32 %s, %s, %s, %s, %s" % (xh, t.cc, th, qh, t.cc),
+        "v_lshl_add_u64 %s, %s, 0, %%[q]" % (pair(x), pair(x)),
+    ]
+
+
 def interleave(a, b):
     """instruction-wise interleave of two independent butterflies; resolves @CARRY markers (the partner's
     instructions provide the wait states between v_sub_co and v_subb_co; pad with s_nop when they do not)"""
@@ -193,9 +231,11 @@ INV_SLOT_ORDER = list(range(7, 15)) + list(range(3, 7)) + [1, 2] + [0]      # co
 INV_NEED = {3: 8, 2: 12, 1: 14, 0: 15}                                      # twiddle quads needed before stage u
 
 
-def gen_inverse():
+def gen_inverse(mul=False):
     """first 12 stages (t = 1..2048) of the inverse transform on a 4096-tile; values leave < 4q (no scaling):
-    mirror image of gen(); same LDS layout and kernel-order twiddle table (built from RootsBackward)."""
+    mirror image of gen(); same LDS layout and kernel-order twiddle table (built from RootsBackward).
+    mul: the input is the pointwise Montgomery product of two blocks (pin, pin2), formed on load (rh_ring_intt_mul); the second
+    operand lands in the twiddle registers v32..v63, so the round-C' twiddle loads are issued after the products."""
     A0, A1, A2, A3 = ADDR, ADDR + 1, ADDR + 2, ADDR + 3
     for t in (T0, T1):
         emit("v_mov_b32 v%d, 0" % (t.H + 1))
@@ -208,6 +248,14 @@ def gen_inverse():
     for k in range(16):
         j, rem = divmod(k, 4)
         emit("global_load_dwordx2 %s, v%d, %%[pin] offset:%d" % (pair(X(k)), SCR + j, rem * 2048 - 4096))
+    if mul:
+        for k in range(16):
+            j, rem = divmod(k, 4)
+            emit("global_load_dwordx2 %s, v%d, %%[pin2] offset:%d" % (pair(TW0 + 2 * k), SCR + j, rem * 2048 - 4096))
+        for k in range(0, 16, 2):                              # x[k] is load k, y[k] load 16 + k of the 32 issued
+            emit("s_waitcnt vmcnt(%d)" % (14 - k))
+            for ins in interleave(mred_lazy_steps(X(k), TW0 + 2 * k, T0), mred_lazy_steps(X(k + 1), TW0 + 2 * (k + 1), T1)):
+                emit(ins)
     # round C' twiddles: tw[256 + slot*256 + tid]
     emit("v_lshlrev_b32 v%d, 4, %%[tid]" % A2)
     for slot in INV_SLOT_ORDER:
@@ -550,10 +598,13 @@ for s1 in (2, 3, 4):
     del out[:]
 gen_inverse()
 inv = list(out)
+del out[:]
+gen_inverse(mul=True)
+inv_mul = list(out)
 clob_v = ", ".join('"v%d"' % i for i in range(NVGPR_USED))
 clob_s = ", ".join('"s%d"' % i for i in range(36, 100))
 text = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  forward: %d instructions, inverse: %d.\n" % (len(fwd), len(inv))
-text += render("NTT_TILE_ASM_BODY", fwd) + "".join(render("NTT_COLS%d_ASM_BODY" % (1 << k), cols[k]) + render("NTT_COLS%d_INV_ASM_BODY" % (1 << k), cols_inv[k]) for k in (2, 3, 4)) + render("NTT_TILE_INV_ASM_BODY", inv)
+text += render("NTT_TILE_ASM_BODY", fwd) + "".join(render("NTT_COLS%d_ASM_BODY" % (1 << k), cols[k]) + render("NTT_COLS%d_INV_ASM_BODY" % (1 << k), cols_inv[k]) for k in (2, 3, 4)) + render("NTT_TILE_INV_ASM_BODY", inv) + render("NTT_TILE_INV_MUL_ASM_BODY", inv_mul)
 text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v, clob_s)
 path = sys.argv[1] if len(sys.argv) > 1 else "ntt_tile_asm.inc"
 open(path, "w").write(text)
