@@ -509,8 +509,20 @@ int rh_std_ntt_submul_launch(rh_ring* r, u64* buf, int npoly, int Lrows, int lim
   const int S1 = r->logN - LT;
   if (S1 > 0 && !cols_done) if (int rc = rh_std_ntt_launch(r, buf, buf, npoly, Lrows, limb0, false, false, 1)) return rc;   // column stages only
   (void)hipGetLastError();
-  LimbScalars sc; memset(&sc, 0, sizeof(sc)); memcpy(sc.s, scalars_host, (size_t)Lrows * 8);
   const size_t toff = (size_t)limb0 * r->N;
+  if (r->asm_tile) {                                   // MRed by the limb's scalar = Shoup multiply by s * 2^-64 mod q
+    LimbShoup sh; memset(&sh, 0, sizeof(sh));
+    for (int i = 0; i < Lrows; ++i) {
+      const u64 q = r->moduli[limb0 + i];
+      sh.w[i] = rh::imform(scalars_host[i] % q, q); sh.wp[i] = rh::shoup_quotient(sh.w[i], q);
+    }
+    if (z) ntt_fwd_tile_submul_asm<true><<<rows << S1, 256, 0, rh_stream(r)>>>(buf, r->d_twk_fwd + toff, r->d_consts + limb0, Lrows, r->logN, npoly, y, y_rows,
+                                                                                   out, out_rows, sh, z, z_rows);
+    else ntt_fwd_tile_submul_asm<false><<<rows << S1, 256, 0, rh_stream(r)>>>(buf, r->d_twk_fwd + toff, r->d_consts + limb0, Lrows, r->logN, npoly, y, y_rows,
+                                                                                 out, out_rows, sh, nullptr, 0);
+    return check_launch("ntt_fwd_tile_submul_asm");
+  }
+  LimbScalars sc; memset(&sc, 0, sizeof(sc)); memcpy(sc.s, scalars_host, (size_t)Lrows * 8);
   ntt_fwd_tile_submul<<<rows << S1, 256, 0, rh_stream(r)>>>(buf, r->d_twk_fwd + toff, r->d_consts + limb0, Lrows, r->logN, npoly, y, y_rows,
                                                          out, out_rows, sc, z, z_rows);
   return check_launch("ntt_fwd_tile_submul");

@@ -80,6 +80,49 @@ ntt_fwd_tile_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const Lim
   fwd_tile_asm_body(lds, blockIdx.x, in, out, twk, consts, L, logN, npoly, Ls);
 }
 
+// Forward tile stages with the subtract-multiply epilogue, hand-scheduled: same contract as ntt_fwd_tile_submul (ntt_kernels.cuh),
+//   out = [z +] MRed(2q - y + NTT(in), s_limb),
+// with MRed by the wave-uniform scalar done as a Shoup multiply by s*2^-64 mod q (sw / sp: that constant and its quotient, per limb).
+struct LimbShoup { u64 w[RH_MAX_LIMBS_K], wp[RH_MAX_LIMBS_K]; };
+template <bool ADD>
+__global__ void __launch_bounds__(256)
+ntt_fwd_tile_submul_asm(const u64* in, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts, int L, int logN, int npoly,
+                        const u64* y, int y_rows, u64* out, int out_rows, LimbShoup sc, const u64* z, int z_rows) {
+  __shared__ u64 lds[LDS_WORDS];
+  const u32 b = blockIdx.x;
+  const u32 limb = b % (u32)L;
+  const u32 r = b / (u32)L;
+  const u32 poly = r % (u32)npoly;
+  const u32 tile = r / (u32)npoly;
+  const size_t toff = (size_t)tile << LT;
+  const u64 pin = uni64((u64)(size_t)(in + (((size_t)poly * L + limb) << logN) + toff));
+  const u64 py = uni64((u64)(size_t)(y + (((size_t)poly * y_rows + limb) << logN) + toff));
+  const u64 pout = uni64((u64)(size_t)(out + (((size_t)poly * out_rows + limb) << logN) + toff));
+  const u64 pz = ADD ? uni64((u64)(size_t)(z + (((size_t)poly * z_rows + limb) << logN) + toff)) : 0;
+  const u64 tw = uni64((u64)(size_t)(twk + ((size_t)limb << logN) + toff));
+  const u64 q = uni64(consts[limb].q);
+  const u64 sw = uni64(sc.w[limb]), sp = uni64(sc.wp[limb]);
+  const u64 nq = (u64)0 - q, nq2 = (u64)0 - 2 * q, nq4 = (u64)0 - 4 * q, q4 = 4 * q, q2 = 2 * q;
+  const u32 lds_off = uni32((u32)(size_t)lds);
+  const u32 tid = threadIdx.x;
+  if constexpr (ADD)
+    asm volatile(NTT_TILE_SUBMUL_ADD_ASM_BODY
+                 :
+                 : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pout] "s"(pout), [py] "s"(py), [pz] "s"(pz), [tw] "s"(tw),
+                   [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)),
+                   [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4), [q2] "s"(q2),
+                   [sw0] "s"((u32)sw), [sw1] "s"((u32)(sw >> 32)), [sp0] "s"((u32)sp), [sp1] "s"((u32)(sp >> 32))
+                 : NTT_TILE_ASM_CLOBBERS);
+  else
+    asm volatile(NTT_TILE_SUBMUL_ASM_BODY
+                 :
+                 : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pout] "s"(pout), [py] "s"(py), [tw] "s"(tw),
+                   [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)),
+                   [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4), [q2] "s"(q2),
+                   [sw0] "s"((u32)sw), [sw1] "s"((u32)(sw >> 32)), [sp0] "s"((u32)sp), [sp1] "s"((u32)(sp >> 32))
+                 : NTT_TILE_ASM_CLOBBERS);
+}
+
 // software-pipelined launch (see ntt_fwd_fused): column stages of span j, then the asm tile body of span j-1
 template <int S1, bool ASMCOLS = false>
 __global__ void __launch_bounds__(256)

@@ -193,6 +193,16 @@ def test_intt_mul_equals_the_three_ring_calls(rh, oracle, logN, L, B):
     lazy = a.copy(); lazy[:, :, ::3] += np.array(mods, dtype=np.uint64)[None, :, None]   # representatives in [q, 2q)
     ring.INTTMul(rh.DevicePoly.from_numpy(ring, lazy), pb, got)
     assert np.array_equal(got.numpy(), ref.numpy())
+    if logN > 12:                                                                      # the pipelined launches (spans of 2 polys), and the C++ bodies
+        for key, val in (("chunk_polys", 2), ("asm_tile", 0)):
+            ring.set_tuning(key, val)
+            ring.INTTMul(rh.DevicePoly.from_numpy(ring, a), pb, got)
+            assert np.array_equal(got.numpy(), ref.numpy()), key
+        ring.set_tuning("asm_tile", 1)
+        ring.INTTMul(pa, pb, pa)                                                       # pipelined, output aliases an input
+        assert np.array_equal(pa.numpy(), ref.numpy())
+        ring.set_tuning("chunk_polys", -1)
+        pa = rh.DevicePoly.from_numpy(ring, a)
     ring.INTTMul(pa, pb, pa)                                                           # output aliases an input
     assert np.array_equal(pa.numpy(), ref.numpy())
     ring.close()

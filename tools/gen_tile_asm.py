@@ -349,7 +349,7 @@ def csub_all(const_name):
             emit("v_bfi_b32 v%d, v%d, v%d, v%d" % (X(kk) + 1, t.M, X(kk) + 1, t.T + 1))
 
 
-def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True):
+def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True, epilogue=None):
     A0, A1, A2, A3 = ADDR, ADDR + 1, ADDR + 2, ADDR + 3
     emit("; ---- prologue: zero halves of the zero-extended pairs, addresses")
     if PRIO in (1, 2):
@@ -426,6 +426,8 @@ def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True):
     emit("s_waitcnt lgkmcnt(0)")
     emit("; ---- round C (twiddle quads arrive in slot order; stage u needs slots < 2^(u+1) - 1)")
     round16(lambda slot: (TW0 + 4 * slot, None), stage_hook=lambda u: emit("s_waitcnt vmcnt(%d)" % (15 - ((2 << u) - 1))))
+    if epilogue:
+        return gen_submul_epilogue(A0, A1, A3, with_z=(epilogue == "submul_add"))
     emit("; ---- canonical reduction: x < 8q -> [0,q)")
     if PRIO in (1, 3):
         emit("s_setprio 2")                                   # finish: reduce, transpose, store -> frees the CU slot sooner
@@ -448,6 +450,79 @@ def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True):
     if tail_wait:
         emit("s_waitcnt vmcnt(0)")
 
+
+class VmTracker:
+    """issue order of vector-memory operations -> the vmcnt that guarantees a given one has completed (they retire in order)"""
+
+    def __init__(self):
+        self.n = 0
+        self.idx = {}
+
+    def issue(self, tag):
+        self.idx[tag] = self.n
+        self.n += 1
+
+    def wait(self, *tags):
+        need = max(self.idx[t] for t in tags)
+        emit("s_waitcnt vmcnt(%d)" % min(self.n - 1 - need, 63))
+
+
+def gen_submul_epilogue(A0, A1, A3, with_z):
+    """tail of the forward tile body with the epilogue of ntt_fwd_tile_submul (ntt_kernels.cuh):
+         out = [z +] MRed(2q - y + NTT(x), s)        (ring/basis_extension.go:255-257, ring/scaling.go:120-124; z: the ring.Add that follows)
+    MRed by the wave-uniform scalar s is a Shoup multiply by s*2^-64 mod q (operands sw0/sw1/sp0/sp1): the canonical result is the
+    same residue.  The transform's values are only brought below 4q before the subtraction (one conditional subtraction, not three).
+    y -> v32..v63 (the twiddle registers, free after round C), z -> v64..v79 in two halves, per-lane offsets v80..v83."""
+    Y0, Z0, EOFF = TW0, TW0 + 32, TW0 + 48
+    vm = VmTracker()
+    emit("; ---- epilogue: out = [z +] MRed(2q - y + NTT(x), s)")
+    emit("v_lshlrev_b32 v%d, 3, %%[tid]" % A0)
+    for j in range(4):
+        emit("v_add_u32 v%d, %d, v%d" % (EOFF + j, 8192 * j + 4096, A0))
+    for k in range(16):
+        j, rem = divmod(k, 4)
+        emit("global_load_dwordx2 %s, v%d, %%[py] offset:%d" % (pair(Y0 + 2 * k), EOFF + j, rem * 2048 - 4096))
+        vm.issue(("y", k))
+    if with_z:
+        for k in range(8):
+            j, rem = divmod(k, 4)
+            emit("global_load_dwordx2 %s, v%d, %%[pz] offset:%d" % (pair(Z0 + 2 * k), EOFF + j, rem * 2048 - 4096))
+            vm.issue(("z", k))
+    csub_all("nq4")
+    for k in range(16):
+        emit("ds_write_b64 v%d, %s offset:%d" % (A1, pair(X(k)), 8 * k))
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("s_barrier")
+    for k in range(16):
+        emit("ds_read_b64 %s, v%d offset:%d" % (pair(X(k)), A3, 2176 * k))
+    emit("s_waitcnt lgkmcnt(0)")
+    sw = ("%[sw0]", "%[sw1]", "%[sp0]", "%[sp1]")
+
+    def one(k, t):
+        x, y = X(k), Y0 + 2 * k
+        st = ["v_lshl_add_u64 %s, %s, 0, %%[q2]" % (pair(x), pair(x)),
+              "v_sub_co_u32 v%d, %s, v%d, v%d" % (x, t.cc, x, y),
+              "@CARRY",
+              "v_subb_co_u32 v%d, %s, v%d, v%d, %s" % (x + 1, t.cc, x + 1, y + 1, t.cc)]
+        st += shoup_mul_steps(x, sw, t) + csub_steps(x, "nq2", t) + csub_steps(x, "nq", t)
+        if with_z:
+            st += ["v_lshl_add_u64 %s, %s, 0, %s" % (pair(x), pair(x), pair(Z0 + 2 * (k % 8)))] + csub_steps(x, "nq", t)
+        return st
+    for k in range(0, 16, 2):
+        if with_z and k == 8:                                  # second half of z into the same registers (their readers have issued)
+            for kk in range(8, 16):
+                j, rem = divmod(kk, 4)
+                emit("global_load_dwordx2 %s, v%d, %%[pz] offset:%d" % (pair(Z0 + 2 * (kk - 8)), EOFF + j, rem * 2048 - 4096))
+                vm.issue(("z", kk))
+        tags = [("y", k + 1)] + ([("z", k + 1)] if with_z else [])
+        vm.wait(*tags)
+        for ins in interleave(one(k, T0), one(k + 1, T1)):
+            emit(ins)
+        for kk in (k, k + 1):
+            j, rem = divmod(kk, 4)
+            emit("global_store_dwordx2 v%d, %s, %%[pout] offset:%d" % (EOFF + j, pair(X(kk)), rem * 2048 - 4096))
+            vm.issue(("o", kk))
+    emit("s_waitcnt vmcnt(0)")
 
 
 def gen_cols(S1=4):
@@ -596,6 +671,12 @@ for s1 in (2, 3, 4):
     gen_cols_inv(s1)
     cols_inv[s1] = list(out)
     del out[:]
+gen(epilogue="submul")
+fwd_sm = list(out)
+del out[:]
+gen(epilogue="submul_add")
+fwd_sma = list(out)
+del out[:]
 gen_inverse()
 inv = list(out)
 del out[:]
@@ -604,7 +685,7 @@ inv_mul = list(out)
 clob_v = ", ".join('"v%d"' % i for i in range(NVGPR_USED))
 clob_s = ", ".join('"s%d"' % i for i in range(36, 100))
 text = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  forward: %d instructions, inverse: %d.\n" % (len(fwd), len(inv))
-text += render("NTT_TILE_ASM_BODY", fwd) + "".join(render("NTT_COLS%d_ASM_BODY" % (1 << k), cols[k]) + render("NTT_COLS%d_INV_ASM_BODY" % (1 << k), cols_inv[k]) for k in (2, 3, 4)) + render("NTT_TILE_INV_ASM_BODY", inv) + render("NTT_TILE_INV_MUL_ASM_BODY", inv_mul)
+text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_SUBMUL_ASM_BODY", fwd_sm) + render("NTT_TILE_SUBMUL_ADD_ASM_BODY", fwd_sma) + "".join(render("NTT_COLS%d_ASM_BODY" % (1 << k), cols[k]) + render("NTT_COLS%d_INV_ASM_BODY" % (1 << k), cols_inv[k]) for k in (2, 3, 4)) + render("NTT_TILE_INV_ASM_BODY", inv) + render("NTT_TILE_INV_MUL_ASM_BODY", inv_mul)
 text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v, clob_s)
 path = sys.argv[1] if len(sys.argv) > 1 else "ntt_tile_asm.inc"
 open(path, "w").write(text)
