@@ -161,7 +161,9 @@ int rh_ring_div_by_last_modulus_many_ntt(rh_ring* r, int round, int level, int n
 int rh_ring_tensor_degree1(rh_ring* r, const uint64_t* a0_dev, const uint64_t* a1_dev, const uint64_t* b0_dev, const uint64_t* b1_dev,
                            uint64_t* c0_dev, uint64_t* c1_dev, uint64_t* c2_dev, int npoly, int level, int mform_first);
 
-/* ---- Galois automorphisms X -> X^gen (ring/automorphism.go), power-of-two rings, never in place.
+/* ---- Galois automorphisms X -> X^gen (ring/automorphism.go), standard and conjugate-invariant rings, never in place.
+ *   conjugate-invariant rings: the NTT-domain table is built over NthRoot = 4N (gen must be 1 mod 4, else the reference's look-up
+ *   runs out of range); the coefficient-domain form is the Z[X+X^-1] branch (:131-156)
  *   rh_ring_automorphism_ntt: AutomorphismNTT (:39-47) / AutomorphismNTTWithIndex (:52-81); add_lazy != 0:
  *                             AutomorphismNTTWithIndexThenAddLazy (:86-117) (out += permuted in, wrapping)
  *   rh_ring_automorphism:     Automorphism (:121-176, standard ring branch), coefficient domain with sign flips   */
@@ -188,7 +190,7 @@ int rh_bext_decompose_and_split(rh_bext* be, int levelQ, int levelP, int nbPi, i
                                 uint64_t* p1Q, uint64_t* p1P, int npoly);
 
 
-/* ---- hybrid key-switch gadget product, NTT-domain input, levelP >= 1: rlwe.Evaluator.GadgetProduct
+/* ---- hybrid key-switch gadget product: rlwe.Evaluator.GadgetProduct.  This entry: NTT-domain ciphertext, levelP >= 1
  * (core/rlwe/evaluator_gadget_product.go:16-30) = gadgetProductMultiplePLazy (:122-188) + ModDown NTT->NTT (:33-46).
  * cx: npoly polys of levelQ+1 limbs (NTT domain).  evkQ / evkP: GadgetCiphertext.Value[i][0][c].Q / .P
  * (core/rlwe/gadgetciphertext.go:17-45) laid out [digit i < beta_key][component c < 2][all limbs of the ring][N], NTT
@@ -201,6 +203,22 @@ int rh_bext_gadget_product(rh_bext* be, int levelQ, int levelP, const uint64_t* 
  * ct_c = add_c + product_c, canonical.  add0 / add1 may be NULL and may alias ct0 / ct1. */
 int rh_bext_gadget_product_then_add(rh_bext* be, int levelQ, int levelP, const uint64_t* cx_dev, const uint64_t* evkQ_dev,
                                     const uint64_t* evkP_dev, int beta_key, const uint64_t* add0_dev, const uint64_t* add1_dev,
+                                    uint64_t* ct0_dev, uint64_t* ct1_dev, int npoly);
+
+/* The same for a COEFFICIENT-domain ciphertext (ct.IsNTT == false; :114-118, :139-143 and ModDown INTT -> INTT :62-66): cx, ct0, ct1 in
+ * the coefficient domain, levelP >= 1. */
+int rh_bext_gadget_product_coeff(rh_bext* be, int levelQ, int levelP, const uint64_t* cx_dev, const uint64_t* evkQ_dev,
+                                 const uint64_t* evkP_dev, int beta_key, uint64_t* ct0_dev, uint64_t* ct1_dev, int npoly);
+
+/* Gadget ciphertexts with at most ONE P modulus, optionally with a power-of-two decomposition on top of the RNS one:
+ * gadgetProductSinglePAndBitDecompLazy (core/rlwe/evaluator_gadget_product.go:190-324) + ModDown (:33-98).
+ *   levelP = 0: one P modulus (be has a P ring);  levelP = -1: none (be created with ringP = NULL, evkP = NULL, needs pw2 > 0)
+ *   pw2 = GadgetCiphertext.BaseTwoDecomposition (0: RNS digits only); digits_per_limb[i] = len(Value[i]) for i <= levelQ (host array,
+ *   NULL when pw2 = 0); key rows: row e = (sum of digits_per_limb before limb i) + j holds Value[i][j]: evkQ / evkP are
+ *   [row][component < 2][all limbs of the ring][N] like rh_bext_gadget_product, key_rows = number of rows supplied
+ *   cx_is_ntt: the ciphertext's domain (cx, ct0 and ct1 alike), as ct.IsNTT in the reference. */
+int rh_bext_gadget_product_single_p(rh_bext* be, int levelQ, int levelP, const uint64_t* cx_dev, int cx_is_ntt, int pw2,
+                                    const int* digits_per_limb, const uint64_t* evkQ_dev, const uint64_t* evkP_dev, int key_rows,
                                     uint64_t* ct0_dev, uint64_t* ct1_dev, int npoly);
 
 /* Hoisted form (rotations of one ciphertext share the decomposition).  Evaluator.DecomposeNTT

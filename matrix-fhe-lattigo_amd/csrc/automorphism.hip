@@ -1,7 +1,8 @@
 // automorphism.hip -- Galois automorphisms X -> X^gen on (poly, limb, coefficient) blocks.
 //
 // Replaces ring/automorphism.go: AutomorphismNTTIndex (:12-35), AutomorphismNTT / ...WithIndex (:39-81),
-// AutomorphismNTTWithIndexThenAddLazy (:86-117) and the coefficient-domain Automorphism for standard rings (:121-176).
+// AutomorphismNTTWithIndexThenAddLazy (:86-117) and the coefficient-domain Automorphism, both branches: standard rings
+// (:158-175) and conjugate-invariant rings Z[X+X^-1]/(X^2N+1) (:131-156).
 // Pure index gathers/scatters: 16*N bytes per limb.  The NTT-domain index is computed in the kernel
 // (two bit reversals and one multiply) instead of being read from a table.
 #include <hip/hip_runtime.h>
@@ -9,16 +10,36 @@
 
 RH_DEV u32 brevn(u32 x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
-// out[row][j] (=|+=) in[row][index(j)], index(j) = bitrev(((gen*(2*bitrev(j)+1) mod 2N) - 1)/2)    (:26-33)
+// out[row][j] (=|+=) in[row][index(j)], index(j) = bitrev(((gen*(2*bitrev(j)+1) mod NthRoot) - 1)/2), bit reversals over
+// lg = log2(NthRoot) - 1 bits (:26-33): NthRoot = 2N (standard, lg = logN) or 4N (conjugate invariant, lg = logN + 1)
 __global__ void __launch_bounds__(256)
-automorphism_ntt_kernel(const u64* in, u64* out, int logN, u32 gen, int add_lazy) {
-  const u32 N = 1u << logN, mask = 2 * N - 1;
+automorphism_ntt_kernel(const u64* in, u64* out, int logN, int lg, u32 gen, int add_lazy) {
+  const u32 N = 1u << logN, mask = (2u << lg) - 1;
   const size_t base = (size_t)blockIdx.x << logN;
   for (u32 j = blockIdx.y * blockDim.x + threadIdx.x; j < N; j += gridDim.y * blockDim.x) {
-    const u32 t1 = 2 * brevn(j, logN) + 1;
+    const u32 t1 = 2 * brevn(j, lg) + 1;
     const u32 t2 = (((gen * t1) & mask) - 1) >> 1;
-    const u64 v = in[base + brevn(t2, logN)];
+    const u64 v = in[base + brevn(t2, lg)];
     out[base + j] = add_lazy ? out[base + j] + v : v;
+  }
+}
+// coefficient domain, conjugate-invariant ring (:131-156): for i in [0, 2N): index = i*gen mod 2N, sign from bit log2(2N) of
+// i*gen; only index < N is written, from coefficient i (i < N) or 2N - i with the sign flipped (i >= N).  i -> index is a
+// bijection of [0, 2N), so every output coefficient is written exactly once: a scatter with one thread per i.
+__global__ void __launch_bounds__(256)
+automorphism_coeff_ci_kernel(const u64* in, u64* out, int logN, u64 gen, const LimbConsts* __restrict__ consts, int L) {
+  const u32 N = 1u << logN;
+  const u64 q = consts[blockIdx.x % (u32)L].q;
+  const size_t base = (size_t)blockIdx.x << logN;
+  for (u32 i = blockIdx.y * blockDim.x + threadIdx.x; i < 2 * N; i += gridDim.y * blockDim.x) {
+    const u64 raw = (u64)i * gen;
+    const u32 index = (u32)(raw & (2 * N - 1));
+    u64 tmp = (raw >> (logN + 1)) & 1;
+    if (index >= N) continue;
+    u32 idx = i;
+    if (idx >= N) { idx = 2 * N - idx; tmp ^= 1; }
+    const u64 v = in[base + idx];
+    out[base + index] = v * (tmp ^ 1) | (q - v) * tmp;
   }
 }
 // coefficient domain, standard ring: out[(i*gen) mod N] = +-in[i], sign from bit logN of i*gen   (:162-175)
@@ -38,7 +59,7 @@ automorphism_coeff_kernel(const u64* in, u64* out, int logN, u64 gen, const Limb
 
 static int common(rh_ring* r, int level, const void* in, const void* out, int npoly) {
   if (!r || !in || !out) return rh_fail(RH_ERR_ARG, "automorphism: null argument");
-  if (r->kind != RH_RING_STANDARD) return rh_fail(RH_ERR_UNSUPPORTED, "automorphism: power-of-two rings only (ring/automorphism.go:14-20)");
+  if (r->kind != RH_RING_STANDARD && r->kind != RH_RING_CI) return rh_fail(RH_ERR_UNSUPPORTED, "automorphism: power-of-two rings only (ring/automorphism.go:14-20)");
   if (in == out) return rh_fail(RH_ERR_ARG, "automorphism: the result cannot be in place (ring/automorphism.go:38)");
   if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "automorphism: level %d out of range [0,%d)", level, r->L);
   if (npoly < 0) return rh_fail(RH_ERR_ARG, "automorphism: npoly < 0");
@@ -57,7 +78,13 @@ extern "C" int rh_ring_automorphism_ntt(rh_ring* r, int level, const uint64_t* i
   const unsigned rows = (unsigned)npoly * (level + 1);
   if (!rows) return RH_OK;
   unsigned chunks = ((unsigned)r->N + 1023) / 1024; if (chunks > 64) chunks = 64;
-  automorphism_ntt_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(in, out, r->logN, (u32)(gen & (2 * (u64)r->N - 1)), add_lazy ? 1 : 0);
+  const int lg = r->kind == RH_RING_CI ? r->logN + 1 : r->logN;          // log2(NthRoot) - 1 with NthRoot = 4N / 2N (ring/ring.go:178-183)
+  const u64 nthroot = (u64)2 << lg;
+  if ((gen & 1) == 0) return rh_fail(RH_ERR_ARG, "automorphism: the Galois element must be odd");
+  // conjugate-invariant ring: the slots are the exponents = 1 mod 4 of the 4N-th root; gen = 3 mod 4 maps them onto exponents the
+  // ring does not hold and the reference's table look-up runs past the N coefficients (index out of range panic)
+  if (r->kind == RH_RING_CI && (gen & 3) != 1) return rh_fail(RH_ERR_ARG, "automorphism: on a conjugate-invariant ring the Galois element must be 1 mod 4");
+  automorphism_ntt_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(in, out, r->logN, lg, (u32)(gen & (nthroot - 1)), add_lazy ? 1 : 0);
   return done("automorphism_ntt_kernel");
 }
 extern "C" int rh_ring_automorphism(rh_ring* r, int level, const uint64_t* in, uint64_t gen, uint64_t* out, int npoly) {
@@ -65,6 +92,8 @@ extern "C" int rh_ring_automorphism(rh_ring* r, int level, const uint64_t* in, u
   const unsigned rows = (unsigned)npoly * (level + 1);
   if (!rows) return RH_OK;
   unsigned chunks = ((unsigned)r->N + 1023) / 1024; if (chunks > 64) chunks = 64;
-  automorphism_coeff_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(in, out, r->logN, gen, r->d_consts, level + 1);
+  if ((gen & 1) == 0) return rh_fail(RH_ERR_ARG, "automorphism: the Galois element must be odd");
+  if (r->kind == RH_RING_CI) automorphism_coeff_ci_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(in, out, r->logN, gen, r->d_consts, level + 1);
+  else automorphism_coeff_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(in, out, r->logN, gen, r->d_consts, level + 1);
   return done("automorphism_coeff_kernel");
 }

@@ -158,7 +158,8 @@ extern "C" int rh_bext_decompose_ntt(rh_bext* be, int levelQ, int levelP, const 
 // cx != null (internal, direct product): the digits' own limbs of decompQ were not filled; the multiply-accumulate reads them from cx.
 static int hoisted_tail(rh_bext* be, int levelQ, int levelP, const uint64_t* decompQ, const uint64_t* decompP, const uint64_t* evkQ,
                         const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly, const uint64_t* cx,
-                        const uint64_t* add0 = nullptr, const uint64_t* add1 = nullptr, uint64_t* out0 = nullptr, uint64_t* out1 = nullptr) {
+                        const uint64_t* add0 = nullptr, const uint64_t* add1 = nullptr, uint64_t* out0 = nullptr, uint64_t* out1 = nullptr,
+                        bool out_ntt = true) {
   // ct0 / ct1 hold the Q-part accumulators; results go to out_c (default: ct_c itself) as [add_c +] ModDown(ct_c, P part)
   if (!out0) out0 = ct0;
   if (!out1) out1 = ct1;
@@ -176,7 +177,14 @@ static int hoisted_tail(rh_bext* be, int levelQ, int levelP, const uint64_t* dec
   ReduceSchedule rs(RQ, levelQ, RP, levelP);
   if (int rc = mac_all(RQ, decompQ, wq, evkQ, beta, rs.QiOverF, ct0, ct1, npoly, LQ, cx, LP)) return rc;
   if (int rc = mac_all(RP, decompP, wp, evkP, beta, rs.PiOverF, aP0, aP1, npoly, LP)) return rc;
-  return rh_bext_moddown_ntt_pair(be, levelQ, levelP, ct0, ct1, aP0, out0, out1, npoly, add0, add1);
+  if (out_ntt) return rh_bext_moddown_ntt_pair(be, levelQ, levelP, ct0, ct1, aP0, out0, out1, npoly, add0, add1);
+  // coefficient-domain ciphertext (:114-118, then ModDown INTT -> INTT :62-66): ringQP.INTT on both components, ModDownQPtoQ
+  if (add0 || add1) return rh_fail(RH_ERR_UNSUPPORTED, "gadget product: the fused Add exists for NTT-domain ciphertexts only");
+  if (int rc = rh_std_ntt_launch(RQ, ct0, ct0, npoly, LQ, 0, true, false, 0)) return rc;
+  if (int rc = rh_std_ntt_launch(RQ, ct1, ct1, npoly, LQ, 0, true, false, 0)) return rc;
+  if (int rc = rh_std_ntt_launch(RP, aP0, aP0, 2 * npoly, LP, 0, true, false, 0)) return rc;
+  if (int rc = rh_bext_moddown_qp_to_q(be, levelQ, levelP, ct0, aP0, out0, npoly)) return rc;
+  return rh_bext_moddown_qp_to_q(be, levelQ, levelP, ct1, aP1, out1, npoly);
 }
 extern "C" int rh_bext_gadget_product_hoisted(rh_bext* be, int levelQ, int levelP, const uint64_t* decompQ, const uint64_t* decompP,
                                               const uint64_t* evkQ, const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly) {
@@ -199,7 +207,8 @@ extern "C" int rh_bext_gadget_product_hoisted_then_add(rh_bext* be, int levelQ, 
 }
 
 static int gadget_product_impl(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, const uint64_t* evkQ, const uint64_t* evkP,
-                               int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly, const uint64_t* add0, const uint64_t* add1) {
+                               int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly, const uint64_t* add0, const uint64_t* add1,
+                               bool is_ntt = true) {
   if (!be || !cx || !evkQ || !evkP || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "gadget_product: null argument");
   RhBextGuard guard(be);
   int beta; if (int rc = ks_check(be, levelQ, levelP, beta_key, "gadget_product", &beta)) return rc;
@@ -213,11 +222,14 @@ static int gadget_product_impl(rh_bext* be, int levelQ, int levelP, const uint64
   u64 *decQ, *decP;
   if (int rc = rh_bext_scratch(be, 3, (size_t)beta * wq, &decQ)) return rc;
   if (int rc = rh_bext_scratch(be, 4, (size_t)beta * wp, &decP)) return rc;
-  u64* cxInv;
-  if (int rc = rh_bext_scratch(be, 2, wq, &cxInv)) return rc;
-  if (int rc = rh_std_ntt_launch(RQ, cx, cxInv, npoly, LQ, 0, true, false, 0)) return rc;                  // ringQ.INTT(cxNTT, cxInvNTT) (:138)
+  u64* other;
+  if (int rc = rh_bext_scratch(be, 2, wq, &other)) return rc;
+  // ctQP.IsNTT: cxNTT = cx, cxInvNTT = INTT(cx) (:134-138); else cxInvNTT = cx, cxNTT = NTT(cx) (:139-143)
+  if (int rc = rh_std_ntt_launch(RQ, cx, other, npoly, LQ, 0, is_ntt, false, 0)) return rc;
+  const u64* cxNTT = is_ntt ? cx : other; const u64* cxInv = is_ntt ? other : cx;
   for (int i = 0; i < beta; ++i)
-    if (int rc = decompose_single_ntt(be, levelQ, levelP, i, cx, cxInv, decQ + (size_t)i * wq, decP + (size_t)i * wp, npoly, false)) return rc;
+    if (int rc = decompose_single_ntt(be, levelQ, levelP, i, cxNTT, cxInv, decQ + (size_t)i * wq, decP + (size_t)i * wp, npoly, false)) return rc;
+  if (!is_ntt) return hoisted_tail(be, levelQ, levelP, decQ, decP, evkQ, evkP, beta_key, ct0, ct1, npoly, cxNTT, nullptr, nullptr, nullptr, nullptr, false);
   if (!add0 && !add1) return hoisted_tail(be, levelQ, levelP, decQ, decP, evkQ, evkP, beta_key, ct0, ct1, npoly, cx);
   u64 *acc0, *acc1;                                  // accumulate beside the outputs: they may alias the addends (or cx)
   if (int rc = rh_bext_scratch(be, 7, wq, &acc0)) return rc;
@@ -235,4 +247,101 @@ extern "C" int rh_bext_gadget_product_then_add(rh_bext* be, int levelQ, int leve
                                                const uint64_t* evkP, int beta_key, const uint64_t* add0, const uint64_t* add1,
                                                uint64_t* ct0, uint64_t* ct1, int npoly) {
   return gadget_product_impl(be, levelQ, levelP, cx, evkQ, evkP, beta_key, ct0, ct1, npoly, add0, add1);
+}
+
+// rlwe.Evaluator.GadgetProduct for a COEFFICIENT-domain ciphertext (ct.IsNTT == false), levelP >= 1: gadgetProductMultiplePLazy with
+// cxInvNTT = cx and cxNTT = NTT(cx) (:139-143), the accumulators brought back with ringQP.INTT (:114-118), ModDown INTT -> INTT
+// = ModDownQPtoQ on both components (:62-66).  cx, ct0, ct1: coefficient domain.
+extern "C" int rh_bext_gadget_product_coeff(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, const uint64_t* evkQ,
+                                            const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly) {
+  return gadget_product_impl(be, levelQ, levelP, cx, evkQ, evkP, beta_key, ct0, ct1, npoly, nullptr, nullptr, false);
+}
+
+// ---- gadgetProductSinglePAndBitDecompLazy (:190-324) + ModDown (:33-98): gadget ciphertexts with at most one P modulus, optionally
+// with a power-of-two decomposition on top of the RNS one.  One digit per Q modulus i; pw2 == 0: the digit is the sign-aware
+// re-embedding of limb i (DecomposeAndSplit, single-prime branch); pw2 > 0: digits_per_limb[i] base-2^pw2 windows of limb i
+// (ring.MaskVec), the same small vector under every modulus.  Each digit is transformed and multiply-accumulated against its key
+// row with the reference's Reduce schedule.  The reference transforms with NTTLazy and accumulates MRedLazy values; the closing
+// Reduce / ModDown outputs are canonical, so the canonical forward transform used here gives the same bits.
+__global__ void __launch_bounds__(256)
+mask_broadcast_kernel(const u64* in, int in_rows, int src_limb, int shift, u64 mask, u64* outQ, int LQ, u64* outP, int LP, int N) {
+  const int k = blockIdx.x * 256 + threadIdx.x, poly = blockIdx.y;
+  if (k >= N) return;
+  const u64 v = (in[((size_t)poly * in_rows + src_limb) * N + k] >> shift) & mask;           // MaskVec (ring/vec_ops.go:870)
+  for (int u = 0; u < LQ; ++u) outQ[((size_t)poly * LQ + u) * N + k] = v;
+  for (int u = 0; u < LP; ++u) outP[((size_t)poly * LP + u) * N + k] = v;
+}
+static int reduce_pair(rh_ring* R, int L, u64* a0, u64* a1, int npoly) {
+  if (int rc = rh_vec_launch(R, RH_OP_REDUCE, a0, nullptr, a0, npoly, L, 0, nullptr, nullptr)) return rc;
+  return rh_vec_launch(R, RH_OP_REDUCE, a1, nullptr, a1, npoly, L, 0, nullptr, nullptr);
+}
+extern "C" int rh_bext_gadget_product_single_p(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, int cx_is_ntt, int pw2,
+                                               const int* digits_per_limb, const uint64_t* evkQ, const uint64_t* evkP, int key_rows,
+                                               uint64_t* ct0, uint64_t* ct1, int npoly) {
+  if (!be || !cx || !evkQ || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "gadget_product_single_p: null argument");
+  RhBextGuard guard(be);
+  rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
+  if (RQ->kind != RH_RING_STANDARD) return rh_fail(RH_ERR_UNSUPPORTED, "gadget_product_single_p: standard rings only");
+  if (levelQ < 0 || levelQ >= RQ->L) return rh_fail(RH_ERR_ARG, "gadget_product_single_p: levelQ %d out of range [0,%d)", levelQ, RQ->L);
+  if (levelP != 0 && levelP != -1) return rh_fail(RH_ERR_ARG, "gadget_product_single_p: levelP must be 0 or -1 (levelP >= 1: rh_bext_gadget_product)");
+  if (levelP == 0 && (!RP || !evkP)) return rh_fail(RH_ERR_ARG, "gadget_product_single_p: levelP = 0 needs a P ring and the key's P part");
+  if (pw2 < 0 || pw2 > 63 || (pw2 > 0 && !digits_per_limb)) return rh_fail(RH_ERR_ARG, "gadget_product_single_p: bad BaseTwoDecomposition");
+  // pw2 == 0 without a P modulus: the reference calls DecomposeAndSplit with nbPi = levelP + 1 = 0, which degenerates (every digit
+  // reads limb 0); such gadget ciphertexts are built with a power-of-two decomposition (core/rlwe/params.go:615-633)
+  if (pw2 == 0 && levelP < 0) return rh_fail(RH_ERR_UNSUPPORTED, "gadget_product_single_p: no P modulus needs BaseTwoDecomposition > 0");
+  if (npoly <= 0) return RH_OK;
+  (void)hipSetDevice(RQ->device);
+  (void)hipGetLastError();
+  const int LQ = levelQ + 1, LP = levelP + 1, N = RQ->N;
+  const size_t wq = (size_t)npoly * LQ * N, wp = (size_t)npoly * LP * N;
+  int rows_needed = 0;
+  for (int i = 0; i < LQ; ++i) rows_needed += pw2 ? digits_per_limb[i] : 1;
+  if (key_rows < rows_needed) return rh_fail(RH_ERR_ARG, "gadget_product_single_p: key has %d rows, level needs %d", key_rows, rows_needed);
+  u64 *cxInvBuf, *c2Q, *c2P = nullptr, *aP0 = nullptr, *aP1 = nullptr;
+  if (int rc = rh_bext_scratch(be, 3, wq, &c2Q)) return rc;
+  if (LP) { if (int rc = rh_bext_scratch(be, 4, wp, &c2P)) return rc; if (int rc = rh_bext_scratch(be, 5, 2 * wp, &aP0)) return rc; aP1 = aP0 + wp; }
+  const u64* cxInv = cx;
+  if (cx_is_ntt) {
+    if (int rc = rh_bext_scratch(be, 2, wq, &cxInvBuf)) return rc;
+    if (int rc = rh_std_ntt_launch(RQ, cx, cxInvBuf, npoly, LQ, 0, true, false, 0)) return rc;          // ringQ.INTT(cx, cxInvNTT) (:201-203)
+    cxInv = cxInvBuf;
+  }
+  const int QiOverF = rh_overflow_margin(RQ->moduli, levelQ) >> 1;
+  const int PiOverF = LP ? rh_overflow_margin(RP->moduli, levelP) >> 1 : 1;
+  const size_t evq = (size_t)RQ->L * N, evp = LP ? (size_t)RP->L * N : 0;
+  const u64 mask = pw2 ? (((u64)1 << pw2) - 1) : 0;
+  const dim3 grid((N + 255) / 256, npoly);
+  int e = 0, reduce = 0;
+  for (int i = 0; i < LQ; ++i) {
+    const int nd = pw2 ? digits_per_limb[i] : 1;
+    if (!pw2) if (int rc = rh_bext_decompose_and_split(be, levelQ, levelP, LP, i, cxInv, c2Q, c2P, npoly)) return rc;   // (:243-245)
+    for (int j = 0; j < nd; ++j, ++e) {
+      if (pw2) {
+        mask_broadcast_kernel<<<grid, 256, 0, rh_stream(RQ)>>>(cxInv, LQ, i, j * pw2, mask, c2Q, LQ, c2P, LP, N);          // (:249-252)
+        if (hipGetLastError() != hipSuccess) return rh_fail(RH_ERR_DEVICE, "mask_broadcast_kernel launch failed");
+      }
+      if (pw2 || j == 0) {                                             // s.NTTLazy under every modulus (:258-262, :285-289)
+        if (int rc = rh_std_ntt_launch(RQ, c2Q, c2Q, npoly, LQ, 0, false, false, 0)) return rc;
+        if (LP) if (int rc = rh_std_ntt_launch(RP, c2P, c2P, npoly, LP, 0, false, false, 0)) return rc;
+      }
+      if (int rc = rh_gadget_mac(RQ, c2Q, evkQ + ((size_t)e * 2) * evq, evkQ + ((size_t)e * 2 + 1) * evq, ct0, ct1, npoly, LQ, e == 0)) return rc;
+      if (LP) if (int rc = rh_gadget_mac(RP, c2P, evkP + ((size_t)e * 2) * evp, evkP + ((size_t)e * 2 + 1) * evp, aP0, aP1, npoly, LP, e == 0)) return rc;
+      if (reduce % QiOverF == QiOverF - 1) if (int rc = reduce_pair(RQ, LQ, ct0, ct1, npoly)) return rc;
+      if (LP && reduce % PiOverF == PiOverF - 1) if (int rc = reduce_pair(RP, LP, aP0, aP1, npoly)) return rc;
+      ++reduce;
+    }
+  }
+  if (reduce % QiOverF != 0) if (int rc = reduce_pair(RQ, LQ, ct0, ct1, npoly)) return rc;
+  if (LP && reduce % PiOverF != 0) if (int rc = reduce_pair(RP, LP, aP0, aP1, npoly)) return rc;
+  if (cx_is_ntt) {
+    if (!LP) return RH_OK;                                             // levelP = -1, NTT -> NTT: CopyLvl (:72-75)
+    return rh_bext_moddown_ntt_pair(be, levelQ, levelP, ct0, ct1, aP0, ct0, ct1, npoly, nullptr, nullptr);
+  }
+  // coefficient-domain ciphertext: ringQP.INTT (:114-118), then ModDownQPtoQ / plain copy
+  if (int rc = rh_std_ntt_launch(RQ, ct0, ct0, npoly, LQ, 0, true, false, 0)) return rc;
+  if (int rc = rh_std_ntt_launch(RQ, ct1, ct1, npoly, LQ, 0, true, false, 0)) return rc;
+  if (!LP) return RH_OK;
+  if (int rc = rh_std_ntt_launch(RP, aP0, aP0, 2 * npoly, LP, 0, true, false, 0)) return rc;
+  if (int rc = rh_bext_moddown_qp_to_q(be, levelQ, levelP, ct0, aP0, ct0, npoly)) return rc;
+  return rh_bext_moddown_qp_to_q(be, levelQ, levelP, ct1, aP1, ct1, npoly);
 }

@@ -104,6 +104,8 @@ def lib():
         "rh_bext_decompose_and_split": (i, [vp, i, i, i, i, vp, vp, vp, i]),
         "rh_bext_gadget_product": (i, [vp, i, i, vp, vp, vp, i, vp, vp, i]),
         "rh_bext_gadget_product_then_add": (i, [vp, i, i, vp, vp, vp, i, vp, vp, vp, vp, i]),
+        "rh_bext_gadget_product_coeff": (i, [vp, i, i, vp, vp, vp, i, vp, vp, i]),
+        "rh_bext_gadget_product_single_p": (i, [vp, i, i, vp, i, i, C.POINTER(i), vp, vp, i, vp, vp, i]),
         "rh_bext_decompose_ntt": (i, [vp, i, i, vp, i, vp, vp, i]),
         "rh_bext_gadget_product_hoisted": (i, [vp, i, i, vp, vp, vp, vp, i, vp, vp, i]),
         "rh_bext_gadget_product_hoisted_then_add": (i, [vp, i, i, vp, vp, vp, vp, i, vp, vp, vp, vp, i]),
@@ -403,10 +405,10 @@ class Ring:
 class BasisExtender:
     """ring.BasisExtender (ring/basis_extension.go:13-79) over a (ringQ, ringP) pair on the same device."""
 
-    def __init__(self, ringQ, ringP):
+    def __init__(self, ringQ, ringP=None):
         self.ringQ, self.ringP = ringQ, ringP
         h = C.c_void_p()
-        _check(lib().rh_bext_create(C.byref(h), ringQ._h, ringP._h))
+        _check(lib().rh_bext_create(C.byref(h), ringQ._h, ringP._h if ringP is not None else None))
         self._h = h
 
     def reserve(self, npoly):

@@ -7,8 +7,9 @@ the HIP library; no key generation, no encoders (those stay with the reference).
   Automorphism           core/rlwe/evaluator_automorphism.go:14-60      AutomorphismHoisted  :62-105
   ApplyEvaluationKey     core/rlwe/evaluator_evaluationkey.go:37-123 (same ring degree)   Relinearize  :125-153
 
-Restrictions (the reference's other branches are not built): ciphertexts in the NTT domain, levelP >= 1
-(gadgetProductMultiplePLazy; the single-P / bit-decomposition branch :190-324 is out of scope), BaseTwoDecomposition 0."""
+GadgetProduct covers both branches of GadgetProductLazy (:102-121): gadgetProductMultiplePLazy (levelP >= 1) and
+gadgetProductSinglePAndBitDecompLazy (levelP <= 0, optional BaseTwoDecomposition), for NTT- and coefficient-domain ciphertexts.
+The hoisted forms and the automorphism / relinearisation callers take NTT-domain ciphertexts and levelP >= 1."""
 import numpy as np
 
 from .ringhip import BasisExtender, DevicePoly, RingHipError, _check, lib
@@ -20,16 +21,26 @@ class GadgetCiphertext:
     Q part [digit][component < 2][limb of ringQ][N], P part [digit][component][limb of ringP][N], NTT domain, Montgomery
     form, shared by every ciphertext of a batch."""
 
-    def __init__(self, ringQ, ringP, valueQ, valueP):
-        valueQ, valueP = np.asarray(valueQ, dtype=np.uint64), np.asarray(valueP, dtype=np.uint64)
-        if valueQ.ndim != 4 or valueP.ndim != 4 or valueQ.shape[:2] != valueP.shape[:2] or valueQ.shape[1] != 2:
-            raise RingHipError("GadgetCiphertext: expected (digits, 2, limbs, N) arrays for Q and P")
-        if valueQ.shape[2] != ringQ.L or valueP.shape[2] != ringP.L:
-            raise RingHipError("GadgetCiphertext: limb counts must be those of ringQ / ringP")
+    def __init__(self, ringQ, ringP, valueQ, valueP, BaseTwoDecomposition=0, digits_per_limb=None):
+        """valueQ / valueP: (rows, 2, limbs, N).  rows = RNS digits; with a power-of-two decomposition (BaseTwoDecomposition > 0,
+        at most one P modulus) row sum(digits_per_limb[:i]) + j holds Value[i][j] and digits_per_limb[i] = len(Value[i]).
+        ringP / valueP may be None: a gadget ciphertext without P (LevelP() == -1)."""
+        valueQ = np.asarray(valueQ, dtype=np.uint64)
+        if valueQ.ndim != 4 or valueQ.shape[1] != 2 or valueQ.shape[2] != ringQ.L:
+            raise RingHipError("GadgetCiphertext: expected a (rows, 2, limbs of ringQ, N) array for Q")
         self.digits = valueQ.shape[0]
         self.Q = DevicePoly.from_numpy(ringQ, valueQ.reshape(self.digits * 2, ringQ.L, ringQ.N))
-        self.P = DevicePoly.from_numpy(ringP, valueP.reshape(self.digits * 2, ringP.L, ringP.N))
-        self.levelQ, self.levelP = ringQ.L - 1, ringP.L - 1
+        self.P = None
+        if ringP is not None:
+            valueP = np.asarray(valueP, dtype=np.uint64)
+            if valueP.ndim != 4 or valueP.shape[:2] != valueQ.shape[:2] or valueP.shape[2] != ringP.L:
+                raise RingHipError("GadgetCiphertext: expected a (rows, 2, limbs of ringP, N) array for P")
+            self.P = DevicePoly.from_numpy(ringP, valueP.reshape(self.digits * 2, ringP.L, ringP.N))
+        self.levelQ, self.levelP = ringQ.L - 1, (ringP.L - 1 if ringP is not None else -1)
+        self.BaseTwoDecomposition = int(BaseTwoDecomposition)
+        self.digits_per_limb = list(digits_per_limb) if digits_per_limb is not None else None
+        if self.BaseTwoDecomposition and (self.levelP > 0 or self.digits_per_limb is None or sum(self.digits_per_limb) != self.digits):
+            raise RingHipError("GadgetCiphertext: BaseTwoDecomposition needs at most one P modulus and digits_per_limb summing to the row count")
 
     def LevelQ(self):
         return self.levelQ
@@ -41,7 +52,7 @@ class GadgetCiphertext:
 class Evaluator:
     """rlwe.Evaluator restricted to the key-switch path; `galois_keys` maps a Galois element to its GadgetCiphertext."""
 
-    def __init__(self, ringQ, ringP, galois_keys=None):
+    def __init__(self, ringQ, ringP=None, galois_keys=None):
         self.ringQ, self.ringP = ringQ, ringP
         self.be = BasisExtender(ringQ, ringP)
         self.galois_keys = dict(galois_keys or {})
@@ -73,11 +84,22 @@ class Evaluator:
 
     # ---- core/rlwe/evaluator_gadget_product.go ---------------------------------------------------------------
     def GadgetProduct(self, levelQ, cx, gadgetCt, ct):
-        """ct = (<decomp(cx), gadget[0]>, <decomp(cx), gadget[1]>) / P mod Q (:16-30); cx and ct in the NTT domain"""
+        """ct = (<decomp(cx), gadget[0]>, <decomp(cx), gadget[1]>) / P mod Q (:16-30).  ct.IsNTT tells the domain of cx and of the
+        result (:14); gadgetCt.LevelP() >= 1 takes gadgetProductMultiplePLazy, <= 0 the single-P / bit-decomposition branch (:109-113)"""
+        import ctypes as C
         levelQ = min(levelQ, gadgetCt.LevelQ())
         self._rows(levelQ, cx, ct.Value[0], ct.Value[1])
-        _check(lib().rh_bext_gadget_product(self.be._h, levelQ, gadgetCt.LevelP(), cx.ptr, gadgetCt.Q.ptr, gadgetCt.P.ptr,
-                                            gadgetCt.digits, ct.Value[0].ptr, ct.Value[1].ptr, cx.npoly))
+        L, lp = lib(), gadgetCt.LevelP()
+        pP = gadgetCt.P.ptr if gadgetCt.P is not None else None
+        if lp >= 1 and ct.IsNTT:
+            _check(L.rh_bext_gadget_product(self.be._h, levelQ, lp, cx.ptr, gadgetCt.Q.ptr, pP, gadgetCt.digits, ct.Value[0].ptr, ct.Value[1].ptr, cx.npoly))
+        elif lp >= 1:
+            _check(L.rh_bext_gadget_product_coeff(self.be._h, levelQ, lp, cx.ptr, gadgetCt.Q.ptr, pP, gadgetCt.digits, ct.Value[0].ptr, ct.Value[1].ptr, cx.npoly))
+        else:
+            dpl = gadgetCt.digits_per_limb
+            arr = (C.c_int * len(dpl))(*dpl) if dpl is not None else None
+            _check(L.rh_bext_gadget_product_single_p(self.be._h, levelQ, lp, cx.ptr, 1 if ct.IsNTT else 0, gadgetCt.BaseTwoDecomposition, arr,
+                                                     gadgetCt.Q.ptr, pP, gadgetCt.digits, ct.Value[0].ptr, ct.Value[1].ptr, cx.npoly))
 
     def GadgetProductThenAdd(self, levelQ, cx, gadgetCt, add0, add1, ct):
         """ct[c] = add_c + GadgetProduct(cx)[c] (ring.Add, canonical) -- the Add the callers below issue right after the

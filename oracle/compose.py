@@ -51,3 +51,103 @@ def gadget_product(N, Q, P, levelQ, levelP, cx, evkQ, evkP):
     if reduce % piof:
         red("P", Pl)
     return [orc.moddown_qp_to_q_ntt(acc[("Q", c)], acc[("P", c)], Ql, Pl, srQ, srP) for c in (0, 1)]
+
+
+def _mac(acc, key, c2, mods, first):
+    op = OPS["MUL_MONT_LAZY"] if first else OPS["MUL_MONT_LAZY_THEN_ADD_LAZY"]
+    prev = acc if not first else np.zeros_like(c2)
+    return np.stack([orc.vec_op(op, key[i], c2[i], prev[i], 0, 0, mods[i]) for i in range(len(mods))])
+
+
+def _reduce(a, mods):
+    return np.stack([orc.vec_op(OPS["REDUCE"], a[i], None, a[i], 0, 0, mods[i]) for i in range(len(mods))])
+
+
+def gadget_product_coeff(N, Q, P, levelQ, levelP, cx, evkQ, evkP):
+    """GadgetProduct for a coefficient-domain ciphertext, levelP >= 1: cxNTT = NTT(cx) (:139-143), the lazy product as above,
+    ringQP.INTT (:114-118), ModDown INTT -> INTT = ModDownQPtoQ (:62-66).  cx and the results: coefficient domain."""
+    LQ, LP = levelQ + 1, levelP + 1
+    Ql, Pl = Q[:LQ], P[:LP]
+    srQ = [orc.SubRingConsts(N, q) for q in Ql]
+    srP = [orc.SubRingConsts(N, p) for p in Pl]
+    beta = (levelQ + levelP + 1) // (levelP + 1)
+    cxntt = np.stack([orc.ntt(cx[i], srQ[i]) for i in range(LQ)])
+    accQ, accP = [None, None], [None, None]
+    qiof = int(2.0 ** 64 / float(max(Ql))) >> 1
+    piof = int(2.0 ** 64 / float(max(Pl))) >> 1
+    reduce = 0
+    for d in range(beta):
+        c2q, c2p = orc.decompose_and_split(levelQ, levelP, LP, d, cx, Q, P)
+        st, ed = d * LP, min(d * LP + LP, LQ)
+        c2q = np.stack([cxntt[i] if st <= i < ed else orc.ntt(c2q[i], srQ[i]) for i in range(LQ)])
+        c2p = np.stack([orc.ntt(c2p[j], srP[j]) for j in range(LP)])
+        for c in (0, 1):
+            accQ[c] = _mac(accQ[c], evkQ[d, c], c2q, Ql, d == 0)
+            accP[c] = _mac(accP[c], evkP[d, c], c2p, Pl, d == 0)
+        if reduce % qiof == qiof - 1:
+            accQ = [_reduce(a, Ql) for a in accQ]
+        if reduce % piof == piof - 1:
+            accP = [_reduce(a, Pl) for a in accP]
+        reduce += 1
+    if reduce % qiof:
+        accQ = [_reduce(a, Ql) for a in accQ]
+    if reduce % piof:
+        accP = [_reduce(a, Pl) for a in accP]
+    out = []
+    for c in (0, 1):
+        q = np.stack([orc.intt(accQ[c][i], srQ[i]) for i in range(LQ)])
+        p = np.stack([orc.intt(accP[c][j], srP[j]) for j in range(LP)])
+        out.append(orc.moddown_qp_to_q(q, p, Ql, Pl))
+    return out
+
+
+def gadget_product_single_p(N, Q, P, levelQ, levelP, cx, is_ntt, pw2, digits_per_limb, evkQ, evkP):
+    """gadgetProductSinglePAndBitDecompLazy (core/rlwe/evaluator_gadget_product.go:190-324) + ModDown (:33-98), levelP in {0, -1}.
+    evkQ / evkP: (rows, 2, limbs, N), row = (digits before limb i) + j.  cx / results in the domain `is_ntt` names."""
+    LQ, LP = levelQ + 1, levelP + 1
+    Ql, Pl = Q[:LQ], (P[:LP] if LP else [])
+    srQ = [orc.SubRingConsts(N, q) for q in Ql]
+    srP = [orc.SubRingConsts(N, p) for p in Pl]
+    cxinv = np.stack([orc.intt(cx[i], srQ[i]) for i in range(LQ)]) if is_ntt else np.asarray(cx, dtype=np.uint64)
+    mask = (1 << pw2) - 1 if pw2 else 0
+    qiof = int(2.0 ** 64 / float(max(Ql))) >> 1
+    piof = (int(2.0 ** 64 / float(max(Pl))) >> 1) if LP else 1
+    accQ, accP = [None, None], [None, None]
+    reduce = e = 0
+    for i in range(LQ):
+        nd = digits_per_limb[i] if pw2 else 1
+        if not pw2:
+            c2q, c2p = orc.decompose_and_split(levelQ, levelP, levelP + 1, i, cxinv, Q, P)
+        for j in range(nd):
+            if pw2:
+                cw = orc.vec_op(OPS["MASK"], cxinv[i], None, np.zeros(N, dtype=np.uint64), j * pw2, mask, Ql[i])
+                c2q = np.stack([cw for _ in range(LQ)])
+                c2p = np.stack([cw for _ in range(LP)]) if LP else None
+            nq = np.stack([orc.ntt(c2q[u], srQ[u], lazy=True) for u in range(LQ)])                    # s.NTTLazy (:258-262)
+            for c in (0, 1):
+                accQ[c] = _mac(accQ[c], evkQ[e, c], nq, Ql, e == 0)
+            if LP:
+                npp = np.stack([orc.ntt(c2p[u], srP[u], lazy=True) for u in range(LP)])
+                for c in (0, 1):
+                    accP[c] = _mac(accP[c], evkP[e, c], npp, Pl, e == 0)
+            if reduce % qiof == qiof - 1:
+                accQ = [_reduce(a, Ql) for a in accQ]
+            if LP and reduce % piof == piof - 1:
+                accP = [_reduce(a, Pl) for a in accP]
+            reduce += 1
+            e += 1
+    if reduce % qiof:
+        accQ = [_reduce(a, Ql) for a in accQ]
+    if LP and reduce % piof:
+        accP = [_reduce(a, Pl) for a in accP]
+    out = []
+    for c in (0, 1):
+        if is_ntt:
+            out.append(orc.moddown_qp_to_q_ntt(accQ[c], accP[c], Ql, Pl, srQ, srP) if LP else accQ[c])
+        else:
+            q = np.stack([orc.intt(accQ[c][i], srQ[i]) for i in range(LQ)])
+            if LP:
+                p = np.stack([orc.intt(accP[c][j], srP[j]) for j in range(LP)])
+                q = orc.moddown_qp_to_q(q, p, Ql, Pl)
+            out.append(q)
+    return out

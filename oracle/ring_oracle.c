@@ -620,6 +620,25 @@ void orc_automorphism_ntt(const uint64_t* in, uint64_t* out, int N, uint64_t gal
   for (int j = 0; j < N; j++) out[j] = add_lazy ? out[j] + in[idx[j]] : in[idx[j]];
   free(idx);
 }
+/* NTT-domain automorphism with an explicit NthRoot (4N for conjugate-invariant rings, Ring.NthRoot() ring/ring.go:178-183) */
+void orc_automorphism_ntt_nthroot(const uint64_t* in, uint64_t* out, int N, uint64_t nthroot, uint64_t gal, int add_lazy) {
+  u64* idx = (u64*)malloc((size_t)N * 8);
+  orc_automorphism_ntt_index(N, nthroot, gal, idx);
+  for (int j = 0; j < N; j++) out[j] = add_lazy ? out[j] + in[idx[j]] : in[idx[j]];      /* caller guarantees idx[j] < N */
+  free(idx);
+}
+/* coefficient-domain automorphism on a conjugate-invariant ring (:131-156) */
+void orc_automorphism_ci(const uint64_t* in, uint64_t* out, int N, uint64_t gal, uint64_t q) {
+  u64 n = (u64)N, mask = 2 * n - 1; int logN = 0; while (((u64)1 << logN) <= mask) logN++;   /* bits.Len64(mask) */
+  for (u64 i = 0; i < 2 * n; i++) {
+    u64 raw = i * gal, index = raw & mask, tmp = (raw >> logN) & 1;
+    if (index < n) {
+      u64 idx = i;
+      if (idx >= n) { idx = 2 * n - idx; tmp ^= 1; }
+      out[index] = in[idx] * (tmp ^ 1) | (q - in[idx]) * tmp;
+    }
+  }
+}
 void orc_automorphism(const uint64_t* in, uint64_t* out, int N, uint64_t gal, uint64_t q) { /* :162-175 */
   u64 mask = (u64)N - 1; int logN = 0; while (((u64)1 << logN) < (u64)N) logN++;
   for (u64 i = 0; i < (u64)N; i++) {

@@ -121,6 +121,8 @@ int  orc_ntt3n_forward_fast(const uint64_t* p1, uint64_t* p2, int N, uint64_t q,
 int  orc_ntt3n_backward_fast(const uint64_t* p1, uint64_t* p2, int N, uint64_t q, uint64_t omega);
 
 /* ---- timing helper for bench.py's cpu_baseline leg: runs `reps` forward NTTs of `nlimbs` limbs, returns seconds */
+void orc_automorphism_ntt_nthroot(const uint64_t* in, uint64_t* out, int N, uint64_t nthroot, uint64_t gal, int add_lazy);
+void orc_automorphism_ci(const uint64_t* in, uint64_t* out, int N, uint64_t gal, uint64_t q);
 double orc_time_ntt_forward(int N, int nlimbs, const uint64_t* moduli, int reps, int threads);
 double orc_time_ntt_forward_polys(int N, int nlimbs, const uint64_t* moduli, int npolys, int reps, int threads);
 

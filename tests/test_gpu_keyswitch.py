@@ -42,3 +42,70 @@ def test_gadget_product_vs_oracle_composition(rh, oracle, N, nq, np_, levelQ, le
         assert np.array_equal(g0[k], e0)
         assert np.array_equal(g1[k], e1)
     be.close(); rq.close(); rp.close()
+
+
+def _rand_key(rng, rows, mods, N):
+    return np.stack([np.stack([np.stack([rng.integers(0, 1 << 62, size=N, dtype=np.uint64) % np.uint64(q) for q in mods]) for _ in range(2)]) for _ in range(rows)])
+
+
+@pytest.mark.parametrize("N,nq,np_,levelQ", [(64, 6, 2, 5), (4096, 5, 2, 4), (8192, 5, 3, 3)])
+def test_gadget_product_coefficient_domain_ciphertext(rh, oracle, N, nq, np_, levelQ):
+    # ct.IsNTT == false (core/rlwe/evaluator_gadget_product.go:114-118, :139-143; ModDown INTT -> INTT :62-66), levelP >= 1
+    from oracle import compose
+    Q, P = QI60[:nq], PI60[:np_]
+    rq, rp = rh.Ring(N, Q), rh.Ring(N, P)
+    rng = np.random.default_rng(N + nq)
+    levelP = np_ - 1
+    beta = (nq - 1 + np_) // np_
+    evkQ, evkP = _rand_key(rng, beta, Q, N), _rand_key(rng, beta, P, N)
+    LQ = levelQ + 1
+    cx = np.stack([np.stack([rng.integers(0, 1 << 62, size=N, dtype=np.uint64) % np.uint64(q) for q in Q[:LQ]]) for _ in range(2)])
+    ev = rh.rlwe.Evaluator(rq, rp)
+    gct = rh.rlwe.GadgetCiphertext(rq, rp, evkQ, evkP)
+    rl = rq.AtLevel(levelQ)
+    ct = rh.Ciphertext([rl.NewPoly(2), rl.NewPoly(2)], is_ntt=False)
+    ev.GadgetProduct(levelQ, rh.DevicePoly.from_numpy(rl, cx), gct, ct)
+    g0, g1 = ct.Value[0].numpy(), ct.Value[1].numpy()
+    for k in range(2):
+        e0, e1 = compose.gadget_product_coeff(N, Q, P, levelQ, levelP, cx[k], evkQ, evkP)
+        assert np.array_equal(g0[k], e0) and np.array_equal(g1[k], e1)
+    ev.close(); rq.close(); rp.close()
+
+
+@pytest.mark.parametrize("N,nq,levelQ,levelP,pw2,is_ntt", [
+    (64, 4, 3, 0, 0, True), (4096, 4, 2, 0, 0, True), (4096, 3, 2, 0, 0, False),          # one P modulus, RNS digits only
+    (64, 3, 2, 0, 16, True), (8192, 3, 2, 0, 20, True), (4096, 3, 1, 0, 31, False),          # ... with a power-of-two decomposition
+    (64, 3, 2, -1, 16, True), (4096, 3, 2, -1, 24, True), (8192, 2, 1, -1, 20, False)])      # no P modulus at all
+def test_gadget_product_single_p_and_bit_decomposition(rh, oracle, N, nq, levelQ, levelP, pw2, is_ntt):
+    # gadgetProductSinglePAndBitDecompLazy (core/rlwe/evaluator_gadget_product.go:190-324) + ModDown (:33-98) vs the oracle composition
+    from oracle import compose
+    Q, P = QI60[:nq], PI60[:1]
+    rq = rh.Ring(N, Q)
+    rp = rh.Ring(N, P) if levelP == 0 else None
+    rng = np.random.default_rng(N + nq * 7 + pw2)
+    dpl = [(61 + pw2 - 1) // pw2 for _ in Q] if pw2 else None      # BaseTwoDecompositionVectorSize: ceil(log q_i / pw2) (params.go:615-633)
+    rows = sum(dpl) if pw2 else nq
+    evkQ = _rand_key(rng, rows, Q, N)
+    evkP = _rand_key(rng, rows, P, N) if levelP == 0 else None
+    LQ = levelQ + 1
+    cx = np.stack([np.stack([rng.integers(0, 1 << 62, size=N, dtype=np.uint64) % np.uint64(q) for q in Q[:LQ]]) for _ in range(2)])
+    ev = rh.rlwe.Evaluator(rq, rp)
+    gct = rh.rlwe.GadgetCiphertext(rq, rp, evkQ, evkP, BaseTwoDecomposition=pw2, digits_per_limb=dpl)
+    assert gct.LevelP() == levelP
+    rl = rq.AtLevel(levelQ)
+    ct = rh.Ciphertext([rl.NewPoly(2), rl.NewPoly(2)], is_ntt=is_ntt)
+    pcx = rh.DevicePoly.from_numpy(rl, cx)
+    ev.GadgetProduct(levelQ, pcx, gct, ct)
+    g0, g1 = ct.Value[0].numpy(), ct.Value[1].numpy()
+    for k in range(2):
+        e0, e1 = compose.gadget_product_single_p(N, Q, P if levelP == 0 else [], levelQ, levelP, cx[k], is_ntt, pw2, dpl, evkQ, evkP)
+        assert np.array_equal(g0[k], e0), (k, 0)
+        assert np.array_equal(g1[k], e1), (k, 1)
+    assert np.array_equal(pcx.numpy(), cx)
+    if pw2 == 0 and levelP == 0:                                    # no P modulus and no power-of-two decomposition: refused (the reference's call degenerates)
+        bad = rh.rlwe.GadgetCiphertext(rq, None, evkQ, None)
+        with pytest.raises(rh.RingHipError):
+            rh.rlwe.Evaluator(rq, None).GadgetProduct(levelQ, pcx, bad, ct)
+    ev.close(); rq.close()
+    if rp is not None:
+        rp.close()
