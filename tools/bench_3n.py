@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""3N transform timing: bench_3n.py <log2(N/3)> <limbs> <batch>   (profiling aid: rocprofv3 --kernel-trace --stats -- python3 tools/bench_3n.py 13 1 1024)"""
+"""3N transform timing: bench_3n.py <log2(N/3)> <limbs> <batch> [block_order 0/1]   (profiling aid: rocprofv3 --kernel-trace --stats -- python3 tools/bench_3n.py 13 1 1024)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -17,7 +17,7 @@ while len(mods) < L:
 dev = torch.device("cuda", 0); stream = torch.cuda.current_stream()
 ring = rh.Ring(N, mods, kind=rh.Matrix3N); ring.set_stream(stream.cuda_stream)
 if len(sys.argv) > 4:
-    ring.set_tuning("perm_inv_shape", int(sys.argv[4]))
+    ring.set_tuning("ntt3n_block_order", int(sys.argv[4]))     # 1: device NTT domain in block order (no permutation pass)
 qs = torch.tensor(mods, dtype=torch.int64, device=dev).view(1, L, 1)
 x = torch.randint(0, 1 << 62, (B, L, N), dtype=torch.int64, device=dev) % qs
 p = rh.DevicePoly.from_torch(ring, x)
