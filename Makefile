@@ -5,7 +5,7 @@ PKG   := matrix-fhe-lattigo_amd
 CSRC  := $(PKG)/csrc
 LIB   := $(PKG)/lib/libringhip.so
 SRCS  := $(CSRC)/engine.hip $(CSRC)/ntt3n.hip $(CSRC)/bext.hip $(CSRC)/rescale.hip $(CSRC)/keyswitch.hip $(CSRC)/kshard.hip $(CSRC)/automorphism.hip
-HDRS  := $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.inc) $(wildcard $(CSRC)/*.hpp) $(wildcard include/*.h)
+HDRS  := $(wildcard $(CSRC)/*.hip.hpp) $(wildcard $(CSRC)/*.inc) $(wildcard $(CSRC)/*.hpp) $(wildcard include/*.h)
 
 all: $(LIB) oracle tests/cpp/test_ring_cpp
 

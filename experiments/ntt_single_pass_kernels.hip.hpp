@@ -1,6 +1,6 @@
-// experiments/ntt_single_pass_kernels.cuh -- forward-NTT variants that were measured on MI355X in round 1 and lost
+// experiments/ntt_single_pass_kernels.hip.hpp -- forward-NTT variants that were measured on MI355X in round 1 and lost
 // ("what did not work").  NOT part of libringhip.so and not built by the Makefile: kept as source so the
-// measurements can be repeated.  They compiled against csrc/ntt_kernels_asm.cuh at commit 27fe980 (which also carried the
+// measurements can be repeated.  They compiled against csrc/ntt_kernels_asm.hip.hpp at commit 27fe980 (which also carried the
 // sc1-load and pre-loaded variants of the generated tile body, tools/gen_tile_asm.py at that commit) and were driven by the
 // tuning keys persistent / cluster / prefetch / cols2 / order_mix of that commit's rh_ring_set_tuning.
 //

@@ -11,9 +11,9 @@
 #include <new>
 #include "../../include/ringhip.h"
 #include "hostmath.hpp"
-#include "ntt_kernels.cuh"
-#include "vec_kernels.cuh"
-#include "ntt_kernels_asm.cuh"
+#include "ntt_kernels.hip.hpp"
+#include "vec_kernels.hip.hpp"
+#include "ntt_kernels_asm.hip.hpp"
 #include "engine_internal.hpp"
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -39,7 +39,7 @@ RhCallScope::~RhCallScope() { tl_stream = prev_st; tl_has_stream = prev_has; tl_
 extern "C" int rh_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
 // ------------------------------------------------------------------------------------------------ table layout
-// natural order -> the order ntt_fwd_tile / ntt_inv_tile read (ntt_kernels.cuh): per 4096-tile T
+// natural order -> the order ntt_fwd_tile / ntt_inv_tile read (ntt_kernels.hip.hpp): per 4096-tile T
 //   [slot]                 round A, slot = (2^u - 1) + g          <- nat[2^(S1+u)   + T*2^u     + g]
 //   [16 + slot*16 + hi4]   round B                                <- nat[2^(S1+4+u) + T*2^(4+u) + (hi4<<u) + g]
 //   [256 + slot*256 + tid] round C                                <- nat[2^(S1+8+u) + T*2^(8+u) + (tid<<u) + g]

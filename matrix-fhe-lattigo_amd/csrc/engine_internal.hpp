@@ -5,7 +5,7 @@
 #include <mutex>
 #include <cstdint>
 #include "../../include/ringhip.h"
-#include "ring_types.cuh"
+#include "ring_types.hip.hpp"
 
 #define RH_MAX_LIMBS 64
 
@@ -47,7 +47,7 @@ struct rh_ring {
   int fuse3n = 1;                 // 3N rings, b = 1: split + radix-3 layer fused with the sub-transforms' column stages
   int block_order3n = 0;          // 3N rings: device-batched NTT domain kept in block order (ntt3n.hip), no permutation pass
   int asm_cols = 1;               // N = 2^16: hand-scheduled column stages (fwd_cols16_asm_body) in place of the C++ body
-  bool asm_tile = true;           // forward tile kernel: hand-scheduled body (ntt_kernels_asm.cuh) vs the C++ one
+  bool asm_tile = true;           // forward tile kernel: hand-scheduled body (ntt_kernels_asm.hip.hpp) vs the C++ one
   bool inv_scale = true;          // false: inverse leaves values < 4q without the N^-1 factor (3N sub-transform)
   int auto_span_rows = 2048;      // chunk_polys = -1: span size of the fused pipeline in (poly, limb) rows
   int chunk_polys = -1;           // -1 = auto (128-poly spans for batches >= 256), 0 = whole batch in two launches, >0 = polys per span

@@ -1,4 +1,4 @@
-// modarith.cuh -- 64-bit modular arithmetic for gfx950 device code.
+// modarith.hip.hpp -- 64-bit modular arithmetic for gfx950 device code.
 //
 // Two families:
 //  (1) the reference's primitives, formula for formula (ring/modular_reduction.go): used wherever the result is not

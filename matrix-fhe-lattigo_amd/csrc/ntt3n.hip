@@ -8,7 +8,7 @@
 //     X^(3m) - w^e      = prod_{k<3} (X^m - w^(e/3 + kN))                              b radix-3 layers
 //     X^(2m) - w^e      = (X^m - w^(e/2))(X^m - w^(e/2 + 3N/2))                        a-1 radix-2 layers
 // After the split and radix-3 layers a limb is nb = 2*3^b independent twisted power-of-two transforms of length
-// n2 = 2^(a-1); they run on the SAME radix-2 kernels as the negacyclic NTT (ntt_kernels.cuh) by presenting each
+// n2 = 2^(a-1); they run on the SAME radix-2 kernels as the negacyclic NTT (ntt_kernels.hip.hpp) by presenting each
 // (limb, block) as a "virtual limb" of a sub-ring with its own twiddle table.  Slot j of block c holds the value at
 // omega^e, e = e0_c + 2*3^(b+1)*bitrev(j); its rank among the totatives is nb*bitrev(j) + rank(e0_c), which is the
 // final permutation (ntt3n_perm_*).
@@ -266,7 +266,7 @@ ntt3n_pre_cols_fwd(const u64* in, u64* out, int N, const tw2* __restrict__ r3, i
       for (int g = 0; g < (1 << st); ++g) {
         const tw2 w = tw[(1 << st) + g];
 #pragma unroll
-        for (int e = 0; e < h; ++e) {                      // ShoupPolicy::fwd (ntt_kernels.cuh)
+        for (int e = 0; e < h; ++e) {                      // ShoupPolicy::fwd (ntt_kernels.hip.hpp)
           u64& U = x[j][g * 2 * h + e]; u64& V = x[j][g * 2 * h + e + h];
           const u64 u = csub(U, q4);
           const u64 X = shoup_mul_acc(V, w.w, w.wp, c.nq, u);

@@ -1,4 +1,4 @@
-// ntt_kernels.cuh -- negacyclic NTT / INTT over Z_q[X]/(X^N+1) for gfx950.
+// ntt_kernels.hip.hpp -- negacyclic NTT / INTT over Z_q[X]/(X^N+1) for gfx950.
 //
 // Replaces ring/ntt.go: nttCoreLazy (:209-552), inttCoreLazy (:554-714) and the NTTStandard*/INTTStandard* wrappers
 // (:174-206) of the reference.  Data layout in HBM: (poly, limb, coefficient) contiguous u64, one launch covers a
@@ -16,15 +16,15 @@
 //   inverse:  the mirror image (K2 first, then K1 with N^-1 folded into the last stage's twiddles).
 // N < 4096: one workgroup per limb, all stages in LDS (ntt_small_*).
 //
-// Arithmetic policies (modarith.cuh):
+// Arithmetic policies (modarith.hip.hpp):
 //   ShoupPolicy  -- fast path; values kept < 8q, outputs canonical.  Used by Forward, Backward, BackwardLazy
 //                   (all canonical in the reference for N >= 16).
 //   MontPolicy   -- the reference's MRedLazy butterfly with its reduce schedule (:315-318, :500-517); reproduces
 //                   ForwardLazy's exact representatives.
 #pragma once
-#include "modarith.cuh"
+#include "modarith.hip.hpp"
 
-#include "ring_types.cuh"
+#include "ring_types.hip.hpp"
 
 // ---------------------------------------------------------------------------------------------------------------
 // policies

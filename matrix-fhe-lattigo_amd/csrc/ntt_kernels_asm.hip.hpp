@@ -1,12 +1,12 @@
-// ntt_kernels_asm.cuh -- forward 4096-tile NTT kernel with a hand-scheduled gfx950 body (tools/gen_tile_asm.py).
+// ntt_kernels_asm.hip.hpp -- forward 4096-tile NTT kernel with a hand-scheduled gfx950 body (tools/gen_tile_asm.py).
 //
-// Same contract as ntt_fwd_tile<ShoupPolicy> with canonical output (ntt_kernels.cuh): last 12 stages of the
+// Same contract as ntt_fwd_tile<ShoupPolicy> with canonical output (ntt_kernels.hip.hpp): last 12 stages of the
 // forward negacyclic NTT (ring/ntt.go:209-552 + reducevec) on one contiguous 4096-coefficient tile.  The C++ wrapper
 // resolves (poly, limb, tile), loads the per-limb constants through the scalar cache and hands everything to one asm
 // statement that owns v0..v123, s36..s99 and vcc.
 #pragma once
-#include "ring_types.cuh"
-#include "ntt_kernels.cuh"
+#include "ring_types.hip.hpp"
+#include "ntt_kernels.hip.hpp"
 #include "ntt_tile_asm.inc"
 
 // wave-uniform values the compiler cannot prove uniform (loop-carried item index of the persistent kernel) -> SGPRs
@@ -80,7 +80,7 @@ ntt_fwd_tile_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const Lim
   fwd_tile_asm_body(lds, blockIdx.x, in, out, twk, consts, L, logN, npoly, Ls);
 }
 
-// Forward tile stages with the subtract-multiply epilogue, hand-scheduled: same contract as ntt_fwd_tile_submul (ntt_kernels.cuh),
+// Forward tile stages with the subtract-multiply epilogue, hand-scheduled: same contract as ntt_fwd_tile_submul (ntt_kernels.hip.hpp),
 //   out = [z +] MRed(2q - y + NTT(in), s_limb),
 // with MRed by the wave-uniform scalar done as a Shoup multiply by s*2^-64 mod q (sw / sp: that constant and its quotient, per limb).
 struct LimbShoup { u64 w[RH_MAX_LIMBS_K], wp[RH_MAX_LIMBS_K]; };

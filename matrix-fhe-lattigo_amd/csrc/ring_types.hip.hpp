@@ -1,6 +1,6 @@
-// ring_types.cuh -- per-limb constant block, twiddle pair and tile geometry shared by host and device code.
+// ring_types.hip.hpp -- per-limb constant block, twiddle pair and tile geometry shared by host and device code.
 #pragma once
-#include "modarith.cuh"
+#include "modarith.hip.hpp"
 
 #define RH_MAX_LIMBS_K 64        // = RH_MAX_LIMBS (engine_internal.hpp): per-limb scalars passed to kernels by value
 struct LimbConsts {

@@ -1,12 +1,12 @@
-// vec_kernels.cuh -- the element-wise kernel family of ring/vec_ops.go on (poly, limb, coefficient) blocks.
+// vec_kernels.hip.hpp -- the element-wise kernel family of ring/vec_ops.go on (poly, limb, coefficient) blocks.
 //
 // One template instantiation per opcode (include/ringhip_ops.h); each thread moves 16 B per operand per step
 // (two coefficients), rows (= one limb of one poly) are mapped to blockIdx.y so the per-limb constants are
 // wave-uniform.  Every formula is the reference's, including the NON-reduction of the lazy forms, so results are
 // bit-identical.  HBM-bound: 8*(operands)*N*L bytes per poly.
 #pragma once
-#include "modarith.cuh"
-#include "ntt_kernels.cuh"
+#include "modarith.hip.hpp"
+#include "ntt_kernels.hip.hpp"
 #include "../../include/ringhip_ops.h"
 
 template <int OP>

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generates matrix-fhe-lattigo_amd/csrc/ntt_tile_asm.inc: the body of the forward 4096-tile NTT kernel (the metric's
-dominant kernel) as ONE hand-scheduled gfx950 assembly block, wrapped by ntt_fwd_tile_asm in ntt_kernels_asm.cuh.
+dominant kernel) as ONE hand-scheduled gfx950 assembly block, wrapped by ntt_fwd_tile_asm in ntt_kernels_asm.hip.hpp.
 
 Why assembly: the butterfly is VALU-issue bound and hipcc's code for it is ~21 slow + 3 fast
 instructions; the sequence below is 16 slow + 2 fast, uses no VCC in the hot chain, and fits 4 waves/SIMD.
@@ -12,9 +12,9 @@ Butterfly (Shoup form, r = V*w - Q'*q in [0,4q), values < 8q), registers are eve
    X  = u + (h<<32) + V0*w0 + Q0*nq0                                     (1 fast + 2 slow)
    Y  = (2u + 4q) - X                                                    (1 + 2 slow)
 
-Same math as ShoupPolicy::fwd / shoup_mul_acc (modarith.cuh); outputs are canonical so results are bit-identical to
+Same math as ShoupPolicy::fwd / shoup_mul_acc (modarith.hip.hpp); outputs are canonical so results are bit-identical to
 the C++ kernel and to the reference's Forward.  Layouts (LDS padding j + j/16, kernel-order twiddles) as in
-ntt_kernels.cuh: fwd_tile_body.
+ntt_kernels.hip.hpp: fwd_tile_body.
 """
 import os
 import sys
@@ -100,7 +100,7 @@ def butterfly_steps(u, v, w, t, sgpr_tw=None):
 
 def inv_butterfly_steps(u, v, w, t, sgpr_tw=None):
     """inverse (Gentleman-Sande) butterfly, U,V < 4q:  X = csub(U+V, 4q) -> U ;  Y = (U + 4q - V)*w in [0,4q) -> V.
-    Same math as ShoupPolicy::inv (ntt_kernels.cuh).  17 slow + 2 fast."""
+    Same math as ShoupPolicy::inv (ntt_kernels.hip.hpp).  17 slow + 2 fast."""
     if sgpr_tw is None:
         w0, w1, p0, p1 = "v%d" % w, "v%d" % (w + 1), "v%d" % (w + 2), "v%d" % (w + 3)
     else:
@@ -468,7 +468,7 @@ class VmTracker:
 
 
 def gen_submul_epilogue(A0, A1, A3, with_z):
-    """tail of the forward tile body with the epilogue of ntt_fwd_tile_submul (ntt_kernels.cuh):
+    """tail of the forward tile body with the epilogue of ntt_fwd_tile_submul (ntt_kernels.hip.hpp):
          out = [z +] MRed(2q - y + NTT(x), s)        (ring/basis_extension.go:255-257, ring/scaling.go:120-124; z: the ring.Add that follows)
     MRed by the wave-uniform scalar s is a Shoup multiply by s*2^-64 mod q (operands sw0/sw1/sp0/sp1): the canonical result is the
     same residue.  The transform's values are only brought below 4q before the subtraction (one conditional subtraction, not three).
@@ -528,7 +528,7 @@ def gen_submul_epilogue(A0, A1, A3, with_z):
 def gen_cols(S1=4):
     """Column stages for N = 2^(12+S1), S1 = 2..4: x[k] = in[c + 4096 k], k < R = 2^S1, one radix-R register round with the
     wave-uniform twiddles tw[1..R-1] (natural order: stage s, group g -> tw[2^s + g] = slot 2^s - 1 + g), outputs < 8q
-    stored back.  Same contract as fwd_cols_body<ShoupPolicy, S1> (ntt_kernels.cuh); operands: tid, pin, pout (row base +
+    stored back.  Same contract as fwd_cols_body<ShoupPolicy, S1> (ntt_kernels.hip.hpp); operands: tid, pin, pout (row base +
     256*cb columns, bytes), tw (limb's natural-order table), nq0, nq1, nq4, q4."""
     R = 1 << S1
     if PRIO in (1, 2):
@@ -591,7 +591,7 @@ def csub_steps(x, const_name, t):
 
 
 def scaled_last_butterfly_steps(u, v, t):
-    """last inverse stage with N^-1 folded in (inv_cols_body, ntt_kernels.cuh): U, V < 4q ->
+    """last inverse stage with N^-1 folded in (inv_cols_body, ntt_kernels.hip.hpp): U, V < 4q ->
     X = canon((U + V) * ninv) -> U,  Y = canon((U + 4q - V) * (psi * ninv)) -> V, both in [0, q)."""
     U, V = pair(u), pair(v)
     ul, uh, vl, vh = "v%d" % u, "v%d" % (u + 1), "v%d" % v, "v%d" % (v + 1)
