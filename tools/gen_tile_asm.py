@@ -19,6 +19,7 @@ ntt_kernels.hip.hpp: fwd_tile_body.
 import os
 import sys
 
+EXP = int(os.environ.get("RH_ASM_EXP", "0"))     # TIMING EXPERIMENTS ONLY (wrong results): 1 no LDS exchanges, 2 no round-B/C twiddle loads, 4 no final reduction, 8 no barriers
 PRIO = int(os.environ.get("RH_ASM_PRIO", "0"))   # s_setprio around the load-issue and store phases (0 = off, for A/B runs)
 out = []
 
@@ -662,6 +663,21 @@ def render(name, lines):
 
 gen()
 fwd = list(out)
+if EXP:
+    keep, seen_epi = [], False
+    for l in fwd:
+        if "canonical reduction" in l:
+            seen_epi = True
+        if (EXP & 1) and (l.startswith("ds_") or l == "s_barrier"):
+            continue
+        if (EXP & 8) and l == "s_barrier":
+            continue
+        if (EXP & 2) and l.startswith("global_load_dwordx4"):
+            continue
+        if (EXP & 4) and seen_epi and (l.startswith("v_lshl_add_u64") or l.startswith("v_ashrrev") or l.startswith("v_bfi")):
+            continue
+        keep.append(l)
+    fwd = keep
 del out[:]
 cols, cols_inv = {}, {}
 for s1 in (2, 3, 4):
