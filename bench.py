@@ -70,12 +70,34 @@ def spawn_ranks(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # relay rank 0's line; if any rank dies, stop the others (their own PIDs) instead of waiting in a collective for the time-out
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while True:
+        rcs = [p.poll() for p in procs]
+        if any(rc not in (None, 0) for rc in rcs):
+            failed = True
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
-    if any(rcs):
-        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+    if failed:
+        sys.stderr.write("bench.py: rank exit codes %s\n" % [p.returncode for p in procs])
         sys.exit(1)
 
 
