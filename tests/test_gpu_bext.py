@@ -118,3 +118,41 @@ def test_config5_shape_keyswitch_digit(rh, oracle):
         eq, ep = oracle.decompose_and_split(23, 5, 6, digit, a[0], Q, P)
         assert np.array_equal(oq.numpy()[0], eq) and np.array_equal(op.numpy()[0], ep)
     be.close(); rq.close(); rp.close()
+
+
+@pytest.mark.parametrize("nq,np_", [(6, 3), (2, 2), (14, 6)])
+def test_adversarial_values_for_the_floating_point_v(rh, oracle, nq, np_):
+    # reconstructRNS decides v = trunc(sum_i float64(y_i) / float64(q_i)) in IEEE double with sequential adds
+    # (ring/basis_extension.go:576-593).  For a centred value X the exact sum is an integer + (X + Q/2)/Q, so values at the ends of
+    # the centred range (X = +-(Q-1)/2, +-(Q/2 - small)) and the values whose shifted form is 0, 1, Q-1 ... put the sum within one
+    # rounding error of an integer: v then hinges on the exact rounding of every division and addition (at the very top of the range
+    # the reference's sum rounds up and the result is X - Q: tests/test_oracle_bext.py).  GPU and oracle (gcc, -ffp-contract=off)
+    # must agree bit for bit on all of them, including the lazy (non-canonical) outputs and the reference's off-by-Q band.
+    N = 256
+    Q, P, rq, rp, be = make(rh, N, nq, np_)
+    bigQ = prod(Q)
+    half = bigQ // 2
+    specials = [0, 1, -1, 2, -2, half, -half, half - 1, -(half - 1), half - 2, half // 2, -(half // 2), 3 * (half // 4)]
+    specials += [s * (1 << k) for k in (10, 40, 61, 100) for s in (1, -1) if (1 << k) < half]
+    specials += [half - (1 << k) for k in (1, 20, 50) if (1 << k) < half] + [-(half - (1 << k)) for k in (1, 20, 50) if (1 << k) < half]
+    rng = np.random.default_rng(nq * 31 + np_)
+    vals = [specials[i % len(specials)] if i < 2 * len(specials) else centered_randoms(rng, bigQ, 1)[0] for i in range(N)]
+    a = np.stack([rns(vals, Q)])
+    pa = rh.DevicePoly.from_numpy(rq, a)
+    pp = rh.DevicePoly(rp, 1, np_)
+    be.ModUpQtoP(nq - 1, np_ - 1, pa, pp)
+    got = pp.numpy()[0]
+    assert np.array_equal(got, oracle.modup_centered(a[0], Q, P))
+    band = half - (half >> 40)
+    for j, p in enumerate(P):                                         # and the values are right (outside the bands), not merely equal
+        assert all(int(x) % p == v % p for x, v in zip(got[j], vals) if abs(v) <= band)
+    # the digit decomposition of the key switch on the same coefficients (centred reconstruction with the raw add, :504-548)
+    if nq >= 4:
+        alpha = np_
+        oq, op_ = rh.DevicePoly(rq, 1, nq), rh.DevicePoly(rp, 1, np_)
+        be.DecomposeAndSplit(nq - 1, np_ - 1, alpha, 0, pa, oq, op_)
+        eq, ep = oracle.decompose_and_split(nq - 1, np_ - 1, alpha, 0, a[0], Q, P)
+        st, ed = 0, min(alpha, nq)
+        keep = [i for i in range(nq) if not (st <= i < ed)]
+        assert np.array_equal(oq.numpy()[0][keep], eq[keep]) and np.array_equal(op_.numpy()[0], ep)
+    be.close(); rq.close(); rp.close()

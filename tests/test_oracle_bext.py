@@ -97,3 +97,29 @@ def test_decompose_and_split_vs_bigint(oracle, levelQ, levelP, nbPi, digit):
         assert got == [c % Qall[j] for c in cent], j
     for j in range(levelP + 1):
         assert [int(x) % Pall[j] for x in op[j]] == [c % Pall[j] for c in cent], j
+
+
+@pytest.mark.parametrize("nq,np_", [(6, 3), (2, 2), (14, 6), (24, 6)])
+def test_modup_exact_at_the_ends_of_the_centred_range(oracle, nq, np_):
+    # values for which sum_i y_i/q_i is within a rounding error of an integer (see tests/test_gpu_bext.py).  The reference's
+    # extension (+ Q/2 before, - Q/2 after: ring/basis_extension.go:188-217) is exact except in bands of relative width < 2^-40 at
+    # the two ENDS of the centred range, where the double sum falls on the wrong side of an integer and v is off by one: there the
+    # result is X -+ Q instead of X (the algorithm's approximation, which random test values never meet).  The restatement must show
+    # exactly that behaviour: exact everywhere else, off by one multiple of Q (and nothing else) in the bands.
+    from conftest import QI60, PI60
+    Q, P = QI60[:nq], PI60[:np_]
+    bigQ = prod(Q)
+    half = bigQ // 2
+    vals = [0, 1, -1, 2, -2, half, -half, half - 1, -(half - 1), half - 2, half // 2, -(half // 2)]
+    vals += [s * (1 << k) for k in (10, 40, 61, 100) for s in (1, -1) if (1 << k) < half]
+    vals += [half - (1 << k) for k in (1, 20, 50) if (1 << k) < half]
+    a = rns(vals, Q)
+    out = oracle.modup_centered(a, Q, P)
+    band = half - (half >> 40)          # |X| beyond it: the sum of up to 32 rounded quotients can fall on the wrong side of the integer
+    for j, p in enumerate(P):
+        for x, v in zip(out[j], vals):
+            if abs(v) <= band:
+                assert int(x) % p == v % p, v
+            else:
+                assert int(x) % p in (v % p, (v - bigQ) % p, (v + bigQ) % p), v
+    assert any(int(out[0][i]) % P[0] != vals[i] % P[0] for i in range(len(vals)) if abs(vals[i]) > band)   # the band is real
