@@ -286,6 +286,15 @@ func (d *DeviceRing) Download(dst ring.Poly, src *DevPoly, k int) {
 // NTT / INTT / MulCoeffsMontgomery ... mirror ring.Ring's methods on device blocks (level = limbs-1).
 func (d *DeviceRing) NTT(p1, p2 *DevPoly)  { d.must(C.rh_ring_ntt(d.h, p1.ptr, p2.ptr, C.int(p1.npoly), C.int(p1.limbs-1), 0)) }
 func (d *DeviceRing) INTT(p1, p2 *DevPoly) { d.must(C.rh_ring_intt(d.h, p1.ptr, p2.ptr, C.int(p1.npoly), C.int(p1.limbs-1), 0)) }
+
+// NTTAtLevel / INTTAtLevel: ring.AtLevel(level).NTT on blocks that carry more limbs than `level`+1 (max-level polys and
+// buffers, ring/ring.go:192-213): limbs 0..level of every poly are transformed, the others untouched.
+func (d *DeviceRing) NTTAtLevel(level int, p1, p2 *DevPoly) {
+	d.must(C.rh_ring_ntt_rows(d.h, p1.ptr, C.int(p1.limbs), p2.ptr, C.int(p2.limbs), C.int(p1.npoly), C.int(level), 0))
+}
+func (d *DeviceRing) INTTAtLevel(level int, p1, p2 *DevPoly) {
+	d.must(C.rh_ring_intt_rows(d.h, p1.ptr, C.int(p1.limbs), p2.ptr, C.int(p2.limbs), C.int(p1.npoly), C.int(level), 0))
+}
 func (d *DeviceRing) MulCoeffsMontgomery(p1, p2, p3 *DevPoly) {
 	d.must(C.rh_ring_vec_op(d.h, C.RH_OP_MUL_MONT, p1.ptr, p2.ptr, p3.ptr, C.int(p3.npoly), C.int(p3.limbs-1), nil, nil))
 }

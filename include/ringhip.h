@@ -8,7 +8,8 @@
  * ring/ring.go:321-331).  The cgo binding a maintainer adds is shown in INTEGRATION.md.
  *
  * Data model.  A "limb" is N uint64 residues; device polynomials are (poly, limb, coefficient) contiguous blocks:
- * word index ((poly*L)+limb)*N + j.  This replaces Poly.Coeffs [][]uint64 (ring/poly.go:13-24) for device-resident
+ * word index ((poly*L)+limb)*N + j, with L = level+1 limbs per poly for the level a call names (the *_rows entry points take
+ * blocks with more limbs per poly: views at a lower level of max-level polys).  This replaces Poly.Coeffs [][]uint64 (ring/poly.go:13-24) for device-resident
  * data; host-pointer entry points take one limb at a time exactly like the NumberTheoreticTransformer interface.
  */
 #ifndef RINGHIP_H
@@ -108,6 +109,13 @@ int rh_ntt_backward_lazy(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2)
 int rh_ring_ntt(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int lazy);
 int rh_ring_intt(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int lazy);
 
+/* The same on blocks that carry MORE limbs per poly than the level they are used at (in_rows / out_rows limbs per poly, each
+ * >= level+1): ring.AtLevel(level) on max-level polys and buffers (ring/ring.go:192-213), the idiomatic use inside the reference's
+ * evaluators.  Limbs 0..level of every poly are transformed, the others are untouched.  With rows == level+1 this IS rh_ring_ntt /
+ * rh_ring_intt; otherwise the call runs poly by poly (correct, but not the throughput path). */
+int rh_ring_ntt_rows(rh_ring* r, const uint64_t* in_dev, int in_rows, uint64_t* out_dev, int out_rows, int npoly, int level, int lazy);
+int rh_ring_intt_rows(rh_ring* r, const uint64_t* in_dev, int in_rows, uint64_t* out_dev, int out_rows, int npoly, int level, int lazy);
+
 /* INTT of a pointwise product, NTT-domain inputs: out = INTT(a . b), the values of ring.MForm(a, t); ring.MulCoeffsMontgomery(t, b, c);
  * ring.INTT(c, c) (the degree-0 part of ckks mulRelin, schemes/ckks/evaluator.go:821-834, and BASELINE config 3) -- canonical, hence
  * bit-identical -- with the product formed on load by the inverse transform's first kernel: 24 bytes per coefficient less traffic
@@ -143,6 +151,10 @@ int rh_ring_set_tuning(rh_ring* r, const char* key, long value);
  * MulRNSScalarMontgomery (ring/operations.go).  Asynchronous. */
 int rh_ring_vec_op(rh_ring* r, int opcode, const uint64_t* p1_dev, const uint64_t* p2_dev, uint64_t* p3_dev, int npoly,
                    int level, const uint64_t* s0_host, const uint64_t* s1_host);
+
+/* rows-per-poly form (see rh_ring_ntt_rows): every operand block with its own limb count >= level+1 */
+int rh_ring_vec_op_rows(rh_ring* r, int opcode, const uint64_t* p1_dev, int rows1, const uint64_t* p2_dev, int rows2, uint64_t* p3_dev,
+                        int rows3, int npoly, int level, const uint64_t* s0_host, const uint64_t* s1_host);
 
 /* ---- RNS rescale (ring/scaling.go): divide by the last modulus, `nb` times.  round = 0: floored, 1: rounded.
  * p0: npoly polys of level+1 limbs; p1: npoly polys of p1_rows >= level+1-nb limbs (limbs 0..level-nb are written).

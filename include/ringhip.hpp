@@ -118,14 +118,16 @@ class Ring {
   Poly NewPoly(int npoly = 1) const { return Poly(*this, npoly, level_ + 1); }
   void Sync() const { check(rh_ring_sync(h_.get())); }
 
-  void NTT(const Poly& p1, Poly& p2) const { check(rh_ring_ntt(h_.get(), p1.data(), p2.data(), p1.npoly(), level_, 0)); }
-  void NTTLazy(const Poly& p1, Poly& p2) const { check(rh_ring_ntt(h_.get(), p1.data(), p2.data(), p1.npoly(), level_, 1)); }
-  void INTT(const Poly& p1, Poly& p2) const { check(rh_ring_intt(h_.get(), p1.data(), p2.data(), p1.npoly(), level_, 0)); }
-  void INTTLazy(const Poly& p1, Poly& p2) const { check(rh_ring_intt(h_.get(), p1.data(), p2.data(), p1.npoly(), level_, 1)); }
+  // polys may carry more limbs than the view's level (AtLevel on max-level polys, ring/ring.go:192-213): the *_rows entry points
+  void NTT(const Poly& p1, Poly& p2) const { check(rh_ring_ntt_rows(h_.get(), p1.data(), p1.limbs(), p2.data(), p2.limbs(), p1.npoly(), level_, 0)); }
+  void NTTLazy(const Poly& p1, Poly& p2) const { check(rh_ring_ntt_rows(h_.get(), p1.data(), p1.limbs(), p2.data(), p2.limbs(), p1.npoly(), level_, 1)); }
+  void INTT(const Poly& p1, Poly& p2) const { check(rh_ring_intt_rows(h_.get(), p1.data(), p1.limbs(), p2.data(), p2.limbs(), p1.npoly(), level_, 0)); }
+  void INTTLazy(const Poly& p1, Poly& p2) const { check(rh_ring_intt_rows(h_.get(), p1.data(), p1.limbs(), p2.data(), p2.limbs(), p1.npoly(), level_, 1)); }
 
   // ring/operations.go -> ring/vec_ops.go
   void VecOp(int op, const Poly* p1, const Poly* p2, Poly& p3, const uint64_t* s0 = nullptr, const uint64_t* s1 = nullptr) const {
-    check(rh_ring_vec_op(h_.get(), op, p1 ? p1->data() : nullptr, p2 ? p2->data() : nullptr, p3.data(), p3.npoly(), level_, s0, s1));
+    check(rh_ring_vec_op_rows(h_.get(), op, p1 ? p1->data() : nullptr, p1 ? p1->limbs() : 0, p2 ? p2->data() : nullptr, p2 ? p2->limbs() : 0,
+                              p3.data(), p3.limbs(), p3.npoly(), level_, s0, s1));
   }
   void Add(const Poly& a, const Poly& b, Poly& c) const { VecOp(RH_OP_ADD, &a, &b, c); }
   void Sub(const Poly& a, const Poly& b, Poly& c) const { VecOp(RH_OP_SUB, &a, &b, c); }

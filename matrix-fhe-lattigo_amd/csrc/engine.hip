@@ -583,6 +583,25 @@ static int ntt_batch(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, i
 }
 extern "C" int rh_ring_ntt(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, int lazy) { return ntt_batch(r, in, out, npoly, level, false, lazy != 0); }
 extern "C" int rh_ring_intt(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, int lazy) { return ntt_batch(r, in, out, npoly, level, true, lazy != 0); }
+// ---- views at a lower level of blocks allocated with MORE limbs per poly (ring.AtLevel(level) on max-level polys and buffers,
+// ring/ring.go:192-213: the idiomatic use inside the reference's evaluators).  The batched kernels stride blocks by level+1 rows; a
+// block with `rows` > level+1 limbs per poly keeps each poly's leading limbs contiguous, so such a call runs poly by poly (npoly
+// launches of one poly each: correct, not the throughput path -- allocate batches at the level they are used at for that).
+static int ntt_rows(rh_ring* r, const uint64_t* in, int in_rows, uint64_t* out, int out_rows, int npoly, int level, bool inverse, bool lazy) {
+  if (!r) return rh_fail(RH_ERR_ARG, "ntt: null argument");
+  if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "ntt: level %d out of range [0,%d)", level, r->L);
+  if (in_rows < level + 1 || out_rows < level + 1) return rh_fail(RH_ERR_ARG, "ntt: blocks with %d / %d limbs per poly used at level %d", in_rows, out_rows, level);
+  if (in_rows == level + 1 && out_rows == level + 1) return ntt_batch(r, in, out, npoly, level, inverse, lazy);
+  for (int k = 0; k < npoly; ++k)
+    if (int rc = ntt_batch(r, in + (size_t)k * in_rows * r->N, out + (size_t)k * out_rows * r->N, 1, level, inverse, lazy)) return rc;
+  return RH_OK;
+}
+extern "C" int rh_ring_ntt_rows(rh_ring* r, const uint64_t* in, int in_rows, uint64_t* out, int out_rows, int npoly, int level, int lazy) {
+  return ntt_rows(r, in, in_rows, out, out_rows, npoly, level, false, lazy != 0);
+}
+extern "C" int rh_ring_intt_rows(rh_ring* r, const uint64_t* in, int in_rows, uint64_t* out, int out_rows, int npoly, int level, int lazy) {
+  return ntt_rows(r, in, in_rows, out, out_rows, npoly, level, true, lazy != 0);
+}
 extern "C" int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, int inverse, int phase) {
   if (phase < 0 || phase > 2) return rh_fail(RH_ERR_ARG, "phase must be 0, 1 or 2");
   return ntt_batch(r, in, out, npoly, level, inverse != 0, false, phase);
@@ -821,4 +840,18 @@ extern "C" int rh_ring_vec_op(rh_ring* r, int opcode, const uint64_t* p1, const 
   if (op_reads_y(opcode) && !p2) return rh_fail(RH_ERR_ARG, "vec_op %d: p2 is null", opcode);
   (void)hipSetDevice(r->device);
   return rh_vec_launch(r, opcode, p1, p2, p3, npoly, level + 1, 0, s0, s1);
+}
+extern "C" int rh_ring_vec_op_rows(rh_ring* r, int opcode, const uint64_t* p1, int rows1, const uint64_t* p2, int rows2, uint64_t* p3, int rows3,
+                                   int npoly, int level, const uint64_t* s0, const uint64_t* s1) {
+  if (!r) return rh_fail(RH_ERR_ARG, "vec_op: null argument");
+  if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "vec_op: level %d out of range [0,%d)", level, r->L);
+  const int need = level + 1;
+  if ((p1 && rows1 < need) || (p2 && rows2 < need) || rows3 < need) return rh_fail(RH_ERR_ARG, "vec_op: a block has fewer than level+1 = %d limbs per poly", need);
+  if ((!p1 || rows1 == need) && (!p2 || rows2 == need) && rows3 == need) return rh_ring_vec_op(r, opcode, p1, p2, p3, npoly, level, s0, s1);
+  for (int k = 0; k < npoly; ++k) {
+    const size_t N = r->N;
+    if (int rc = rh_ring_vec_op(r, opcode, p1 ? p1 + (size_t)k * rows1 * N : nullptr, p2 ? p2 + (size_t)k * rows2 * N : nullptr,
+                                p3 + (size_t)k * rows3 * N, 1, level, s0, s1)) return rc;
+  }
+  return RH_OK;
 }

@@ -87,6 +87,8 @@ def lib():
         "rh_ntt_backward": (i, [vp, i, U64P, U64P]), "rh_ntt_backward_lazy": (i, [vp, i, U64P, U64P]),
         "rh_ring_ntt": (i, [vp, vp, vp, i, i, i]), "rh_ring_intt": (i, [vp, vp, vp, i, i, i]),
         "rh_ring_ntt_phase": (i, [vp, vp, vp, i, i, i, i]),
+        "rh_ring_ntt_rows": (i, [vp, vp, i, vp, i, i, i, i]), "rh_ring_intt_rows": (i, [vp, vp, i, vp, i, i, i, i]),
+        "rh_ring_vec_op_rows": (i, [vp, i, vp, i, vp, i, vp, i, i, i, U64P, U64P]),
         "rh_ring_intt_mul": (i, [vp, vp, vp, vp, i, i]),
         "rh_ring_ntt3n_reorder": (i, [vp, vp, vp, i, i, i]),
         "rh_ring_set_tuning": (i, [vp, C.c_char_p, C.c_long]),
@@ -292,30 +294,37 @@ class Ring:
             pass
 
     # ---- NTT (ring/ntt.go:127-152) -----------------------------------------------------------------------------
-    def _chk(self, *polys):
-        """The C ABI strides every block by level+1 rows per poly (ringhip.h "Data model"), so a batch must be allocated at
-        exactly the level it is used at.  The reference's ring.AtLevel(l) on polys with MORE limbs (ring/ring.go:192-213)
-        is accepted for a single poly only (its leading limbs are contiguous); a batch raises instead of striding wrongly."""
+    def _chk(self, *polys, rows_ok=False):
+        """The batched C entry points stride every block by level+1 rows per poly (ringhip.h "Data model").  The reference's
+        ring.AtLevel(l) on polys with MORE limbs (ring/ring.go:192-213) goes through the *_rows entry points (NTT, INTT, the
+        element-wise family: rows_ok); the other batched calls accept it for a single poly only (leading limbs contiguous) and
+        refuse a batch instead of striding wrongly.  Returns True when a poly has more limbs than the view's level."""
+        more = False
         for p in polys:
             if p is None:
                 continue
             if p.limbs < self.level + 1:
                 raise RingHipError("poly has %d limbs, ring level needs %d" % (p.limbs, self.level + 1))
-            if p.limbs != self.level + 1 and p.npoly > 1:
-                raise RingHipError("batch of %d polys has %d limbs per poly but the ring view is at level %d: device blocks are "
-                                   "strided by level+1 rows, allocate the batch at that level" % (p.npoly, p.limbs, self.level))
+            if p.limbs != self.level + 1:
+                more = True
+                if p.npoly > 1 and not rows_ok:
+                    raise RingHipError("batch of %d polys has %d limbs per poly but the ring view is at level %d: this call strides "
+                                       "blocks by level+1 rows, allocate the batch at that level" % (p.npoly, p.limbs, self.level))
+        return more
 
-    def NTT(self, p1, p2):
-        self._chk(p1, p2); _check(lib().rh_ring_ntt(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 0))
+    def _ntt(self, p1, p2, inverse, lazy):
+        L = lib()
+        if self._chk(p1, p2, rows_ok=True):
+            f = L.rh_ring_intt_rows if inverse else L.rh_ring_ntt_rows
+            _check(f(self._h, p1.ptr, p1.limbs, p2.ptr, p2.limbs, p1.npoly, self.level, lazy))
+        else:
+            f = L.rh_ring_intt if inverse else L.rh_ring_ntt
+            _check(f(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, lazy))
 
-    def NTTLazy(self, p1, p2):
-        self._chk(p1, p2); _check(lib().rh_ring_ntt(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 1))
-
-    def INTT(self, p1, p2):
-        self._chk(p1, p2); _check(lib().rh_ring_intt(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 0))
-
-    def INTTLazy(self, p1, p2):
-        self._chk(p1, p2); _check(lib().rh_ring_intt(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 1))
+    def NTT(self, p1, p2): self._ntt(p1, p2, False, 0)
+    def NTTLazy(self, p1, p2): self._ntt(p1, p2, False, 1)
+    def INTT(self, p1, p2): self._ntt(p1, p2, True, 0)
+    def INTTLazy(self, p1, p2): self._ntt(p1, p2, True, 1)
 
     def NTT3NReorder(self, p1, p2, to_reference=True):
         """3N rings: NTT-domain block between block order (tuning ntt3n_block_order) and the Go transformer's order; out of place"""
@@ -368,9 +377,14 @@ class Ring:
     # ---- element-wise (ring/operations.go -> ring/vec_ops.go) --------------------------------------------------
     def vec_op(self, op, p1, p2, p3, s0=None, s1=None):
         code = OPS[op] if isinstance(op, str) else int(op)
-        self._chk(p1, p2, p3)
+        more = self._chk(p1, p2, p3, rows_ok=True)
         a = _u64(s0) if s0 is not None else None
         b = _u64(s1) if s1 is not None else None
+        if more:
+            _check(lib().rh_ring_vec_op_rows(self._h, code, p1.ptr if p1 is not None else None, p1.limbs if p1 is not None else 0,
+                                             p2.ptr if p2 is not None else None, p2.limbs if p2 is not None else 0,
+                                             p3.ptr, p3.limbs, p3.npoly, self.level, _p(a), _p(b)))
+            return
         _check(lib().rh_ring_vec_op(self._h, code, p1.ptr if p1 is not None else None, p2.ptr if p2 is not None else None,
                                     p3.ptr, p3.npoly, self.level, _p(a), _p(b)))
 

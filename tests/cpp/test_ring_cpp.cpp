@@ -98,6 +98,20 @@ int main() {
   for (int l = 0; l < 2; ++l)
     for (int j = 0; j < N; ++j) EXPECT(c[l * N + j] == (j == 1 ? mods[l] - 15 : 0));
 
+  // Ring.AtLevel(l) on polys allocated at the top level (ring/ring.go:192-213): limbs 0..l transformed, the rest untouched
+  {
+    Ring lo = R.AtLevel(0);
+    std::vector<uint64_t> h(2 * N);
+    for (int j = 0; j < 2 * N; ++j) h[j] = (uint64_t)(j * 2654435761u) % mods[j / N];
+    Poly full = R.NewPoly(), ref = lo.NewPoly();
+    full.upload(h);
+    ref.upload(std::vector<uint64_t>(h.begin(), h.begin() + N));
+    lo.NTT(full, full); lo.NTT(ref, ref);
+    std::vector<uint64_t> g = full.download(), e = ref.download();
+    EXPECT(std::equal(e.begin(), e.end(), g.begin()));
+    EXPECT(std::equal(h.begin() + N, h.end(), g.begin() + N));
+  }
+
   // key switch (core/rlwe/evaluator_gadget_product.go): direct == hoisted == the shard path with every limb owned
   {
     const int n = 4096;

@@ -97,25 +97,40 @@ def test_levels_use_leading_limbs(rh, oracle):
 
 
 def test_at_level_on_a_batch_with_more_limbs(rh, oracle):
-    # ring.AtLevel(level) on max-level polys (ring/ring.go:192-213): the C ABI strides blocks by level+1 rows, so a single
-    # poly with more limbs works (leading limbs contiguous, the others untouched) and a BATCH is refused instead of being
-    # read with the wrong stride
+    # ring.AtLevel(level) on max-level polys (ring/ring.go:192-213), the idiomatic use inside the reference's evaluators: NTT, INTT and
+    # the element-wise family take blocks with more limbs per poly than the view's level (rh_ring_*_rows: limbs 0..level of every
+    # poly processed, the others untouched); calls without a rows form refuse a BATCH instead of striding wrongly
     N, mods = 4096, QI60[:4]
     ring = rh.Ring(N, mods)
     rng = np.random.default_rng(11)
-    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(2)])
-    one = rh.DevicePoly.from_numpy(ring, a[:1])
-    ring.AtLevel(1).NTT(one, one)
-    got = one.numpy()[0]
-    srs = [oracle.SubRingConsts(N, q) for q in mods[:2]]
-    assert np.array_equal(got[:2], np.stack([oracle.ntt(a[0, i], srs[i]) for i in range(2)]))
-    assert np.array_equal(got[2:], a[0, 2:])
+    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(3)])
+    b = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(3)])
+    srs = [oracle.SubRingConsts(N, q) for q in mods]
+    v = ring.AtLevel(1)
+    pa = rh.DevicePoly.from_numpy(ring, a)
+    v.NTT(pa, pa)                                                  # in place on the max-level batch
+    got = pa.numpy()
+    for k in range(3):
+        assert np.array_equal(got[k, :2], np.stack([oracle.ntt(a[k, i], srs[i]) for i in range(2)]))
+        assert np.array_equal(got[k, 2:], a[k, 2:])               # limbs above the level untouched
+    out2 = v.NewPoly(3)                                            # a block AT the level as the other operand
+    v.INTT(pa, out2)
+    assert np.array_equal(out2.numpy(), a[:, :2])
+    pb = rh.DevicePoly.from_numpy(ring, b)
+    v.Add(rh.DevicePoly.from_numpy(ring, a), pb, pb)               # element-wise: max-level blocks on all three operands
+    gb = pb.numpy()
+    for k in range(3):
+        for i in range(2):
+            assert np.array_equal(gb[k, i], oracle.vec_op(rh.OPS["ADD"], a[k, i], b[k, i], b[k, i], 0, 0, mods[i]))
+        assert np.array_equal(gb[k, 2:], b[k, 2:])
+    v.MulRNSScalarMontgomery(rh.DevicePoly.from_numpy(ring, a), [5, 7], out2)   # mixed: 4-limb input, 2-limb output
+    for i in range(2):
+        assert np.array_equal(out2.numpy()[2, i], oracle.vec_op(rh.OPS["MUL_SCALAR_MONT"], a[2, i], None, a[2, i], [5, 7][i], 0, mods[i]))
     two = rh.DevicePoly.from_numpy(ring, a)
+    with pytest.raises(rh.RingHipError):                           # no rows form for the automorphisms: a batch is refused
+        v.AutomorphismNTT(two, 5, rh.DevicePoly.from_numpy(ring, a))
     with pytest.raises(rh.RingHipError):
-        ring.AtLevel(1).NTT(two, two)
-    with pytest.raises(rh.RingHipError):
-        ring.AtLevel(1).Add(two, two, two)
-    assert np.array_equal(two.numpy(), a)
+        ring.AtLevel(3).NTT(v.NewPoly(1), v.NewPoly(1))            # fewer limbs than the level: always an error
     ring.close()
 
 
