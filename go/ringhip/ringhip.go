@@ -46,7 +46,7 @@ type Transformer struct {
 // replacing ring.NewNumberTheoreticTransformerStandard (ring/ntt.go:46-56).
 func Factory(device int) func(*ring.SubRing, int) ring.NumberTheoreticTransformer {
 	return func(s *ring.SubRing, n int) ring.NumberTheoreticTransformer {
-		return &Transformer{s: s, n: n, device: device, kind: C.RH_RING_STANDARD}
+		return &Transformer{s: s, n: n, device: device, kind: C.int(C.RH_RING_STANDARD)}
 	}
 }
 
@@ -60,12 +60,12 @@ func Factory(device int) func(*ring.SubRing, int) ring.NumberTheoreticTransforme
 // INTEGRATION.md (a `case interface{ IsConjugateInvariant() bool }` arm) or the in-package placement of this file.
 func FactoryCI(device int) func(*ring.SubRing, int) ring.NumberTheoreticTransformer {
 	return func(s *ring.SubRing, n int) ring.NumberTheoreticTransformer {
-		return &Transformer{s: s, n: n, device: device, kind: C.RH_RING_CI}
+		return &Transformer{s: s, n: n, device: device, kind: C.int(C.RH_RING_CI)}
 	}
 }
 
 // IsConjugateInvariant lets a patched SubRing.Type() recognise the ring type without importing this package.
-func (t *Transformer) IsConjugateInvariant() bool { return t.kind == C.RH_RING_CI }
+func (t *Transformer) IsConjugateInvariant() bool { return t.kind == C.int(C.RH_RING_CI) }
 
 // Factory3N replaces ring.NewNumberTheoreticTransformer3N (ring/ntt_3n.go:35-79): pass it to
 // ring.NewRingWithCustomNTT(N, moduli, Factory3N(dev), 3*N) -- what ring.NewRing does for N divisible by 3
@@ -82,7 +82,7 @@ func Factory3N(device int) func(*ring.SubRing, int) ring.NumberTheoreticTransfor
 		if err != nil { // same panic as ring/ntt_3n.go:40-42
 			panic(fmt.Sprintf("failed to find primitive 3N-th root: %v", err))
 		}
-		return &Transformer{s: s, n: n, device: device, kind: C.RH_RING_3N, omega: om}
+		return &Transformer{s: s, n: n, device: device, kind: C.int(C.RH_RING_3N), omega: om}
 	}
 }
 
@@ -95,7 +95,7 @@ func Factory3N(device int) func(*ring.SubRing, int) ring.NumberTheoreticTransfor
 //	omega := ref.NthRoot
 func Factory3NLike(device int, omegaOf func(s *ring.SubRing, n int) uint64) func(*ring.SubRing, int) ring.NumberTheoreticTransformer {
 	return func(s *ring.SubRing, n int) ring.NumberTheoreticTransformer {
-		return &Transformer{s: s, n: n, device: device, kind: C.RH_RING_3N, omega: omegaOf(s, n)}
+		return &Transformer{s: s, n: n, device: device, kind: C.int(C.RH_RING_3N), omega: omegaOf(s, n)}
 	}
 }
 
@@ -111,7 +111,7 @@ func (t *Transformer) init() {
 		mred := C.uint64_t(s.MRedConstant)
 		bred := [2]C.uint64_t{C.uint64_t(s.BRedConstant[0]), C.uint64_t(s.BRedConstant[1])}
 		var rc C.int
-		if t.kind == C.RH_RING_3N {
+		if t.kind == C.int(C.RH_RING_3N) {
 			om := C.uint64_t(t.omega)
 			rc = C.rh_ring_create(&t.h, C.int(t.device), t.kind, C.int(t.n), 1, &q, &mred, &bred[0], nil, nil, nil, &om)
 		} else {
@@ -210,9 +210,9 @@ func NewDeviceRingWithOmega(r *ring.Ring, device int, omega []uint64) (*DeviceRi
 	tn := N // table words per limb = NthRoot/2
 	switch {
 	case N%3 == 0:
-		kind = C.RH_RING_3N
+		kind = C.int(C.RH_RING_3N)
 	case r.NthRoot() == uint64(4*N):
-		kind, tn = C.RH_RING_CI, 2*N
+		kind, tn = C.int(C.RH_RING_CI), 2*N
 	}
 	mod := make([]C.uint64_t, L)
 	mred := make([]C.uint64_t, L)
@@ -225,7 +225,7 @@ func NewDeviceRingWithOmega(r *ring.Ring, device int, omega []uint64) (*DeviceRi
 	runtime.LockOSThread()
 	defer runtime.UnlockOSThread()
 	var rc C.int
-	if kind == C.RH_RING_3N {
+	if kind == C.int(C.RH_RING_3N) {
 		if len(omega) != L {
 			return nil, fmt.Errorf("ringhip: a 3N device ring needs one primitive 3N-th root per modulus (Transformer.Omega())")
 		}
