@@ -19,7 +19,7 @@ ntt_kernels.hip.hpp: fwd_tile_body.
 import os
 import sys
 
-EXP = int(os.environ.get("RH_ASM_EXP", "0"))     # TIMING EXPERIMENTS ONLY (wrong results): 1 no LDS exchanges, 2 no round-B/C twiddle loads, 4 no final reduction, 8 no barriers
+EXP = int(os.environ.get("RH_ASM_EXP", "0"))     # TIMING EXPERIMENTS ONLY (wrong results): 1 no LDS exchanges, 2 no round-B/C twiddle loads, 4 no final reduction, 8 no barriers, 16 no round C
 PRIO = int(os.environ.get("RH_ASM_PRIO", "0"))   # s_setprio around the load-issue and store phases (0 = off, for A/B runs)
 out = []
 
@@ -426,7 +426,10 @@ def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True, epilogue
         emit("ds_read_b64 %s, v%d offset:%d" % (pair(X(k)), A1, 8 * k))
     emit("s_waitcnt lgkmcnt(0)")
     emit("; ---- round C (twiddle quads arrive in slot order; stage u needs slots < 2^(u+1) - 1)")
-    round16(lambda slot: (TW0 + 4 * slot, None), stage_hook=lambda u: emit("s_waitcnt vmcnt(%d)" % (15 - ((2 << u) - 1))))
+    if EXP & 16 and not epilogue:      # TIMING ONLY: an 8-stage pass (rounds A and B) -- what a balanced 8 + 8 split's pass would cost
+        emit("s_waitcnt vmcnt(0)")
+    else:
+        round16(lambda slot: (TW0 + 4 * slot, None), stage_hook=lambda u: emit("s_waitcnt vmcnt(%d)" % (15 - ((2 << u) - 1))))
     if epilogue:
         return gen_submul_epilogue(A0, A1, A3, with_z=(epilogue == "submul_add"))
     emit("; ---- canonical reduction: x < 8q -> [0,q)")
