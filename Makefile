@@ -21,7 +21,7 @@ tests/cpp/test_ring_cpp: tests/cpp/test_ring_cpp.cpp tests/cpp/golden_vectors.in
 
 oracle: oracle/libring_oracle.so
 oracle/libring_oracle.so: oracle/ring_oracle.c oracle/ring_oracle.h include/ringhip_ops.h
-	gcc -O3 -march=native -fno-fast-math -ffp-contract=off -fPIC -shared -pthread oracle/ring_oracle.c -o $@
+	gcc -O3 -march=x86-64-v3 -fno-fast-math -ffp-contract=off -fPIC -shared -pthread oracle/ring_oracle.c -o $@
 
 clean:
 	rm -f $(LIB) oracle/libring_oracle.so
