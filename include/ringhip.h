@@ -136,7 +136,7 @@ int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int
  *   asm_tile / asm_cols   1: generated hand-scheduled bodies (default), 0: the C++ kernels
  *   fuse_submul     1: ModDown / rescale subtract-multiply in the forward tile kernel's epilogue (default)
  *   fuse3n          1: 3N rings, split + radix-3 layer fused with the sub-transforms' column stages (default)
- *   perm_inv_shape  3N inverse permutation tile: 32 / 64 (default) / 128 words per block-order run
+ *   perm_fwd_shape / perm_inv_shape  3N permutation tile as 10*A + B: block-order runs of 2^A words, rank-order runs of nb * 2^B words
  * One key changes a LAYOUT, not a value (3N rings, N = 3*2^k >= 24576, default 0):
  *   ntt3n_block_order  1: rh_ring_ntt / rh_ring_intt keep the NTT domain in "block order" (slot j of block c of the radix-2
  *                   sub-transforms at word c*N/6 + j) instead of the Go transformer's ascending-totative order

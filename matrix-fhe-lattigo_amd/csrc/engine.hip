@@ -674,6 +674,7 @@ extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
   if (!strcmp(key, "auto_span_rows")) { if (value < 1) return rh_fail(RH_ERR_ARG, "auto_span_rows must be >= 1"); r->auto_span_rows = (int)value; return RH_OK; }
   if (!strcmp(key, "fuse_submul")) { r->fuse_submul = (int)value; return RH_OK; }
   if (!strcmp(key, "perm_inv_shape")) { r->perm_inv_shape = (int)value; return RH_OK; }
+  if (!strcmp(key, "perm_fwd_shape")) { r->perm_fwd_shape = (int)value; return RH_OK; }
   if (!strcmp(key, "fuse3n")) { r->fuse3n = (int)value; return RH_OK; }
   if (!strcmp(key, "ntt3n_block_order")) {
     if (r->kind != RH_RING_3N) return rh_fail(RH_ERR_ARG, "ntt3n_block_order: not a 3N ring");

@@ -43,7 +43,8 @@ struct rh_ring {
   std::vector<void*> rescale_tables;      // per level, rescale.hip
   u64* d_rs[2] = {nullptr, nullptr}; size_t rs_words[2] = {0, 0};
   int fuse_submul = 1;            // ModDown / rescale: subtract-multiply fused into the forward tile kernel's epilogue
-  int perm_inv_shape = 64;        // 3N inverse permutation tile: words per block-order run (32 / 64 / 128)
+  int perm_fwd_shape = 44;        // 3N permutation tiles as 10*A + B: block-order runs of 2^A words, rank-order runs of nb * 2^B words
+  int perm_inv_shape = 44;        // (4, 4) measured best on MI355X for both directions (12 KiB tiles, 13 workgroups per CU): 1.06 -> 0.91 ms at the config 4 ring
   int fuse3n = 1;                 // 3N rings, b = 1: split + radix-3 layer fused with the sub-transforms' column stages
   int block_order3n = 0;          // 3N rings: device-batched NTT domain kept in block order (ntt3n.hip), no permutation pass
   int asm_cols = 1;               // N = 2^16: hand-scheduled column stages (fwd_cols16_asm_body) in place of the C++ body

@@ -555,6 +555,22 @@ static int ntt3n_block_order_launch(rh_ring* r, const u64* in, u64* out, int npo
   return RH_OK;
 }
 
+// tiled permutation with tile shape (A, B) encoded as 10*A + B (block-order runs of 2^A words, rank-order runs of nb * 2^B words);
+// the tile is 2^(A+B) * nb words of LDS, so smaller shapes trade run length for workgroups per CU
+template <bool FWD>
+static bool launch_perm_tiled(int shape, unsigned rows, int log_n2, int nb, hipStream_t st, const u64* in, u64* out, int N, const int* rank) {
+  const int A = shape / 10, B = shape % 10;
+  if (A < 3 || B < 3 || A + B > log_n2) return false;
+  const dim3 g(rows, 1u << (log_n2 - A - B));
+  const size_t lds = ((size_t)1 << A) * (((size_t)nb << B) + 1) * 8;
+#define RH_PERM(a, b) case 10 * a + b: ntt3n_perm_tiled<FWD, a, b><<<g, 256, lds, st>>>(in, out, N, nb, log_n2, rank); return true
+  switch (shape) {
+    RH_PERM(5, 5); RH_PERM(6, 4); RH_PERM(7, 3); RH_PERM(4, 4); RH_PERM(5, 4); RH_PERM(4, 5); RH_PERM(5, 3); RH_PERM(6, 3); RH_PERM(3, 5); RH_PERM(4, 3); RH_PERM(3, 4);
+  }
+#undef RH_PERM
+  return false;
+}
+
 // reference order <-> block order of NTT-domain data (never in place): the permutation pass on its own
 int rh_ring3n_reorder_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, bool to_reference) {
   rh_ring3n_state* s = r->s3n;
@@ -566,13 +582,12 @@ int rh_ring3n_reorder_launch(rh_ring* r, const u64* in, u64* out, int npoly, int
   hipStream_t st = rh_stream(r);
   auto chunks = [](int work) { int g = (work + 255) / 256; return g < 1 ? 1 : (g > 64 ? 64 : g); };
   const bool tiled = s->log_n2 >= 2 * PT && nb <= 6;
-  const dim3 pgrid(rows, 1u << (s->log_n2 >= 2 * PT ? s->log_n2 - 2 * PT : 0));
   if (to_reference) {
-    if (tiled) ntt3n_perm_tiled<true, 5, 5><<<pgrid, 256, (size_t)32 * (32 * nb + 1) * 8, st>>>(in, out, N, nb, s->log_n2, s->d_rank);
-    else ntt3n_perm_fwd<<<dim3(rows, chunks(N)), 256, 0, st>>>(in, out, N, nb, s->log_n2, s->d_block_of_rank, r->d_consts, Lrows, 0);
+    if (!(tiled && launch_perm_tiled<true>(r->perm_fwd_shape, rows, s->log_n2, nb, st, in, out, N, s->d_rank)))
+      ntt3n_perm_fwd<<<dim3(rows, chunks(N)), 256, 0, st>>>(in, out, N, nb, s->log_n2, s->d_block_of_rank, r->d_consts, Lrows, 0);
   } else {
-    if (tiled) ntt3n_perm_tiled<false, 6, 4><<<pgrid, 256, (size_t)64 * (16 * nb + 1) * 8, st>>>(in, out, N, nb, s->log_n2, s->d_rank);
-    else ntt3n_perm_inv<<<dim3(rows, chunks(N)), 256, 0, st>>>(in, out, N, nb, s->log_n2, s->d_block_of_rank);
+    if (!(tiled && launch_perm_tiled<false>(r->perm_inv_shape, rows, s->log_n2, nb, st, in, out, N, s->d_rank)))
+      ntt3n_perm_inv<<<dim3(rows, chunks(N)), 256, 0, st>>>(in, out, N, nb, s->log_n2, s->d_block_of_rank);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "3N reorder launch failed: %s", hipGetErrorString(e));
@@ -595,10 +610,7 @@ int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
   const tw2* r3f = s->d_r3_fwd + (size_t)limb0 * s->r3_stride;
   const tw2* r3i = s->d_r3_inv + (size_t)limb0 * s->r3_stride;
   auto chunks = [](int work) { int g = (work + 255) / 256; return g < 1 ? 1 : (g > 64 ? 64 : g); };
-  const bool tiled = s->log_n2 >= 2 * PT && nb <= 6;     // LDS: 32*(32*nb+1)*8 bytes = 48 KiB at nb = 6
-  const size_t perm_lds = (size_t)32 * (32 * nb + 1) * 8;
-  const dim3 pgrid(rows, 1u << (s->log_n2 >= 2 * PT ? s->log_n2 - 2 * PT : 0));
-  const size_t perm_lds_inv = (size_t)64 * (16 * nb + 1) * 8;      // (A, B) = (6, 4): same mid-bit count, 512-byte write runs
+  const bool tiled = s->log_n2 >= 2 * PT && nb <= 6;     // LDS: 2^A * (2^B * nb + 1) * 8 bytes (48 KiB for (5, 5) at nb = 6)
   if (!inverse) {
     const int S1sub = s->sub ? s->log_n2 - 12 : 0;
     const bool fuse = s->b == 1 && s->sub && r->fuse3n && S1sub >= 1 && S1sub <= 3;    // 6 * 2^S1 coefficients per thread
@@ -621,13 +633,11 @@ int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
       // (poly, limb, block) rows of length n2: limb-major virtual limb index = limb*nb + c
       if (int rc = rh_std_ntt_launch(s->sub, tmp, tmp, npoly, Lrows * nb, limb0 * nb, false, false, 0)) return rc;
     }
-    if (tiled) ntt3n_perm_tiled<true, 5, 5><<<pgrid, 256, perm_lds, st>>>(tmp, out, N, nb, s->log_n2, s->d_rank);
-    else ntt3n_perm_fwd<<<dim3(rows, chunks(N)), 256, 0, st>>>(tmp, out, N, nb, s->log_n2, s->d_block_of_rank, c, Lrows, s->sub ? 0 : 1);
+    if (!(tiled && launch_perm_tiled<true>(r->perm_fwd_shape, rows, s->log_n2, nb, st, tmp, out, N, s->d_rank)))
+      ntt3n_perm_fwd<<<dim3(rows, chunks(N)), 256, 0, st>>>(tmp, out, N, nb, s->log_n2, s->d_block_of_rank, c, Lrows, s->sub ? 0 : 1);
   } else {
-    if (tiled && r->perm_inv_shape == 64) ntt3n_perm_tiled<false, 6, 4><<<pgrid, 256, perm_lds_inv, st>>>(in, tmp, N, nb, s->log_n2, s->d_rank);
-    else if (tiled && r->perm_inv_shape == 128) ntt3n_perm_tiled<false, 7, 3><<<pgrid, 256, (size_t)128 * (8 * nb + 1) * 8, st>>>(in, tmp, N, nb, s->log_n2, s->d_rank);
-    else if (tiled) ntt3n_perm_tiled<false, 5, 5><<<pgrid, 256, perm_lds, st>>>(in, tmp, N, nb, s->log_n2, s->d_rank);
-    else ntt3n_perm_inv<<<dim3(rows, chunks(N)), 256, 0, st>>>(in, tmp, N, nb, s->log_n2, s->d_block_of_rank);
+    if (!(tiled && launch_perm_tiled<false>(r->perm_inv_shape, rows, s->log_n2, nb, st, in, tmp, N, s->d_rank)))
+      ntt3n_perm_inv<<<dim3(rows, chunks(N)), 256, 0, st>>>(in, tmp, N, nb, s->log_n2, s->d_block_of_rank);
     const int S1sub = s->sub ? s->log_n2 - 12 : 0;
     const bool fuse = s->b == 1 && s->sub && r->fuse3n && S1sub >= 1 && S1sub <= 3;
     if (s->sub) {

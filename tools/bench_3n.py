@@ -18,6 +18,10 @@ dev = torch.device("cuda", 0); stream = torch.cuda.current_stream()
 ring = rh.Ring(N, mods, kind=rh.Matrix3N); ring.set_stream(stream.cuda_stream)
 if len(sys.argv) > 4:
     ring.set_tuning("ntt3n_block_order", int(sys.argv[4]))     # 1: device NTT domain in block order (no permutation pass)
+if len(sys.argv) > 5:
+    ring.set_tuning("perm_fwd_shape", int(sys.argv[5]))        # 10*A + B
+if len(sys.argv) > 6:
+    ring.set_tuning("perm_inv_shape", int(sys.argv[6]))
 qs = torch.tensor(mods, dtype=torch.int64, device=dev).view(1, L, 1)
 x = torch.randint(0, 1 << 62, (B, L, N), dtype=torch.int64, device=dev) % qs
 p = rh.DevicePoly.from_torch(ring, x)
