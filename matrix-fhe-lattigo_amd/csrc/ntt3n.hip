@@ -235,7 +235,7 @@ ntt3n_post_b1_inv(const u64* in, u64* out, int N, const tw2* __restrict__ r3, in
 // the first S1 stages run in place on them with block j's twiddles (virtual limb limb*6 + j of the sub-ring) and the
 // sub-ring only runs its tile kernel afterwards.  Same arithmetic as ntt3n_pre_b1_fwd followed by fwd_cols_body.
 template <int S1>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, S1 == 3 ? 3 : (S1 == 2 ? 5 : 8))))   // 6 * 2^S1 coefficients live
 ntt3n_pre_cols_fwd(const u64* in, u64* out, int N, const tw2* __restrict__ r3, int r3_stride, const Limb3N* __restrict__ l3,
                    const LimbConsts* __restrict__ consts, int L, const tw2* __restrict__ sub_tw, int log_n2) {
   constexpr int R = 1 << S1;
@@ -282,7 +282,7 @@ ntt3n_pre_cols_fwd(const u64* in, u64* out, int N, const tw2* __restrict__ r3, i
 
 // inverse mirror: the sub-transforms' column stages (unscaled, values < 4q) fused with the radix-3 layer + split
 template <int S1>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3)))     // 6 * 2^S1 coefficients live: let the allocator use the registers
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, S1 == 3 ? 4 : (S1 == 2 ? 5 : 8))))   // 6 * 2^S1 coefficients live
 ntt3n_cols_post_inv(const u64* in, u64* out, int N, const tw2* __restrict__ r3, int r3_stride, const Limb3N* __restrict__ l3,
                     const LimbConsts* __restrict__ consts, int L, const tw2* __restrict__ sub_tw, int log_n2) {
   constexpr int R = 1 << S1;
