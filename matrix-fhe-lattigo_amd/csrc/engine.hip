@@ -478,6 +478,43 @@ int rh_std_ntt_fwd_strided(rh_ring* r, u64* data, int npoly, int Lrows, int limb
   return std_ntt_launch_span(r, data, data, npoly, Lrows, limb0, false, false, 0, Ls);
 }
 
+// Forward canonical transform, in place, of the non-digit limbs of every digit block of a hybrid decomposition
+// (DecomposeSingleNTT, core/rlwe/evaluator_gadget_product.go:455-478, for all digits at once): block j holds npoly polys
+// of LQ rows and its limbs [j*LP, min((j+1)*LP, LQ)) are left alone.  One software-pipelined stream of launches instead of
+// two strided transforms (before / after the digit's limbs) per digit.  Needs the hand-scheduled bodies (N = 2^14 .. 2^16).
+bool rh_can_ntt_digits(const rh_ring* r) {
+  const int S1 = r->logN - LT;
+  return r->kind == RH_RING_STANDARD && r->asm_tile && r->asm_cols && r->digit_pipeline && S1 >= 2 && S1 <= 4;
+}
+int rh_std_ntt_fwd_digits(rh_ring* r, u64* data, size_t digit_stride, int npoly, int beta, int LQ, int LP) {
+  if (!rh_can_ntt_digits(r)) return rh_fail(RH_ERR_UNSUPPORTED, "digit-block transform needs the hand-scheduled bodies (2^14 <= N <= 2^16)");
+  if (npoly <= 0 || beta <= 0) return RH_OK;
+  (void)hipGetLastError();
+  const int S1 = r->logN - LT;
+  hipStream_t st = rh_stream(r);
+  auto rows = [&](int j) {                          // digit j: its transformed rows
+    GapRows g; g.Ls = LQ; g.gap0 = (u32)(j * LP);
+    int gl = LQ - j * LP; if (gl > LP) gl = LP; if (gl < 0) gl = 0;
+    g.gap_len = (u32)gl; g.L = LQ - gl;
+    return g;
+  };
+  for (int j = 0; j <= beta; ++j) {
+    GapRows g1 = j < beta ? rows(j) : GapRows{1, 1, 0, 0}, g2 = j >= 1 ? rows(j - 1) : GapRows{1, 1, 0, 0};
+    const unsigned n1 = j < beta ? (unsigned)npoly * g1.L * 16 : 0, n2 = j >= 1 ? ((unsigned)npoly * g2.L) << S1 : 0;
+    const unsigned grid = n1 > n2 ? n1 : n2;
+    if (!grid) continue;
+    if (!g1.L) g1.L = 1;
+    if (!g2.L) g2.L = 1;
+    u64* d1 = data + (size_t)(j < beta ? j : 0) * digit_stride; u64* d2 = data + (size_t)(j >= 1 ? j - 1 : 0) * digit_stride;
+    switch (S1) {
+      case 2: ntt_fwd_fused_gap_asm<2><<<grid, 256, 0, st>>>(d1, n1, g1, d2, n2, npoly, g2, r->d_tw_fwd, r->d_twk_fwd, r->d_consts); break;
+      case 3: ntt_fwd_fused_gap_asm<3><<<grid, 256, 0, st>>>(d1, n1, g1, d2, n2, npoly, g2, r->d_tw_fwd, r->d_twk_fwd, r->d_consts); break;
+      case 4: ntt_fwd_fused_gap_asm<4><<<grid, 256, 0, st>>>(d1, n1, g1, d2, n2, npoly, g2, r->d_tw_fwd, r->d_twk_fwd, r->d_consts); break;
+    }
+  }
+  return check_launch("ntt_fwd_fused_gap_asm");
+}
+
 bool rh_can_fuse_submul(const rh_ring* r) { return r->kind == RH_RING_STANDARD && r->logN >= LT && r->fuse_submul; }
 // Forward canonical transform of `buf` (in place up to its tile stages) fused with out = MRed(2q - y + NTT(buf), s_limb):
 // column stages as usual, then ntt_fwd_tile_submul.  y / out: (poly, limb) blocks with y_rows / out_rows limbs per poly.
@@ -673,6 +710,7 @@ extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
   if (!strcmp(key, "asm_tile")) { r->asm_tile = value != 0; return RH_OK; }
   if (!strcmp(key, "auto_span_rows")) { if (value < 1) return rh_fail(RH_ERR_ARG, "auto_span_rows must be >= 1"); r->auto_span_rows = (int)value; return RH_OK; }
   if (!strcmp(key, "fuse_submul")) { r->fuse_submul = (int)value; return RH_OK; }
+  if (!strcmp(key, "digit_pipeline")) { r->digit_pipeline = (int)value; return RH_OK; }
   if (!strcmp(key, "perm_inv_shape")) { r->perm_inv_shape = (int)value; return RH_OK; }
   if (!strcmp(key, "perm_fwd_shape")) { r->perm_fwd_shape = (int)value; return RH_OK; }
   if (!strcmp(key, "fuse3n")) { r->fuse3n = (int)value; return RH_OK; }

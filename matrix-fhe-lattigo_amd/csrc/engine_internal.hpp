@@ -43,6 +43,7 @@ struct rh_ring {
   std::vector<void*> rescale_tables;      // per level, rescale.hip
   u64* d_rs[2] = {nullptr, nullptr}; size_t rs_words[2] = {0, 0};
   int fuse_submul = 1;            // ModDown / rescale: subtract-multiply fused into the forward tile kernel's epilogue
+  int digit_pipeline = 1;         // key switch: all digit blocks transformed by one pipelined stream of launches (N = 2^14 .. 2^16)
   int perm_fwd_shape = 44;        // 3N permutation tiles as 10*A + B: block-order runs of 2^A words, rank-order runs of nb * 2^B words
   int perm_inv_shape = 44;        // (4, 4) measured best on MI355X for both directions (12 KiB tiles, 13 workgroups per CU): 1.06 -> 0.91 ms at the config 4 ring
   int fuse3n = 1;                 // 3N rings, b = 1: split + radix-3 layer fused with the sub-transforms' column stages
@@ -73,6 +74,8 @@ struct RhCallScope {                                         // installs (stream
 
 int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase = 0);
 int rh_std_ntt_fwd_strided(rh_ring* r, u64* data, int npoly, int Lrows, int limb0, int Ls);
+bool rh_can_ntt_digits(const rh_ring* r);
+int rh_std_ntt_fwd_digits(rh_ring* r, u64* data, size_t digit_stride, int npoly, int beta, int LQ, int LP);
 bool rh_can_fuse_submul(const rh_ring* r);
 int rh_std_ntt_submul_launch(rh_ring* r, u64* buf, int npoly, int Lrows, int limb0, const u64* y, int y_rows, u64* out, int out_rows,
                              const u64* scalars_host, bool cols_done = false, const u64* z = nullptr, int z_rows = 0);

@@ -49,6 +49,10 @@ int rh_gadget_mac(rh_ring* r, const u64* c2, const u64* e0, const u64* e1, u64* 
 // acc_c = sum_i MRedLazy(evk_c[i], c2[i]) with the reference's Reduce schedule (after every `overf` digits and at the end,
 // core/rlwe/evaluator_gadget_product.go:166-187) kept in registers -- the accumulators are written once instead of being
 // read and rewritten per digit.  poly is the fast block index, so the workgroups that share a key row run together.
+// BETA > 0: the digit count at compile time -- the 3 * BETA 16-byte loads of an element pair are issued before the first multiply.
+// Not limited by the vector ALUs (a variant with ONE Montgomery reduction per output, 0.4 x the instructions, ran 8 % slower at
+// 68 VGPRs) nor by key re-reads (PMC: fetch + write = the algorithmic 3.1 GB per launch): 4.8 TB/s over 4 + 2 streams.
+template <int BETA>
 __global__ void __launch_bounds__(256)
 gadget_mac_all_kernel(const u64* c2, size_t digit_stride, const u64* __restrict__ evk, size_t evk_stride, int beta, int overf,
                       u64* acc0, u64* acc1, unsigned n, const LimbConsts* __restrict__ consts, int L, int npoly,
@@ -57,14 +61,12 @@ gadget_mac_all_kernel(const u64* c2, size_t digit_stride, const u64* __restrict_
   const LimbConsts c = consts[limb];
   const size_t ro = ((size_t)poly * L + limb) * n, eo = (size_t)limb * n;
   const unsigned npairs = n >> 1;
-  for (unsigned i = blockIdx.y * blockDim.x + threadIdx.x; i < npairs; i += gridDim.y * blockDim.x) {
+  const unsigned per = (npairs + gridDim.y - 1) / gridDim.y;        // a contiguous run of the row per workgroup
+  const unsigned lim = min(npairs, (blockIdx.y + 1) * per);
+  for (unsigned i = blockIdx.y * per + threadIdx.x; i < lim; i += blockDim.x) {
     ulonglong2 a = {0, 0}, b = {0, 0};
     int red = 0;
-    for (int d = 0; d < beta; ++d) {
-      const u64* src = (cx && (int)limb / digit_limbs == d) ? cx + ro : c2 + (size_t)d * digit_stride + ro;
-      const ulonglong2 x = *reinterpret_cast<const ulonglong2*>(src + 2 * (size_t)i);
-      const ulonglong2 k0 = *reinterpret_cast<const ulonglong2*>(evk + ((size_t)d * 2) * evk_stride + eo + 2 * (size_t)i);
-      const ulonglong2 k1 = *reinterpret_cast<const ulonglong2*>(evk + ((size_t)d * 2 + 1) * evk_stride + eo + 2 * (size_t)i);
+    auto term = [&](const ulonglong2& x, const ulonglong2& k0, const ulonglong2& k1) {
       a.x += mred_lazy(k0.x, x.x, c.q, c.qinv); a.y += mred_lazy(k0.y, x.y, c.q, c.qinv);
       b.x += mred_lazy(k1.x, x.x, c.q, c.qinv); b.y += mred_lazy(k1.y, x.y, c.q, c.qinv);
       if (red % overf == overf - 1) {
@@ -72,6 +74,22 @@ gadget_mac_all_kernel(const u64* c2, size_t digit_stride, const u64* __restrict_
         b.x = bred_add(b.x, c.q, c.bred0); b.y = bred_add(b.y, c.q, c.bred0);
       }
       ++red;
+    };
+    auto ld = [&](const u64* p) { return *reinterpret_cast<const ulonglong2*>(p + 2 * (size_t)i); };
+    auto xsrc = [&](int d) { return (cx && (int)limb / digit_limbs == d) ? cx + ro : c2 + (size_t)d * digit_stride + ro; };
+    if constexpr (BETA > 0) {
+      ulonglong2 x[BETA], k0[BETA], k1[BETA];
+#pragma unroll
+      for (int d = 0; d < BETA; ++d) {
+        x[d] = ld(xsrc(d));
+        k0[d] = ld(evk + ((size_t)d * 2) * evk_stride + eo);
+        k1[d] = ld(evk + ((size_t)d * 2 + 1) * evk_stride + eo);
+      }
+#pragma unroll
+      for (int d = 0; d < BETA; ++d) term(x[d], k0[d], k1[d]);
+    } else {
+      for (int d = 0; d < beta; ++d)
+        term(ld(xsrc(d)), ld(evk + ((size_t)d * 2) * evk_stride + eo), ld(evk + ((size_t)d * 2 + 1) * evk_stride + eo));
     }
     if (red % overf != 0) {
       a.x = bred_add(a.x, c.q, c.bred0); a.y = bred_add(a.y, c.q, c.bred0);
@@ -86,8 +104,15 @@ static int mac_all(rh_ring* r, const u64* c2, size_t digit_stride, const u64* ev
                    const u64* cx = nullptr, int digit_limbs = 1) {
   const unsigned n = (unsigned)r->N;
   unsigned chunks = (n / 2 + 1023) / 1024; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
-  gadget_mac_all_kernel<<<dim3((unsigned)npoly * L, chunks), 256, 0, rh_stream(r)>>>(c2, digit_stride, evk, (size_t)r->L * n, beta, overf, a0, a1, n,
-                                                                                 r->d_consts, L, npoly, cx, digit_limbs);
+#define RH_MAC_ALL(B) gadget_mac_all_kernel<B><<<dim3((unsigned)npoly * L, chunks), 256, 0, rh_stream(r)>>>( \
+    c2, digit_stride, evk, (size_t)r->L * n, beta, overf, a0, a1, n, r->d_consts, L, npoly, cx, digit_limbs)
+  switch (beta) {
+    case 2: RH_MAC_ALL(2); break;
+    case 3: RH_MAC_ALL(3); break;
+    case 4: RH_MAC_ALL(4); break;
+    default: RH_MAC_ALL(0);
+  }
+#undef RH_MAC_ALL
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_mac_all_kernel launch failed: %s", hipGetErrorString(e));
   return RH_OK;
@@ -113,6 +138,32 @@ static int decompose_single_ntt(rh_bext* be, int levelQ, int levelP, int i, cons
   if (copy_digit && hipMemcpy2DAsync(c2Q + (size_t)st * N, (size_t)LQ * N * 8, cx + (size_t)st * N, (size_t)LQ * N * 8, (size_t)(ed - st) * N * 8, npoly,
                                      hipMemcpyDeviceToDevice, rh_stream(RQ)) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_product: digit copy failed");
   return rh_std_ntt_launch(RP, c2P, c2P, npoly, LP, 0, false, false, 0);
+}
+
+// DecomposeSingleNTT for every digit: the basis extensions digit by digit, then ONE pipelined transform of all the Q blocks
+// (rh_std_ntt_fwd_digits) and one of all the P blocks (contiguous: beta * npoly polys of LP limbs).
+static int decompose_all_ntt(rh_bext* be, int levelQ, int levelP, int beta, const u64* cx, const u64* cxInv, u64* decQ, u64* decP, int npoly,
+                             bool copy_digit) {
+  rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
+  const int LQ = levelQ + 1, LP = levelP + 1, N = RQ->N;
+  const size_t wq = (size_t)npoly * LQ * N, wp = (size_t)npoly * LP * N;
+  if (!rh_can_ntt_digits(RQ)) {
+    for (int i = 0; i < beta; ++i)
+      if (int rc = decompose_single_ntt(be, levelQ, levelP, i, cx, cxInv, decQ + (size_t)i * wq, decP + (size_t)i * wp, npoly, copy_digit)) return rc;
+    return RH_OK;
+  }
+  for (int i = 0; i < beta; ++i)
+    if (int rc = rh_bext_decompose_and_split(be, levelQ, levelP, LP, i, cxInv, decQ + (size_t)i * wq, decP + (size_t)i * wp, npoly)) return rc;
+  if (int rc = rh_std_ntt_fwd_digits(RQ, decQ, wq, npoly, beta, LQ, LP)) return rc;
+  if (copy_digit)
+    for (int i = 0; i < beta; ++i) {
+      const int st = i * LP; int ed = st + LP; if (ed > LQ) ed = LQ;
+      if (ed > st && hipMemcpy2DAsync(decQ + (size_t)i * wq + (size_t)st * N, (size_t)LQ * N * 8, cx + (size_t)st * N, (size_t)LQ * N * 8,
+                                      (size_t)(ed - st) * N * 8, npoly, hipMemcpyDeviceToDevice, rh_stream(RQ)) != hipSuccess)
+        return rh_fail(RH_ERR_DEVICE, "gadget_product: digit copy failed");
+    }
+  if (rh_can_ntt_digits(RP)) return rh_std_ntt_fwd_digits(RP, decP, wp, npoly, beta, LP, 0);   // no limb skipped
+  return rh_std_ntt_launch(RP, decP, decP, beta * npoly, LP, 0, false, false, 0);
 }
 
 // the Reduce schedule of gadgetProductMultiplePLazy(Hoisted) (:166-187, :408-428)
@@ -149,9 +200,8 @@ extern "C" int rh_bext_decompose_ntt(rh_bext* be, int levelQ, int levelP, const 
   if (int rc = rh_std_ntt_launch(RQ, c2, other, npoly, LQ, 0, c2_is_ntt != 0, false, 0)) return rc;
   const u64* polyNTT = c2_is_ntt ? c2 : other;
   const u64* polyInv = c2_is_ntt ? other : c2;
-  for (int i = 0; i < beta; ++i)
-    if (int rc = decompose_single_ntt(be, levelQ, levelP, i, polyNTT, polyInv, decompQ + (size_t)i * wq, decompP + (size_t)i * wp, npoly)) return rc;
-  return RH_OK;
+  (void)wp;
+  return decompose_all_ntt(be, levelQ, levelP, beta, polyNTT, polyInv, decompQ, decompP, npoly, true);
 }
 
 // Evaluator.GadgetProductHoisted (:326-349) = gadgetProductMultiplePLazyHoisted (:373-429) + ModDown NTT->NTT (:33-46).
@@ -227,8 +277,7 @@ static int gadget_product_impl(rh_bext* be, int levelQ, int levelP, const uint64
   // ctQP.IsNTT: cxNTT = cx, cxInvNTT = INTT(cx) (:134-138); else cxInvNTT = cx, cxNTT = NTT(cx) (:139-143)
   if (int rc = rh_std_ntt_launch(RQ, cx, other, npoly, LQ, 0, is_ntt, false, 0)) return rc;
   const u64* cxNTT = is_ntt ? cx : other; const u64* cxInv = is_ntt ? other : cx;
-  for (int i = 0; i < beta; ++i)
-    if (int rc = decompose_single_ntt(be, levelQ, levelP, i, cxNTT, cxInv, decQ + (size_t)i * wq, decP + (size_t)i * wp, npoly, false)) return rc;
+  if (int rc = decompose_all_ntt(be, levelQ, levelP, beta, cxNTT, cxInv, decQ, decP, npoly, false)) return rc;
   if (!is_ntt) return hoisted_tail(be, levelQ, levelP, decQ, decP, evkQ, evkP, beta_key, ct0, ct1, npoly, cxNTT, nullptr, nullptr, nullptr, nullptr, false);
   if (!add0 && !add1) return hoisted_tail(be, levelQ, levelP, decQ, decP, evkQ, evkP, beta_key, ct0, ct1, npoly, cx);
   u64 *acc0, *acc1;                                  // accumulate beside the outputs: they may alias the addends (or cx)

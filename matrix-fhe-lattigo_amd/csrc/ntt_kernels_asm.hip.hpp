@@ -13,10 +13,13 @@
 RH_DEV u32 uni32(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
 RH_DEV u64 uni64(u64 x) { return ((u64)uni32((u32)(x >> 32)) << 32) | uni32((u32)x); }
 
+// gap_len > 0: the L transformed rows of a poly skip the limbs [gap0, gap0 + gap_len) of its Ls rows (the digit's own limbs of a
+// hybrid key-switch decomposition): row l is limb l + (l >= gap0 ? gap_len : 0)
 RH_DEV void fwd_tile_asm_body(u64* lds, const u32 b, const u64* in, u64* out, const tw2* __restrict__ twk,
-                              const LimbConsts* __restrict__ consts, int L, int logN, int npoly, int Ls = 0) {
+                              const LimbConsts* __restrict__ consts, int L, int logN, int npoly, int Ls = 0, u32 gap0 = 0, u32 gap_len = 0) {
   if (Ls == 0) Ls = L;                     // rows per poly of the block (>= L)
-  const u32 limb = b % (u32)L;
+  const u32 lrow = b % (u32)L;
+  const u32 limb = lrow + (lrow >= gap0 ? gap_len : 0u);
   const u32 r = b / (u32)L;
   const u32 poly = r % (u32)npoly;
   const u32 tile = r / (u32)npoly;
@@ -44,11 +47,12 @@ constexpr bool has_asm_cols(int S1) { return S1 >= 2 && S1 <= 4; }
                [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4) : NTT_TILE_ASM_CLOBBERS)
 template <int S1>
 RH_DEV void fwd_cols_asm_body(const u32 b, const u64* in, u64* out, const tw2* __restrict__ twn,
-                              const LimbConsts* __restrict__ consts, int L, int Ls = 0) {
+                              const LimbConsts* __restrict__ consts, int L, int Ls = 0, u32 gap0 = 0, u32 gap_len = 0) {
   if (Ls == 0) Ls = L;                     // rows per poly of the block (>= L)
   static_assert(has_asm_cols(S1), "asm column stages exist for S1 = 2..4");
   constexpr int logN = LT + S1;
-  const u32 limb = b % (u32)L;
+  const u32 lrow = b % (u32)L;
+  const u32 limb = lrow + (lrow >= gap0 ? gap_len : 0u);         // see fwd_tile_asm_body
   const u32 r = b / (u32)L;
   const size_t base = (((size_t)(r >> 4) * Ls + limb) << logN) + (r & 15) * 256;
   const u64 pin = uni64((u64)(size_t)(in + base));
@@ -131,6 +135,18 @@ ntt_fwd_fused_asm(const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n
   __shared__ u64 lds[LDS_WORDS];
   if (blockIdx.x < n1) fwd_cols_best<S1, ASMCOLS>(blockIdx.x, in1, out1, twn, consts, L, logN);
   if (blockIdx.x < n2) fwd_tile_asm_body(lds, blockIdx.x, data2, data2, twk, consts, L, logN, npoly2);
+}
+
+// The same pipeline over the digit blocks of a hybrid key-switch decomposition (rh_std_ntt_fwd_digits): launch j runs the
+// column stages of digit j's non-digit limbs and the tile stages of digit j-1's; each digit skips its own limbs (GapRows).
+struct GapRows { int L, Ls; u32 gap0, gap_len; };
+template <int S1>
+__global__ void __launch_bounds__(256)
+ntt_fwd_fused_gap_asm(u64* data1, unsigned n1, GapRows g1, u64* data2, unsigned n2, int npoly2, GapRows g2,
+                      const tw2* __restrict__ twn, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts) {
+  __shared__ u64 lds[LDS_WORDS];
+  if (blockIdx.x < n1) fwd_cols_asm_body<S1>(blockIdx.x, data1, data1, twn, consts, g1.L, g1.Ls, g1.gap0, g1.gap_len);
+  if (blockIdx.x < n2) fwd_tile_asm_body(lds, blockIdx.x, data2, data2, twk, consts, g2.L, LT + S1, npoly2, g2.Ls, g2.gap0, g2.gap_len);
 }
 
 // ---- inverse: first 12 stages (t = 1..2048) on a 4096-tile, values leave < 4q (N^-1 is applied by ntt_inv_cols).

@@ -113,12 +113,17 @@ class Evaluator:
     def BaseRNSDecompositionVectorSize(self, levelQ, levelP):
         return (levelQ + levelP + 1) // (levelP + 1)                  # core/rlwe/params.go:635-642
 
-    def DecomposeNTT(self, levelQ, levelP, c2, c2IsNTT):
-        """(:431-453) -> (decompQ, decompP): digit i of poly k is row i*npoly + k of each block"""
+    def DecomposeNTT(self, levelQ, levelP, c2, c2IsNTT, decompQP=None):
+        """(:431-453) -> (decompQ, decompP): digit i of poly k is row i*npoly + k of each block.  `decompQP` is the
+        caller's buffer pair, as in the reference (its BuffDecompQP argument); without it the blocks are allocated here."""
         beta = self.BaseRNSDecompositionVectorSize(levelQ, levelP)
         rq, rp = self.ringQ.AtLevel(levelQ), self.ringP.AtLevel(levelP)
         self._rows(levelQ, c2)
-        dq, dp = DevicePoly(rq, beta * c2.npoly, levelQ + 1), DevicePoly(rp, beta * c2.npoly, levelP + 1)
+        if decompQP is None:
+            decompQP = (DevicePoly(rq, beta * c2.npoly, levelQ + 1), DevicePoly(rp, beta * c2.npoly, levelP + 1))
+        dq, dp = decompQP
+        if (dq.npoly, dq.limbs, dp.npoly, dp.limbs) != (beta * c2.npoly, levelQ + 1, beta * c2.npoly, levelP + 1):
+            raise RingHipError("DecomposeNTT: decompQP must hold %d polys of %d and %d limbs" % (beta * c2.npoly, levelQ + 1, levelP + 1))
         _check(lib().rh_bext_decompose_ntt(self.be._h, levelQ, levelP, c2.ptr, 1 if c2IsNTT else 0, dq.ptr, dp.ptr, c2.npoly))
         return dq, dp
 

@@ -18,7 +18,8 @@ def oracle_gadget_product(oracle, rh, N, Q, P, levelQ, levelP, cx, evkQ, evkP):
     return compose.gadget_product(N, Q, P, levelQ, levelP, cx, evkQ, evkP)
 
 
-@pytest.mark.parametrize("N,nq,np_,levelQ,levelP", [(64, 6, 2, 5, 1), (8192, 8, 3, 7, 2), (4096, 24, 6, 23, 5), (64, 9, 2, 6, 1), (8192, 9, 3, 6, 2), (8192, 8, 3, 7, 1), (4096, 7, 4, 3, 2)])
+@pytest.mark.parametrize("N,nq,np_,levelQ,levelP", [(64, 6, 2, 5, 1), (8192, 8, 3, 7, 2), (4096, 24, 6, 23, 5), (64, 9, 2, 6, 1), (8192, 9, 3, 6, 2), (8192, 8, 3, 7, 1), (4096, 7, 4, 3, 2),
+                                                   (16384, 8, 3, 6, 2), (16384, 4, 4, 3, 3), (65536, 5, 2, 4, 1)])
 def test_gadget_product_vs_oracle_composition(rh, oracle, N, nq, np_, levelQ, levelP):
     Q, P = QI60[:nq], PI60[:np_]
     rq, rp = rh.Ring(N, Q), rh.Ring(N, P)

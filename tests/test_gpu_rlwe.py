@@ -23,7 +23,8 @@ def make_case(rh, N, nq, np_, npoly, seed):
     return Q, P, rq, rp, beta, evkQ, evkP, c0, c1
 
 
-@pytest.mark.parametrize("N,nq,np_", [(64, 6, 2), (4096, 7, 3), (8192, 5, 2)])
+# N >= 2^14: all digit blocks transformed by one pipelined stream of launches (rh_std_ntt_fwd_digits), (7, 3): digits of 3, 3, 1 limbs
+@pytest.mark.parametrize("N,nq,np_", [(64, 6, 2), (4096, 7, 3), (8192, 5, 2), (16384, 7, 3), (16384, 6, 2), (32768, 5, 2)])
 def test_hoisted_equals_direct_and_oracle(rh, oracle, N, nq, np_):
     Q, P, rq, rp, beta, evkQ, evkP, _c0, cx = make_case(rh, N, nq, np_, 2, N + nq)
     ev = rh.rlwe.Evaluator(rq, rp)

@@ -28,6 +28,16 @@ for _ in range(3): f()
 e1.record(stream); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 3
 print("span_rows", span, "batch", B, "ms", round(ms, 3), "keyswitch/s", round(B / ms * 1e3))
+if os.environ.get("RH_KS_AB"):          # same-box A/B of a ring tuning key: RH_KS_AB=key
+    key = os.environ["RH_KS_AB"]
+    for rep in range(3):
+        for val in [int(v) for v in os.environ.get('RH_KS_AB_VALS', '0,1').split(',')]:
+            rq.set_tuning(key, val); rp.set_tuning(key, val)
+            f(); torch.cuda.synchronize()
+            e0.record(stream)
+            for _ in range(5): f()
+            e1.record(stream); torch.cuda.synchronize()
+            print("  %s=%d ms %.3f" % (key, val, e0.elapsed_time(e1) / 5))
 if len(sys.argv) > 3:
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):

@@ -24,7 +24,7 @@ write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"units": "bytes per launch", "corrections": "FETCH_SIZE KiB x2 (gfx950), WRITE_SIZE KiB x1", "kernels": {}}
 total = 0.0
 for k in sorted(set(fetch) | set(write)):
-    if "ntt" not in k and "vec_op" not in k and "bext" not in k:
+    if not any(t in k for t in ("ntt", "vec_op", "bext", "gadget", "perm", "automorphism", "rescale")):
         continue
     f = fetch.get(k, 0.0) * 1024 * 2
     w = write.get(k, 0.0) * 1024
