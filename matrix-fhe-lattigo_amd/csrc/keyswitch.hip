@@ -52,20 +52,22 @@ int rh_gadget_mac(rh_ring* r, const u64* c2, const u64* e0, const u64* e1, u64* 
 // BETA > 0: the digit count at compile time -- the 3 * BETA 16-byte loads of an element pair are issued before the first multiply.
 // Not limited by the vector ALUs (a variant with ONE Montgomery reduction per output, 0.4 x the instructions, ran 8 % slower at
 // 68 VGPRs) nor by key re-reads (PMC: fetch + write = the algorithmic 3.1 GB per launch): 4.8 TB/s over 4 + 2 streams.
-template <int BETA>
+template <int BETA, int PP>
 __global__ void __launch_bounds__(256)
 gadget_mac_all_kernel(const u64* c2, size_t digit_stride, const u64* __restrict__ evk, size_t evk_stride, int beta, int overf,
                       u64* acc0, u64* acc1, unsigned n, const LimbConsts* __restrict__ consts, int L, int npoly,
                       const u64* cx, int digit_limbs) {   // cx != null: limb l of digit l / digit_limbs is read from cx (:467-468), not from c2
-  const u32 poly = blockIdx.x % (u32)npoly, limb = blockIdx.x / (u32)npoly;
+  // PP polys per workgroup (BETA > 0): the 2 * BETA key words of an element pair are loaded once and used for PP polys
+  const u32 groups = ((u32)npoly + PP - 1) / PP;
+  const u32 poly0 = (blockIdx.x % groups) * PP, limb = blockIdx.x / groups;
   const LimbConsts c = consts[limb];
-  const size_t ro = ((size_t)poly * L + limb) * n, eo = (size_t)limb * n;
+  const size_t eo = (size_t)limb * n;
   const unsigned npairs = n >> 1;
   const unsigned per = (npairs + gridDim.y - 1) / gridDim.y;        // a contiguous run of the row per workgroup
   const unsigned lim = min(npairs, (blockIdx.y + 1) * per);
   for (unsigned i = blockIdx.y * per + threadIdx.x; i < lim; i += blockDim.x) {
-    ulonglong2 a = {0, 0}, b = {0, 0};
-    int red = 0;
+    ulonglong2 a, b;
+    int red;
     auto term = [&](const ulonglong2& x, const ulonglong2& k0, const ulonglong2& k1) {
       a.x += mred_lazy(k0.x, x.x, c.q, c.qinv); a.y += mred_lazy(k0.y, x.y, c.q, c.qinv);
       b.x += mred_lazy(k1.x, x.x, c.q, c.qinv); b.y += mred_lazy(k1.y, x.y, c.q, c.qinv);
@@ -76,27 +78,39 @@ gadget_mac_all_kernel(const u64* c2, size_t digit_stride, const u64* __restrict_
       ++red;
     };
     auto ld = [&](const u64* p) { return *reinterpret_cast<const ulonglong2*>(p + 2 * (size_t)i); };
-    auto xsrc = [&](int d) { return (cx && (int)limb / digit_limbs == d) ? cx + ro : c2 + (size_t)d * digit_stride + ro; };
+    auto finish = [&](size_t ro) {
+      if (red % overf != 0) {
+        a.x = bred_add(a.x, c.q, c.bred0); a.y = bred_add(a.y, c.q, c.bred0);
+        b.x = bred_add(b.x, c.q, c.bred0); b.y = bred_add(b.y, c.q, c.bred0);
+      }
+      *reinterpret_cast<ulonglong2*>(acc0 + ro + 2 * (size_t)i) = a;
+      *reinterpret_cast<ulonglong2*>(acc1 + ro + 2 * (size_t)i) = b;
+    };
     if constexpr (BETA > 0) {
-      ulonglong2 x[BETA], k0[BETA], k1[BETA];
+      ulonglong2 k0[BETA], k1[BETA];
 #pragma unroll
       for (int d = 0; d < BETA; ++d) {
-        x[d] = ld(xsrc(d));
         k0[d] = ld(evk + ((size_t)d * 2) * evk_stride + eo);
         k1[d] = ld(evk + ((size_t)d * 2 + 1) * evk_stride + eo);
       }
+      for (u32 pp = 0; pp < (u32)PP && poly0 + pp < (u32)npoly; ++pp) {
+        const size_t ro = ((size_t)(poly0 + pp) * L + limb) * n;
+        ulonglong2 x[BETA];
 #pragma unroll
-      for (int d = 0; d < BETA; ++d) term(x[d], k0[d], k1[d]);
+        for (int d = 0; d < BETA; ++d) x[d] = ld((cx && (int)limb / digit_limbs == d) ? cx + ro : c2 + (size_t)d * digit_stride + ro);
+        a = {0, 0}; b = {0, 0}; red = 0;
+#pragma unroll
+        for (int d = 0; d < BETA; ++d) term(x[d], k0[d], k1[d]);
+        finish(ro);
+      }
     } else {
+      const size_t ro = ((size_t)poly0 * L + limb) * n;               // PP == 1
+      a = {0, 0}; b = {0, 0}; red = 0;
       for (int d = 0; d < beta; ++d)
-        term(ld(xsrc(d)), ld(evk + ((size_t)d * 2) * evk_stride + eo), ld(evk + ((size_t)d * 2 + 1) * evk_stride + eo));
+        term(ld((cx && (int)limb / digit_limbs == d) ? cx + ro : c2 + (size_t)d * digit_stride + ro),
+             ld(evk + ((size_t)d * 2) * evk_stride + eo), ld(evk + ((size_t)d * 2 + 1) * evk_stride + eo));
+      finish(ro);
     }
-    if (red % overf != 0) {
-      a.x = bred_add(a.x, c.q, c.bred0); a.y = bred_add(a.y, c.q, c.bred0);
-      b.x = bred_add(b.x, c.q, c.bred0); b.y = bred_add(b.y, c.q, c.bred0);
-    }
-    *reinterpret_cast<ulonglong2*>(acc0 + ro + 2 * (size_t)i) = a;
-    *reinterpret_cast<ulonglong2*>(acc1 + ro + 2 * (size_t)i) = b;
   }
 }
 
@@ -104,14 +118,17 @@ static int mac_all(rh_ring* r, const u64* c2, size_t digit_stride, const u64* ev
                    const u64* cx = nullptr, int digit_limbs = 1) {
   const unsigned n = (unsigned)r->N;
   unsigned chunks = (n / 2 + 1023) / 1024; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
-#define RH_MAC_ALL(B) gadget_mac_all_kernel<B><<<dim3((unsigned)npoly * L, chunks), 256, 0, rh_stream(r)>>>( \
+  const int PPE = npoly >= 8 ? 4 : 1;             // polys per workgroup (same-box A/B at batch 64: 1 / 2 / 4 / 8 -> 9.04 / 8.93 / 8.89 / 8.92 ms per product)
+#define RH_MAC_ALL(B, PP) gadget_mac_all_kernel<B, PP><<<dim3(((unsigned)npoly + PP - 1) / PP * L, chunks), 256, 0, rh_stream(r)>>>( \
     c2, digit_stride, evk, (size_t)r->L * n, beta, overf, a0, a1, n, r->d_consts, L, npoly, cx, digit_limbs)
+#define RH_MAC_PP(B) do { if (PPE == 4) RH_MAC_ALL(B, 4); else RH_MAC_ALL(B, 1); } while (0)
   switch (beta) {
-    case 2: RH_MAC_ALL(2); break;
-    case 3: RH_MAC_ALL(3); break;
-    case 4: RH_MAC_ALL(4); break;
-    default: RH_MAC_ALL(0);
+    case 2: RH_MAC_PP(2); break;
+    case 3: RH_MAC_PP(3); break;
+    case 4: RH_MAC_PP(4); break;
+    default: RH_MAC_ALL(0, 1);
   }
+#undef RH_MAC_PP
 #undef RH_MAC_ALL
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_mac_all_kernel launch failed: %s", hipGetErrorString(e));
