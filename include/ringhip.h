@@ -109,6 +109,12 @@ int rh_ntt_backward_lazy(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2)
 int rh_ring_ntt(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int lazy);
 int rh_ring_intt(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int lazy);
 
+/* Ring.NTT on several blocks in one call (device-API extension: e.g. both operands of a product, schemes/ckks/evaluator.go:821-834
+ * after the two NTTs).  in[k] / out[k]: block k, npoly[k] polys of (level+1) limbs; each pair may alias.  Same results as nblocks
+ * rh_ring_ntt calls; for two-pass standard rings (N >= 8192) the software pipeline of the fused launches runs through the block
+ * boundaries.  The pointer arrays are host arrays of device pointers, read before the call returns. */
+int rh_ring_ntt_many(rh_ring* r, const uint64_t* const* in_dev, uint64_t* const* out_dev, const int* npoly, int nblocks, int level);
+
 /* The same on blocks that carry MORE limbs per poly than the level they are used at (in_rows / out_rows limbs per poly, each
  * >= level+1): ring.AtLevel(level) on max-level polys and buffers (ring/ring.go:192-213), the idiomatic use inside the reference's
  * evaluators.  Limbs 0..level of every poly are transformed, the others are untouched.  With rows == level+1 this IS rh_ring_ntt /

@@ -123,6 +123,15 @@ class Ring {
   void NTTLazy(const Poly& p1, Poly& p2) const { check(rh_ring_ntt_rows(h_.get(), p1.data(), p1.limbs(), p2.data(), p2.limbs(), p1.npoly(), level_, 1)); }
   void INTT(const Poly& p1, Poly& p2) const { check(rh_ring_intt_rows(h_.get(), p1.data(), p1.limbs(), p2.data(), p2.limbs(), p1.npoly(), level_, 0)); }
   void INTTLazy(const Poly& p1, Poly& p2) const { check(rh_ring_intt_rows(h_.get(), p1.data(), p1.limbs(), p2.data(), p2.limbs(), p1.npoly(), level_, 1)); }
+  // Ring.NTT on several blocks in one call (rh_ring_ntt_many): every poly of a block at this view's level (limbs() == level + 1)
+  void NTTMany(const std::vector<std::pair<const Poly*, Poly*>>& blocks) const {
+    std::vector<const uint64_t*> in; std::vector<uint64_t*> out; std::vector<int> cnt;
+    for (const auto& b : blocks) {
+      if (b.first->limbs() != level_ + 1 || b.second->limbs() != level_ + 1) throw std::invalid_argument("NTTMany: blocks must hold level+1 limbs per poly");
+      in.push_back(b.first->data()); out.push_back(b.second->data()); cnt.push_back(b.first->npoly());
+    }
+    check(rh_ring_ntt_many(h_.get(), in.data(), out.data(), cnt.data(), (int)in.size(), level_));
+  }
 
   // ring/operations.go -> ring/vec_ops.go
   void VecOp(int op, const Poly* p1, const Poly* p2, Poly& p3, const uint64_t* s0 = nullptr, const uint64_t* s1 = nullptr) const {

@@ -392,18 +392,24 @@ static void launch_fused(rh_ring* r, const u64* in1, u64* out1, unsigned n1, u64
 }
 
 // Forward canonical transform of a large batch: software pipeline over spans of `chunk` polys in ONE stream; launch j
-// runs the column stages of span j fused with the tile stages of span j-1 (ntt_fwd_fused).
-static int std_ntt_fwd_pipelined(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, int chunk) {
+// runs the column stages of span j fused with the tile stages of span j-1 (ntt_fwd_fused).  The spans may come from several
+// blocks (rh_ring_ntt_many): the pipeline runs through the block boundaries, so only the first launch of the first block and
+// the last launch of the last block are not fused.
+struct NttSeg { const u64* in; u64* out; int npoly; };
+static int std_ntt_fwd_pipelined_segs(rh_ring* r, const NttSeg* segs, int nseg, int Lrows, int limb0, int chunk) {
   (void)hipGetLastError();
   const int N = r->N, S1 = r->logN - LT;
   const size_t toff = (size_t)limb0 * N, stride = (size_t)Lrows * N;
   const LimbConsts* c = r->d_consts + limb0;
-  const int nspans = (npoly + chunk - 1) / chunk;
+  std::vector<NttSeg> spans;
+  for (int k = 0; k < nseg; ++k)
+    for (int p = 0; p < segs[k].npoly; p += chunk)
+      spans.push_back(NttSeg{segs[k].in + (size_t)p * stride, segs[k].out + (size_t)p * stride, segs[k].npoly - p < chunk ? segs[k].npoly - p : chunk});
+  const int nspans = (int)spans.size();
   for (int j = 0; j <= nspans; ++j) {
-    const int p1 = j * chunk, n1p = j < nspans ? ((npoly - p1 < chunk) ? npoly - p1 : chunk) : 0;
-    const int p2 = (j - 1) * chunk, n2p = j >= 1 ? ((npoly - p2 < chunk) ? npoly - p2 : chunk) : 0;
+    const int n1p = j < nspans ? spans[j].npoly : 0, n2p = j >= 1 ? spans[j - 1].npoly : 0;
     const unsigned n1 = (unsigned)n1p * Lrows * 16, n2 = ((unsigned)n2p * Lrows) << S1;
-    const u64* i1 = in + (size_t)p1 * stride; u64* o1 = out + (size_t)p1 * stride; u64* d2 = out + (size_t)p2 * stride;
+    const u64* i1 = j < nspans ? spans[j].in : nullptr; u64* o1 = j < nspans ? spans[j].out : nullptr; u64* d2 = j >= 1 ? spans[j - 1].out : nullptr;
     switch (S1) {
       case 1: launch_fused<1>(r, i1, o1, n1, d2, n2, n2p, toff, c, Lrows); break;
       case 2: launch_fused<2>(r, i1, o1, n1, d2, n2, n2p, toff, c, Lrows); break;
@@ -413,6 +419,10 @@ static int std_ntt_fwd_pipelined(rh_ring* r, const u64* in, u64* out, int npoly,
     }
   }
   return check_launch("ntt_fwd_fused");
+}
+static int std_ntt_fwd_pipelined(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, int chunk) {
+  const NttSeg seg{in, out, npoly};
+  return std_ntt_fwd_pipelined_segs(r, &seg, 1, Lrows, limb0, chunk);
 }
 
 template <int S1>
@@ -620,6 +630,29 @@ static int ntt_batch(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, i
 }
 extern "C" int rh_ring_ntt(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, int lazy) { return ntt_batch(r, in, out, npoly, level, false, lazy != 0); }
 extern "C" int rh_ring_intt(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, int lazy) { return ntt_batch(r, in, out, npoly, level, true, lazy != 0); }
+// Ring.NTT on several blocks in one call (device-API extension; e.g. both operands of a product): for two-pass standard rings the
+// software pipeline of the fused launches runs through all the blocks; otherwise the blocks are transformed one after the other.
+extern "C" int rh_ring_ntt_many(rh_ring* r, const uint64_t* const* in, uint64_t* const* out, const int* npoly, int nblocks, int level) {
+  if (!r || !in || !out || !npoly || nblocks < 0) return rh_fail(RH_ERR_ARG, "ntt_many: bad argument");
+  if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "ntt_many: level %d out of range [0,%d)", level, r->L);
+  long total = 0;
+  for (int k = 0; k < nblocks; ++k) {
+    if (!in[k] || !out[k] || npoly[k] < 0) return rh_fail(RH_ERR_ARG, "ntt_many: block %d: null pointer or npoly < 0", k);
+    total += npoly[k];
+  }
+  (void)hipSetDevice(r->device);
+  const int Lrows = level + 1;
+  int chunk = r->chunk_polys;
+  if (chunk < 0) chunk = r->auto_span_rows / Lrows > 0 ? r->auto_span_rows / Lrows : 1;
+  if (r->kind == RH_RING_STANDARD && r->logN > LT && chunk > 0 && total > chunk) {
+    std::vector<NttSeg> segs;
+    for (int k = 0; k < nblocks; ++k) if (npoly[k] > 0) segs.push_back(NttSeg{in[k], out[k], npoly[k]});
+    return std_ntt_fwd_pipelined_segs(r, segs.data(), (int)segs.size(), Lrows, 0, chunk);
+  }
+  for (int k = 0; k < nblocks; ++k)
+    if (int rc = ntt_batch(r, in[k], out[k], npoly[k], level, false, false)) return rc;
+  return RH_OK;
+}
 // ---- views at a lower level of blocks allocated with MORE limbs per poly (ring.AtLevel(level) on max-level polys and buffers,
 // ring/ring.go:192-213: the idiomatic use inside the reference's evaluators).  The batched kernels stride blocks by level+1 rows; a
 // block with `rows` > level+1 limbs per poly keeps each poly's leading limbs contiguous, so such a call runs poly by poly (npoly

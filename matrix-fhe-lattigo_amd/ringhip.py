@@ -90,6 +90,7 @@ def lib():
         "rh_ring_ntt_rows": (i, [vp, vp, i, vp, i, i, i, i]), "rh_ring_intt_rows": (i, [vp, vp, i, vp, i, i, i, i]),
         "rh_ring_vec_op_rows": (i, [vp, i, vp, i, vp, i, vp, i, i, i, U64P, U64P]),
         "rh_ring_intt_mul": (i, [vp, vp, vp, vp, i, i]),
+        "rh_ring_ntt_many": (i, [vp, vp, vp, vp, i, i]),
         "rh_ring_ntt3n_reorder": (i, [vp, vp, vp, i, i, i]),
         "rh_ring_set_tuning": (i, [vp, C.c_char_p, C.c_long]),
         "rh_ring_vec_op": (i, [vp, i, vp, vp, vp, i, i, U64P, U64P]),
@@ -329,6 +330,15 @@ class Ring:
     def NTT3NReorder(self, p1, p2, to_reference=True):
         """3N rings: NTT-domain block between block order (tuning ntt3n_block_order) and the Go transformer's order; out of place"""
         self._chk(p1, p2); _check(lib().rh_ring_ntt3n_reorder(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 1 if to_reference else 0))
+
+    def NTTMany(self, pairs):
+        """Ring.NTT(p1, p2) for every (p1, p2) of `pairs` in one call (rh_ring_ntt_many): one software pipeline through all blocks"""
+        n = len(pairs)
+        for p1, p2 in pairs:
+            self._chk(p1, p2)
+        ins = (C.c_void_p * n)(*[p1.ptr for p1, _ in pairs]); outs = (C.c_void_p * n)(*[p2.ptr for _, p2 in pairs])
+        cnt = (C.c_int * n)(*[p1.npoly for p1, _ in pairs])
+        _check(lib().rh_ring_ntt_many(self._h, ins, outs, cnt, n, self.level))
 
     def INTTMul(self, p1, p2, p3):
         """p3 = INTT(p1 . p2) for NTT-domain p1, p2: the values of MForm(p1, t); MulCoeffsMontgomery(t, p2, p3); INTT(p3, p3)

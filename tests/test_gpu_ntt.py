@@ -198,6 +198,34 @@ def test_fused_pipeline_spans_give_identical_results(rh, oracle, logN, chunk):
     ring.close()
 
 
+@pytest.mark.parametrize("logN,chunk", [(10, -1), (13, 2), (15, 3), (16, -1)])
+def test_ntt_many_blocks_equal_separate_calls(rh, oracle, logN, chunk):
+    # rh_ring_ntt_many: one software pipeline through several blocks (in place and out of place) == one Ring.NTT per block == oracle
+    N, mods = 1 << logN, QI60[:3]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(100 + logN)
+    sizes = [5, 1, 4]
+    blocks = [np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(b)]) for b in sizes]
+    refs = []
+    for a in blocks:
+        p, o = rh.DevicePoly.from_numpy(ring, a), ring.NewPoly(a.shape[0])
+        ring.NTT(p, o); refs.append(o.numpy())
+    if chunk > 0:
+        ring.set_tuning("chunk_polys", chunk)
+    else:
+        ring.set_tuning("auto_span_rows", 6)          # spans of 2 polys: 10 polys in three blocks are pipelined
+    ps = [rh.DevicePoly.from_numpy(ring, a) for a in blocks]
+    outs = [ps[0], ring.NewPoly(sizes[1]), ps[2]]     # blocks 0 and 2 in place, block 1 out of place
+    ring.NTTMany(list(zip(ps, outs)))
+    for o, r in zip(outs, refs):
+        assert np.array_equal(o.numpy(), r)
+    srs = [oracle.SubRingConsts(N, q) for q in mods]
+    assert np.array_equal(outs[2].numpy()[3, 2], oracle.ntt(blocks[2][3, 2], srs[2]))
+    assert np.array_equal(ps[1].numpy(), blocks[1])   # the out-of-place input is untouched
+    ring.NTTMany([])                                  # no block: nothing to do
+    ring.close()
+
+
 @pytest.mark.parametrize("logN", [12, 13, 16])
 def test_asm_tile_kernel_equals_cxx_kernel(rh, oracle, logN):
     # the hand-scheduled forward tile kernel (default) and the C++ one must agree bit for bit, incl. worst-case inputs

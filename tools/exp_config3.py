@@ -13,14 +13,17 @@ qs = torch.tensor(QI60[:L], dtype=torch.int64, device=dev).view(1, L, 1)
 mk = lambda: torch.randint(0, 1 << 62, (B, L, N), dtype=torch.int64, device=dev) % qs
 a, b = mk(), mk()
 pa, pb = rh.DevicePoly.from_torch(ring, a), rh.DevicePoly.from_torch(ring, b)
-def f():
+def f_sep():
     ring.NTT(pa, pa); ring.NTT(pb, pb); ring.INTTMul(pa, pb, pa)
-for span in (512, 1024, 2048, 4096, 8192):
+def f_many():
+    ring.NTTMany([(pa, pa), (pb, pb)]); ring.INTTMul(pa, pb, pa)
+for span in (1024, 2048, 4096):
     ring.set_tuning("auto_span_rows", span)
-    f(); f(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(10): f()
-    e1.record(stream); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
-    print("span_rows", span, "ms", round(ms, 3), "polymul/s", round(B / ms * 1e3))
+    for name, f in (("two NTT calls", f_sep), ("NTTMany", f_many), ("two NTT calls", f_sep), ("NTTMany", f_many)):
+        f(); f(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(10): f()
+        e1.record(stream); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        print("span_rows", span, name, "ms", round(ms, 3), "polymul/s", round(B / ms * 1e3))
