@@ -492,11 +492,12 @@ int rh_std_ntt_fwd_strided(rh_ring* r, u64* data, int npoly, int Lrows, int limb
 // (DecomposeSingleNTT, core/rlwe/evaluator_gadget_product.go:455-478, for all digits at once): block j holds npoly polys
 // of LQ rows and its limbs [j*LP, min((j+1)*LP, LQ)) are left alone.  One software-pipelined stream of launches instead of
 // two strided transforms (before / after the digit's limbs) per digit.  Needs the hand-scheduled bodies (N = 2^14 .. 2^16).
+// lazy_out: the outputs stay < 8q, not canonical (for a consumer that reduces anyway, never for a caller-visible block).
 bool rh_can_ntt_digits(const rh_ring* r) {
   const int S1 = r->logN - LT;
   return r->kind == RH_RING_STANDARD && r->asm_tile && r->asm_cols && r->digit_pipeline && S1 >= 2 && S1 <= 4;
 }
-int rh_std_ntt_fwd_digits(rh_ring* r, u64* data, size_t digit_stride, int npoly, int beta, int LQ, int LP) {
+int rh_std_ntt_fwd_digits(rh_ring* r, u64* data, size_t digit_stride, int npoly, int beta, int LQ, int LP, bool lazy_out) {
   if (!rh_can_ntt_digits(r)) return rh_fail(RH_ERR_UNSUPPORTED, "digit-block transform needs the hand-scheduled bodies (2^14 <= N <= 2^16)");
   if (npoly <= 0 || beta <= 0) return RH_OK;
   (void)hipGetLastError();
@@ -516,11 +517,13 @@ int rh_std_ntt_fwd_digits(rh_ring* r, u64* data, size_t digit_stride, int npoly,
     if (!g1.L) g1.L = 1;
     if (!g2.L) g2.L = 1;
     u64* d1 = data + (size_t)(j < beta ? j : 0) * digit_stride; u64* d2 = data + (size_t)(j >= 1 ? j - 1 : 0) * digit_stride;
+#define RH_GAP(S, Z) ntt_fwd_fused_gap_asm<S, Z><<<grid, 256, 0, st>>>(d1, n1, g1, d2, n2, npoly, g2, r->d_tw_fwd, r->d_twk_fwd, r->d_consts)
     switch (S1) {
-      case 2: ntt_fwd_fused_gap_asm<2><<<grid, 256, 0, st>>>(d1, n1, g1, d2, n2, npoly, g2, r->d_tw_fwd, r->d_twk_fwd, r->d_consts); break;
-      case 3: ntt_fwd_fused_gap_asm<3><<<grid, 256, 0, st>>>(d1, n1, g1, d2, n2, npoly, g2, r->d_tw_fwd, r->d_twk_fwd, r->d_consts); break;
-      case 4: ntt_fwd_fused_gap_asm<4><<<grid, 256, 0, st>>>(d1, n1, g1, d2, n2, npoly, g2, r->d_tw_fwd, r->d_twk_fwd, r->d_consts); break;
+      case 2: if (lazy_out) RH_GAP(2, true); else RH_GAP(2, false); break;
+      case 3: if (lazy_out) RH_GAP(3, true); else RH_GAP(3, false); break;
+      case 4: if (lazy_out) RH_GAP(4, true); else RH_GAP(4, false); break;
     }
+#undef RH_GAP
   }
   return check_launch("ntt_fwd_fused_gap_asm");
 }

@@ -171,7 +171,10 @@ static int decompose_all_ntt(rh_bext* be, int levelQ, int levelP, int beta, cons
   }
   for (int i = 0; i < beta; ++i)
     if (int rc = rh_bext_decompose_and_split(be, levelQ, levelP, LP, i, cxInv, decQ + (size_t)i * wq, decP + (size_t)i * wp, npoly)) return rc;
-  if (int rc = rh_std_ntt_fwd_digits(RQ, decQ, wq, npoly, beta, LQ, LP)) return rc;
+  // internal product (copy_digit == false): the blocks feed the key multiply-accumulate only, whose MRedLazy takes any 64-bit
+  // operand and whose closing Reduce is canonical -- the transforms skip their final reduction (outputs < 8q)
+  const bool lazy = !copy_digit;
+  if (int rc = rh_std_ntt_fwd_digits(RQ, decQ, wq, npoly, beta, LQ, LP, lazy)) return rc;
   if (copy_digit)
     for (int i = 0; i < beta; ++i) {
       const int st = i * LP; int ed = st + LP; if (ed > LQ) ed = LQ;
@@ -179,7 +182,7 @@ static int decompose_all_ntt(rh_bext* be, int levelQ, int levelP, int beta, cons
                                       (size_t)(ed - st) * N * 8, npoly, hipMemcpyDeviceToDevice, rh_stream(RQ)) != hipSuccess)
         return rh_fail(RH_ERR_DEVICE, "gadget_product: digit copy failed");
     }
-  if (rh_can_ntt_digits(RP)) return rh_std_ntt_fwd_digits(RP, decP, wp, npoly, beta, LP, 0);   // no limb skipped
+  if (rh_can_ntt_digits(RP)) return rh_std_ntt_fwd_digits(RP, decP, wp, npoly, beta, LP, 0, lazy);   // no limb skipped
   return rh_std_ntt_launch(RP, decP, decP, beta * npoly, LP, 0, false, false, 0);
 }
 

@@ -15,6 +15,8 @@ RH_DEV u64 uni64(u64 x) { return ((u64)uni32((u32)(x >> 32)) << 32) | uni32((u32
 
 // gap_len > 0: the L transformed rows of a poly skip the limbs [gap0, gap0 + gap_len) of its Ls rows (the digit's own limbs of a
 // hybrid key-switch decomposition): row l is limb l + (l >= gap0 ? gap_len : 0)
+// LAZY: no final canonical reduction, outputs < 8q (internal consumers only)
+template <bool LAZY = false>
 RH_DEV void fwd_tile_asm_body(u64* lds, const u32 b, const u64* in, u64* out, const tw2* __restrict__ twk,
                               const LimbConsts* __restrict__ consts, int L, int logN, int npoly, int Ls = 0, u32 gap0 = 0, u32 gap_len = 0) {
   if (Ls == 0) Ls = L;                     // rows per poly of the block (>= L)
@@ -31,12 +33,13 @@ RH_DEV void fwd_tile_asm_body(u64* lds, const u32 b, const u64* in, u64* out, co
   const u64 nq = (u64)0 - q, nq2 = (u64)0 - 2 * q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
   const u32 lds_off = uni32((u32)(size_t)lds);
   const u32 tid = threadIdx.x;
-  asm volatile(NTT_TILE_ASM_BODY
-                 :
-                 : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw),
-                   [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)),
-                   [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4)
-                 : NTT_TILE_ASM_CLOBBERS);
+#define RH_TILE_FWD_ASM(BODY)                                                                                          \
+  asm volatile(BODY : : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw),             \
+               [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)), [nq0] "s"((u32)nq),                    \
+               [nq1] "s"((u32)(nq >> 32)), [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4) : NTT_TILE_ASM_CLOBBERS)
+  if constexpr (LAZY) RH_TILE_FWD_ASM(NTT_TILE_LAZY_ASM_BODY);
+  else RH_TILE_FWD_ASM(NTT_TILE_ASM_BODY);
+#undef RH_TILE_FWD_ASM
 }
 
 // column stages for N = 2^14 .. 2^16 (S1 = 2..4): hand-scheduled radix-2^S1 register round with wave-uniform twiddles;
@@ -140,13 +143,13 @@ ntt_fwd_fused_asm(const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n
 // The same pipeline over the digit blocks of a hybrid key-switch decomposition (rh_std_ntt_fwd_digits): launch j runs the
 // column stages of digit j's non-digit limbs and the tile stages of digit j-1's; each digit skips its own limbs (GapRows).
 struct GapRows { int L, Ls; u32 gap0, gap_len; };
-template <int S1>
+template <int S1, bool LAZY>
 __global__ void __launch_bounds__(256)
 ntt_fwd_fused_gap_asm(u64* data1, unsigned n1, GapRows g1, u64* data2, unsigned n2, int npoly2, GapRows g2,
                       const tw2* __restrict__ twn, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts) {
   __shared__ u64 lds[LDS_WORDS];
   if (blockIdx.x < n1) fwd_cols_asm_body<S1>(blockIdx.x, data1, data1, twn, consts, g1.L, g1.Ls, g1.gap0, g1.gap_len);
-  if (blockIdx.x < n2) fwd_tile_asm_body(lds, blockIdx.x, data2, data2, twk, consts, g2.L, LT + S1, npoly2, g2.Ls, g2.gap0, g2.gap_len);
+  if (blockIdx.x < n2) fwd_tile_asm_body<LAZY>(lds, blockIdx.x, data2, data2, twk, consts, g2.L, LT + S1, npoly2, g2.Ls, g2.gap0, g2.gap_len);
 }
 
 // ---- inverse: first 12 stages (t = 1..2048) on a 4096-tile, values leave < 4q (N^-1 is applied by ntt_inv_cols).

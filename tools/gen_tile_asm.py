@@ -350,7 +350,7 @@ def csub_all(const_name):
             emit("v_bfi_b32 v%d, v%d, v%d, v%d" % (X(kk) + 1, t.M, X(kk) + 1, t.T + 1))
 
 
-def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True, epilogue=None):
+def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True, epilogue=None, lazy_out=False):
     A0, A1, A2, A3 = ADDR, ADDR + 1, ADDR + 2, ADDR + 3
     emit("; ---- prologue: zero halves of the zero-extended pairs, addresses")
     if PRIO in (1, 2):
@@ -435,9 +435,10 @@ def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True, epilogue
     emit("; ---- canonical reduction: x < 8q -> [0,q)")
     if PRIO in (1, 3):
         emit("s_setprio 2")                                   # finish: reduce, transpose, store -> frees the CU slot sooner
-    csub_all("nq4")
-    csub_all("nq2")
-    csub_all("nq")
+    if not lazy_out:                                          # lazy_out: values leave < 8q (consumers that reduce anyway: the key
+        csub_all("nq4")                                       # multiply-accumulate of the gadget product takes any 64-bit operand)
+        csub_all("nq2")
+        csub_all("nq")
     for k in range(16):
         emit("ds_write_b64 v%d, %s offset:%d" % (A1, pair(X(k)), 8 * k))
     emit("s_waitcnt lgkmcnt(0)")
@@ -690,6 +691,9 @@ for s1 in (2, 3, 4):
     gen_cols_inv(s1)
     cols_inv[s1] = list(out)
     del out[:]
+gen(lazy_out=True)
+fwd_lazy = list(out)
+del out[:]
 gen(epilogue="submul")
 fwd_sm = list(out)
 del out[:]
@@ -704,7 +708,7 @@ inv_mul = list(out)
 clob_v = ", ".join('"v%d"' % i for i in range(NVGPR_USED))
 clob_s = ", ".join('"s%d"' % i for i in range(36, 100))
 text = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  forward: %d instructions, inverse: %d.\n" % (len(fwd), len(inv))
-text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_SUBMUL_ASM_BODY", fwd_sm) + render("NTT_TILE_SUBMUL_ADD_ASM_BODY", fwd_sma) + "".join(render("NTT_COLS%d_ASM_BODY" % (1 << k), cols[k]) + render("NTT_COLS%d_INV_ASM_BODY" % (1 << k), cols_inv[k]) for k in (2, 3, 4)) + render("NTT_TILE_INV_ASM_BODY", inv) + render("NTT_TILE_INV_MUL_ASM_BODY", inv_mul)
+text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_LAZY_ASM_BODY", fwd_lazy) + render("NTT_TILE_SUBMUL_ASM_BODY", fwd_sm) + render("NTT_TILE_SUBMUL_ADD_ASM_BODY", fwd_sma) + "".join(render("NTT_COLS%d_ASM_BODY" % (1 << k), cols[k]) + render("NTT_COLS%d_INV_ASM_BODY" % (1 << k), cols_inv[k]) for k in (2, 3, 4)) + render("NTT_TILE_INV_ASM_BODY", inv) + render("NTT_TILE_INV_MUL_ASM_BODY", inv_mul)
 text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v, clob_s)
 path = sys.argv[1] if len(sys.argv) > 1 else "ntt_tile_asm.inc"
 open(path, "w").write(text)
