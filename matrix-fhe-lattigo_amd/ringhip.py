@@ -460,6 +460,12 @@ class BasisExtender:
         """rlwe.Evaluator.GadgetProduct for NTT-domain cx; evk*_ptr: device pointers of the key blocks (see ringhip.h)"""
         _check(lib().rh_bext_gadget_product(self._h, levelQ, levelP, cx.ptr, evkQ_ptr, evkP_ptr, beta_key, ct0.ptr, ct1.ptr, cx.npoly))
 
+    def GadgetProductThenAdd(self, levelQ, levelP, cx, evkQ_ptr, evkP_ptr, beta_key, add0, add1, ct0, ct1):
+        """ct_c = add_c + GadgetProduct(cx)_c (rh_bext_gadget_product_then_add); add_c may be None and may alias ct_c"""
+        _check(lib().rh_bext_gadget_product_then_add(self._h, levelQ, levelP, cx.ptr, evkQ_ptr, evkP_ptr, beta_key,
+                                                     add0.ptr if add0 is not None else None, add1.ptr if add1 is not None else None,
+                                                     ct0.ptr, ct1.ptr, cx.npoly))
+
     def close(self):
         if getattr(self, "_h", None):
             lib().rh_bext_destroy(self._h)

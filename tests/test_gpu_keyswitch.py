@@ -6,7 +6,7 @@ parity needs no key generation.  End-to-end key-switch semantics are pinned only
 import numpy as np
 import pytest
 
-from conftest import QI60, PI60
+from conftest import QI60, PI60, uniform_mod
 
 pytestmark = pytest.mark.gpu
 
@@ -42,6 +42,36 @@ def test_gadget_product_vs_oracle_composition(rh, oracle, N, nq, np_, levelQ, le
         e0, e1 = oracle_gadget_product(oracle, rh, N, Q, P, levelQ, levelP, cx[k], evkQ, evkP)
         assert np.array_equal(g0[k], e0)
         assert np.array_equal(g1[k], e1)
+    be.close(); rq.close(); rp.close()
+
+
+@pytest.mark.parametrize("N,nq,np_,npoly", [(2048, 4, 2, 34), (16384, 6, 2, 32)])
+def test_gadget_product_larger_batch_and_aliased_addends(rh, oracle, N, nq, np_, npoly):
+    # a batch large enough for the multi-poly key MAC workgroups and the pipelined digit transforms; repeated calls reuse the scratch;
+    # the product with addends that alias the outputs
+    Q, P = QI60[:nq], PI60[:np_]
+    rq, rp = rh.Ring(N, Q), rh.Ring(N, P)
+    be = rh.BasisExtender(rq, rp)
+    rng = np.random.default_rng(7 * N + npoly)
+    levelQ, levelP = nq - 1, np_ - 1
+    beta = (levelQ + levelP + 1) // (levelP + 1)
+    cx = np.stack([np.stack([uniform_mod(rng, q, N) for q in Q]) for _ in range(npoly)])
+    add = np.stack([np.stack([uniform_mod(rng, q, N) for q in Q]) for _ in range(npoly)])
+    evkQ, evkP = _rand_key(rng, beta, Q, N), _rand_key(rng, beta, P, N)
+    dq = rh.DevicePoly.from_numpy(rq, evkQ.reshape(beta * 2, nq, N)); dp = rh.DevicePoly.from_numpy(rp, evkP.reshape(beta * 2, np_, N))
+    pcx = rh.DevicePoly.from_numpy(rq, cx)
+    ct0, ct1 = rh.DevicePoly(rq, npoly, nq), rh.DevicePoly(rq, npoly, nq)
+    for _ in range(2):
+        be.GadgetProduct(levelQ, levelP, pcx, dq.ptr, dp.ptr, beta, ct0, ct1)
+    a0, a1 = rh.DevicePoly.from_numpy(rq, add), rh.DevicePoly.from_numpy(rq, add)
+    be.GadgetProductThenAdd(levelQ, levelP, pcx, dq.ptr, dp.ptr, beta, a0, a1, a0, a1)     # outputs alias the addends
+    g0, g1, s0, s1 = ct0.numpy(), ct1.numpy(), a0.numpy(), a1.numpy()
+    for k in (0, npoly // 2 - 1, npoly // 2, npoly - 1):
+        e0, e1 = oracle_gadget_product(oracle, rh, N, Q, P, levelQ, levelP, cx[k], evkQ, evkP)
+        assert np.array_equal(g0[k], e0) and np.array_equal(g1[k], e1)
+        for i, q in enumerate(Q):
+            assert np.array_equal(s0[k, i], (e0[i] + add[k, i]) % np.uint64(q))
+            assert np.array_equal(s1[k, i], (e1[i] + add[k, i]) % np.uint64(q))
     be.close(); rq.close(); rp.close()
 
 
