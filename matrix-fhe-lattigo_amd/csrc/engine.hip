@@ -365,7 +365,7 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
     if (phase != 1) {
       // the hand-scheduled body leaves values < 4q unscaled: right whenever column stages follow, and for N = 4096
       // sub-rings of the 3N transform (inv_scale = false), which scale in their own last layer
-      if (r->asm_tile && (S1 > 0 || !r->inv_scale)) ntt_inv_tile_asm<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly);
+      if (r->asm_tile && (S1 > 0 || !r->inv_scale)) ntt_inv_tile_asm<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly, 0);
       else ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, (S1 == 0 && r->inv_scale) ? 1 : 0, npoly);
     }
     const bool acols = phase != 2 && r->asm_cols && r->asm_tile && r->inv_scale;
@@ -528,6 +528,27 @@ int rh_std_ntt_fwd_digits(rh_ring* r, u64* data, size_t digit_stride, int npoly,
   return check_launch("ntt_fwd_fused_gap_asm");
 }
 
+// Inverse canonical transform of ONE limb of every poly of a block with in_rows limbs per poly into a dense block of npoly rows
+// (the last limb of a rescale step): the tile kernel reads the limb where it lies -- no gather copy.  Hand-scheduled bodies only.
+bool rh_can_intt_limb_strided(const rh_ring* r) {
+  const int S1 = r->logN - LT;
+  return r->kind == RH_RING_STANDARD && r->asm_tile && r->asm_cols && r->inv_scale && S1 >= 2 && S1 <= 4;
+}
+int rh_std_intt_limb_strided(rh_ring* r, const u64* in, int in_rows, int limb, u64* out, int npoly) {
+  if (!rh_can_intt_limb_strided(r)) return rh_fail(RH_ERR_UNSUPPORTED, "strided single-limb inverse transform needs the hand-scheduled bodies");
+  if (npoly <= 0) return RH_OK;
+  (void)hipGetLastError();
+  const int S1 = r->logN - LT;
+  const size_t toff = (size_t)limb * r->N;
+  hipStream_t st = rh_stream(r);
+  ntt_inv_tile_asm<<<(unsigned)npoly << S1, 256, 0, st>>>(in + toff, out, r->d_twk_inv + toff, r->d_consts + limb, 1, r->logN, npoly, in_rows);
+  const dim3 g((unsigned)npoly * 16);
+  if (S1 == 4) ntt_inv_cols_asm<4><<<g, 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb, r->d_consts + limb, 1);
+  else if (S1 == 3) ntt_inv_cols_asm<3><<<g, 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb, r->d_consts + limb, 1);
+  else ntt_inv_cols_asm<2><<<g, 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb, r->d_consts + limb, 1);
+  return check_launch("strided single-limb inverse transform");
+}
+
 bool rh_can_fuse_submul(const rh_ring* r) { return r->kind == RH_RING_STANDARD && r->logN >= LT && r->fuse_submul; }
 // Forward canonical transform of `buf` (in place up to its tile stages) fused with out = MRed(2q - y + NTT(buf), s_limb):
 // column stages as usual, then ntt_fwd_tile_submul.  y / out: (poly, limb) blocks with y_rows / out_rows limbs per poly.
@@ -540,6 +561,16 @@ int rh_std_ntt_expand_cols_launch(rh_ring* r, const u64* tmp, u64* buf, int npol
   (void)hipGetLastError();
   const RescaleLimb* T = (const RescaleLimb*)table_dev;
   const dim3 g(rows * 16);
+  bool lazy_ok = r->asm_tile && r->asm_cols && S1 >= 2 && S1 <= 4;      // hand-scheduled body: needs qL + q <= 8q for every limb
+  for (int i = 0; i < Lrows && lazy_ok; ++i) lazy_ok = qL / 7 <= r->moduli[i] && qL - 1 < 7 * r->moduli[i];
+  if (lazy_ok) {
+    switch (S1) {
+      case 2: ntt_fwd_cols_expand_asm<2><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, mode, qL); break;
+      case 3: ntt_fwd_cols_expand_asm<3><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, mode, qL); break;
+      case 4: ntt_fwd_cols_expand_asm<4><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, mode, qL); break;
+    }
+    return check_launch("ntt_fwd_cols_expand_asm");
+  }
   switch (S1) {
     case 1: ntt_fwd_cols_expand<1><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;
     case 2: ntt_fwd_cols_expand<2><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, r->logN, mode, qL); break;

@@ -68,6 +68,33 @@ RH_DEV void fwd_cols_asm_body(const u32 b, const u64* in, u64* out, const tw2* _
   else if constexpr (S1 == 3) RH_COLS_FWD_ASM(NTT_COLS8_ASM_BODY);
   else RH_COLS_FWD_ASM(NTT_COLS4_ASM_BODY);
 }
+// Column stages fed by the re-expansion of a rescale step, hand-scheduled (same outputs contract as ntt_fwd_cols_expand,
+// ntt_kernels.hip.hpp: values < 8q congruent to the expanded limb): x = cred(t + hq, qL) + s is NOT reduced modulo the limb's q --
+// the launcher checks qL + q <= 8q for every limb, which the first stage's conditional subtraction needs.
+template <int S1>
+__global__ void __launch_bounds__(256)
+ntt_fwd_cols_expand_asm(const u64* tmp, u64* out, const tw2* __restrict__ twn, const LimbConsts* __restrict__ consts,
+                        const RescaleLimb* __restrict__ T, int L, int mode, u64 qL) {
+  static_assert(has_asm_cols(S1), "asm column stages exist for S1 = 2..4");
+  constexpr int logN = LT + S1;
+  const u32 b = blockIdx.x;
+  const u32 limb = b % (u32)L;
+  const u32 r = b / (u32)L;
+  const u64 pin = uni64((u64)(size_t)(tmp + ((size_t)(r >> 4) << logN) + (r & 15) * 256));
+  const u64 pout = uni64((u64)(size_t)(out + (((size_t)(r >> 4) * L + limb) << logN) + (r & 15) * 256));
+  const u64 tw = uni64((u64)(size_t)(twn + ((size_t)limb << logN)));
+  const u64 q = uni64(consts[limb].q);
+  const u64 nq = (u64)0 - q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
+  const u64 hq = mode == 1 ? (qL - 1) >> 1 : 0, sadd = mode == 1 ? uni64(T[limb].s) : 0, nqL = (u64)0 - qL;
+  const u32 tid = threadIdx.x;
+#define RH_COLS_EXP_ASM(BODY)                                                                                       \
+  asm volatile(BODY : : [tid] "v"(tid), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw), [nq0] "s"((u32)nq),        \
+               [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4), [hq] "s"(hq), [nqL] "s"(nqL), [sadd] "s"(sadd) : NTT_TILE_ASM_CLOBBERS)
+  if constexpr (S1 == 4) RH_COLS_EXP_ASM(NTT_COLS16_EXPAND_ASM_BODY);
+  else if constexpr (S1 == 3) RH_COLS_EXP_ASM(NTT_COLS8_EXPAND_ASM_BODY);
+  else RH_COLS_EXP_ASM(NTT_COLS4_EXPAND_ASM_BODY);
+#undef RH_COLS_EXP_ASM
+}
 template <int S1, bool ASMCOLS>
 RH_DEV void fwd_cols_best(const u32 b, const u64* in, u64* out, const tw2* __restrict__ twn,
                           const LimbConsts* __restrict__ consts, int L, int logN) {
@@ -157,13 +184,14 @@ ntt_fwd_fused_gap_asm(u64* data1, unsigned n1, GapRows g1, u64* data2, unsigned 
 // MUL: the tile's input is MRedLazy(in, in2) formed on load (rh_ring_intt_mul; same contract as inv_tile_body<true>)
 template <bool MUL = false>
 RH_DEV void inv_tile_asm_body(u64* lds, const u32 b, const u64* in, const u64* in2, u64* out, const tw2* __restrict__ twk,
-                              const LimbConsts* __restrict__ consts, int L, int logN, int npoly) {
+                              const LimbConsts* __restrict__ consts, int L, int logN, int npoly, int in_Ls = 0) {
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
   const u32 poly = r % (u32)npoly;
   const u32 tile = r / (u32)npoly;
   const size_t base = (((size_t)poly * L + limb) << logN) + ((size_t)tile << LT);
-  const u64 pin = uni64((u64)(size_t)(in + base));
+  // in_Ls > 0: the input block has in_Ls rows per poly (a limb gathered out of a larger block); the output is dense
+  const u64 pin = uni64((u64)(size_t)(in + (in_Ls ? (((size_t)poly * in_Ls + limb) << logN) + ((size_t)tile << LT) : base)));
   const u64 pout = uni64((u64)(size_t)(out + base));
   const u64 tw = uni64((u64)(size_t)(twk + ((size_t)limb << logN) + ((size_t)tile << LT)));
   const u64 q = uni64(consts[limb].q);
@@ -222,9 +250,9 @@ ntt_inv_cols_asm(u64* data, const tw2* __restrict__ twn, const tw2* __restrict__
 
 __global__ void __launch_bounds__(256)
 ntt_inv_tile_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts,
-                 int L, int logN, int npoly) {
+                 int L, int logN, int npoly, int in_Ls) {
   __shared__ u64 lds[LDS_WORDS];
-  inv_tile_asm_body<false>(lds, blockIdx.x, in, nullptr, out, twk, consts, L, logN, npoly);
+  inv_tile_asm_body<false>(lds, blockIdx.x, in, nullptr, out, twk, consts, L, logN, npoly, in_Ls);
 }
 __global__ void __launch_bounds__(256)
 ntt_inv_tile_mul_asm(const u64* in, const u64* in2, u64* out, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts,

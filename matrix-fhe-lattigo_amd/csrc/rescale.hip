@@ -159,8 +159,12 @@ extern "C" int rh_ring_div_by_last_modulus_many_ntt(rh_ring* r, int round, int l
     if (int rc = ensure_scratch(r, 1, (size_t)npoly * level * N)) return rc;
     RescaleLimb* T; if (int rc = rescale_table(r, level, &T)) return rc;
     u64* tmp = r->d_rs[0]; u64* buff = r->d_rs[1];
-    gather_limb_kernel<<<grid, 256, 0, rh_stream(r)>>>(p0, level + 1, level, tmp, N);
-    if (int rc = rh_std_ntt_launch(r, tmp, tmp, npoly, 1, level, true, true, 0)) return rc;
+    if (rh_can_intt_limb_strided(r)) {               // the inverse tile stages read the last limb where it lies
+      if (int rc = rh_std_intt_limb_strided(r, p0, level + 1, level, tmp, npoly)) return rc;
+    } else {
+      gather_limb_kernel<<<grid, 256, 0, rh_stream(r)>>>(p0, level + 1, level, tmp, N);
+      if (int rc = rh_std_ntt_launch(r, tmp, tmp, npoly, 1, level, true, true, 0)) return rc;
+    }
     if (level > 0 && rh_can_fuse_submul(r)) {          // p1 = MRed(2q - p0 + NTT(buff), c_i) in the tile kernel's epilogue (:120-124)
       std::vector<u64> sc(level);
       for (int i = 0; i < level; ++i) sc[i] = rh::mform(r->moduli[i] - rh::invmod_prime(r->moduli[level] % r->moduli[i], r->moduli[i]), r->moduli[i]);

@@ -530,8 +530,11 @@ def gen_submul_epilogue(A0, A1, A3, with_z):
     emit("s_waitcnt vmcnt(0)")
 
 
-def gen_cols(S1=4):
-    """Column stages for N = 2^(12+S1), S1 = 2..4: x[k] = in[c + 4096 k], k < R = 2^S1, one radix-R register round with the
+def gen_cols(S1=4, expand=False):
+    """expand: the inputs are the coefficient-domain last limb t of a rescale step (ring/scaling.go:97-118), re-expanded on load as
+    x = cred(t + hq, qL) + s  (operands hq, nqL = -qL, sadd: SGPR pairs; DivFloor passes hq = sadd = 0), NOT reduced modulo the limb's
+    q: the host guarantees qL + q <= 8q, the first stage's conditional subtraction and the Shoup multiply take it from there.
+    Column stages for N = 2^(12+S1), S1 = 2..4: x[k] = in[c + 4096 k], k < R = 2^S1, one radix-R register round with the
     wave-uniform twiddles tw[1..R-1] (natural order: stage s, group g -> tw[2^s + g] = slot 2^s - 1 + g), outputs < 8q
     stored back.  Same contract as fwd_cols_body<ShoupPolicy, S1> (ntt_kernels.hip.hpp); operands: tid, pin, pout (row base +
     256*cb columns, bytes), tw (limb's natural-order table), nq0, nq1, nq4, q4."""
@@ -552,9 +555,20 @@ def gen_cols(S1=4):
     emit("s_waitcnt lgkmcnt(0)")
     if PRIO in (1, 2):
         emit("s_setprio 0")
+    if expand:
+        for kk in range(0, R, 2):
+            ks = [((kk + j) >> 1) + (R >> 1) * ((kk + j) & 1) for j in (0, 1)]
+            emit("s_waitcnt vmcnt(%d)" % (R - 2 - kk))
+            a, b = [], []
+            for lst, k, t in ((a, ks[0], T0), (b, ks[1], T1)):
+                lst.append("v_lshl_add_u64 %s, %s, 0, %%[hq]" % (pair(X(k)), pair(X(k))))
+                lst.extend(csub_steps(X(k), "nqL", t))
+                lst.append("v_lshl_add_u64 %s, %s, 0, %%[sadd]" % (pair(X(k)), pair(X(k))))
+            for ins in interleave(a, b):
+                emit(ins)
 
     def pair_hook(u, i):
-        if u == 0:
+        if u == 0 and not expand:
             emit("s_waitcnt vmcnt(%d)" % (R - (2 * i + 4)))
     round16(lambda slot: (None, ("s%d" % (36 + 4 * slot), "s%d" % (37 + 4 * slot), "s%d" % (38 + 4 * slot), "s%d" % (39 + 4 * slot))),
             pair_hook=pair_hook, stages=S1)
@@ -683,13 +697,16 @@ if EXP:
         keep.append(l)
     fwd = keep
 del out[:]
-cols, cols_inv = {}, {}
+cols, cols_inv, cols_exp = {}, {}, {}
 for s1 in (2, 3, 4):
     gen_cols(s1)
     cols[s1] = list(out)
     del out[:]
     gen_cols_inv(s1)
     cols_inv[s1] = list(out)
+    del out[:]
+    gen_cols(s1, expand=True)
+    cols_exp[s1] = list(out)
     del out[:]
 gen(lazy_out=True)
 fwd_lazy = list(out)
@@ -708,7 +725,7 @@ inv_mul = list(out)
 clob_v = ", ".join('"v%d"' % i for i in range(NVGPR_USED))
 clob_s = ", ".join('"s%d"' % i for i in range(36, 100))
 text = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  forward: %d instructions, inverse: %d.\n" % (len(fwd), len(inv))
-text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_LAZY_ASM_BODY", fwd_lazy) + render("NTT_TILE_SUBMUL_ASM_BODY", fwd_sm) + render("NTT_TILE_SUBMUL_ADD_ASM_BODY", fwd_sma) + "".join(render("NTT_COLS%d_ASM_BODY" % (1 << k), cols[k]) + render("NTT_COLS%d_INV_ASM_BODY" % (1 << k), cols_inv[k]) for k in (2, 3, 4)) + render("NTT_TILE_INV_ASM_BODY", inv) + render("NTT_TILE_INV_MUL_ASM_BODY", inv_mul)
+text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_LAZY_ASM_BODY", fwd_lazy) + render("NTT_TILE_SUBMUL_ASM_BODY", fwd_sm) + render("NTT_TILE_SUBMUL_ADD_ASM_BODY", fwd_sma) + "".join(render("NTT_COLS%d_ASM_BODY" % (1 << k), cols[k]) + render("NTT_COLS%d_INV_ASM_BODY" % (1 << k), cols_inv[k]) + render("NTT_COLS%d_EXPAND_ASM_BODY" % (1 << k), cols_exp[k]) for k in (2, 3, 4)) + render("NTT_TILE_INV_ASM_BODY", inv) + render("NTT_TILE_INV_MUL_ASM_BODY", inv_mul)
 text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v, clob_s)
 path = sys.argv[1] if len(sys.argv) > 1 else "ntt_tile_asm.inc"
 open(path, "w").write(text)
