@@ -45,3 +45,55 @@ def test_div_many_coefficient_and_ntt_domain(rh, oracle, N, L, nb, round_):
     assert np.array_equal(chk.numpy(), exp)
     assert not po.numpy()[:, L - nb:].any()                   # limbs above the new level are not written
     ring.close()
+
+
+def _ntt_prime_below(bits, two_n, skip=0):
+    """largest primes p < 2^bits with p = 1 mod 2N (deterministic Miller-Rabin for 64-bit integers)"""
+    def is_prime(n):
+        if n < 2:
+            return False
+        for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+            if n % p == 0:
+                return n == p
+        d, s = n - 1, 0
+        while d % 2 == 0:
+            d //= 2; s += 1
+        for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+            x = pow(a, d, n)
+            if x in (1, n - 1):
+                continue
+            for _ in range(s - 1):
+                x = x * x % n
+                if x == n - 1:
+                    break
+            else:
+                return False
+        return True
+    p = ((1 << bits) // two_n) * two_n + 1
+    while True:
+        p -= two_n
+        if is_prime(p):
+            if skip == 0:
+                return p
+            skip -= 1
+
+
+@pytest.mark.parametrize("round_", [0, 1])
+def test_rescale_with_moduli_of_different_sizes(rh, oracle, round_):
+    # last modulus 61 bits, the others 50 bits: qL + q > 8q, so the re-expansion must be reduced modulo each limb's q (the
+    # hand-scheduled column stages that skip this reduction are not eligible; the launcher falls back)
+    N = 1 << 14
+    Q = [_ntt_prime_below(50, 2 * N, 0), _ntt_prime_below(50, 2 * N, 1), QI60[0]]
+    ring = rh.Ring(N, Q)
+    rng = np.random.default_rng(50 + round_)
+    a = np.stack([np.stack([rng.integers(0, 1 << 62, size=N, dtype=np.uint64) % np.uint64(q) for q in Q]) for _ in range(2)])
+    exp = np.stack([oracle.div_by_last_modulus_many(a[k], Q, 1, round_) for k in range(2)])
+    pn = rh.DevicePoly.from_numpy(ring, a)
+    ring.NTT(pn, pn)
+    po = rh.DevicePoly.from_numpy(ring, np.zeros((2, 3, N), dtype=np.uint64))
+    (ring.DivRoundByLastModulusManyNTT if round_ else ring.DivFloorByLastModulusManyNTT)(1, pn, po)
+    sub = ring.AtLevel(1)
+    chk = rh.DevicePoly.from_numpy(sub, po.numpy()[:, :2].copy())
+    sub.INTT(chk, chk)
+    assert np.array_equal(chk.numpy(), exp)
+    ring.close()
