@@ -66,6 +66,38 @@ def test_config5_gadget_product_real_size(rh, oracle, logN):
     ev.close(); rq.close(); rp.close()
 
 
+def test_config5_gadget_product_benchmark_batch(rh, oracle):
+    """the batch the key-switch numbers are quoted on (64 polys, N = 2^16, Q = 24, P = 6: the multi-poly key multiply-accumulate
+    workgroups, the pipelined digit transforms without their final reduction): polys 0, 31, 63 of the batch against the oracle, and the
+    whole batch against the hoisted product of the same input"""
+    import torch
+    N, nq, np_, B = 1 << 16, 24, 6, 64
+    Q, P, beta, evkQ, evkP, _mk = _ks_case(N, nq, np_, 1, 4242)
+    dev = torch.device("cuda", 0)
+    rq, rp = rh.Ring(N, Q), rh.Ring(N, P)
+    for r in (rq, rp):
+        r.set_stream(torch.cuda.current_stream().cuda_stream)
+    ev = rh.rlwe.Evaluator(rq, rp)
+    gct = rh.rlwe.GadgetCiphertext(rq, rp, evkQ, evkP)
+    qs = torch.tensor(Q, dtype=torch.int64, device=dev).view(1, nq, 1)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    cx = torch.randint(0, 1 << 62, (B, nq, N), dtype=torch.int64, device=dev, generator=g) % qs
+    o0, o1, h0, h1 = (torch.empty_like(cx) for _ in range(4))
+    pcx = rh.DevicePoly.from_torch(rq, cx)
+    direct = rh.Ciphertext([rh.DevicePoly.from_torch(rq, o0), rh.DevicePoly.from_torch(rq, o1)], is_ntt=True)
+    ev.GadgetProduct(nq - 1, pcx, gct, direct)
+    torch.cuda.synchronize()
+    for k in (0, 31, 63):
+        e0, e1 = oracle_gadget_product(oracle, rh, N, Q, P, nq - 1, np_ - 1, cx[k].cpu().numpy().view(np.uint64), evkQ, evkP)
+        assert np.array_equal(o0[k].cpu().numpy().view(np.uint64), e0) and np.array_equal(o1[k].cpu().numpy().view(np.uint64), e1)
+    dec = ev.DecomposeNTT(nq - 1, np_ - 1, pcx, True)
+    hoisted = rh.Ciphertext([rh.DevicePoly.from_torch(rq, h0), rh.DevicePoly.from_torch(rq, h1)], is_ntt=True)
+    ev.GadgetProductHoisted(nq - 1, dec, gct, hoisted)
+    torch.cuda.synchronize()
+    assert torch.equal(h0, o0) and torch.equal(h1, o1)
+    ev.close(); rq.close(); rp.close()
+
+
 def test_config5_limb_sharded_one_rank_real_size(rh, oracle):
     """sharding.LimbShardedKeySwitch (rh_kshard_*) with one rank at N = 2^16, Q = 24, P = 6 vs the oracle composition"""
     import torch

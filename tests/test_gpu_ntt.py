@@ -168,6 +168,37 @@ def test_metric_size_properties(rh, oracle):
     ring.close()
 
 
+def test_metric_full_batch_properties(rh, oracle):
+    # the metric's full configuration (N = 2^16, 16 limbs, 1024 polys = 8 GiB per block, the pipelined fused launches): round trip and
+    # linearity over the WHOLE batch (compared on the device), three (poly, limb) rows against the oracle
+    import torch
+    N, mods, B = 1 << 16, QI60[:16], 1024
+    dev = torch.device("cuda", 0)
+    ring = rh.Ring(N, mods)
+    ring.set_stream(torch.cuda.current_stream().cuda_stream)
+    qs = torch.tensor(mods, dtype=torch.int64, device=dev).view(1, 16, 1)
+    g = torch.Generator(device=dev); g.manual_seed(99)
+    a = torch.randint(0, 1 << 62, (B, 16, N), dtype=torch.int64, device=dev, generator=g) % qs
+    b = torch.randint(0, 1 << 62, (B, 16, N), dtype=torch.int64, device=dev, generator=g) % qs
+    na, nb = torch.empty_like(a), torch.empty_like(b)
+    pa, pb, pna, pnb = (rh.DevicePoly.from_torch(ring, t) for t in (a, b, na, nb))
+    ring.NTT(pa, pna); ring.NTT(pb, pnb)
+    rows = [(0, 0), (517, 9), (1023, 15)]
+    got = {r: na[r[0], r[1]].cpu().numpy().view(np.uint64) for r in rows}
+    src = {r: a[r[0], r[1]].cpu().numpy().view(np.uint64) for r in rows}
+    for (k, i) in rows:
+        assert np.array_equal(got[(k, i)], oracle.ntt(src[(k, i)], oracle.SubRingConsts(N, mods[i])))
+    ring.Add(pa, pb, pb)                              # b <- a + b (coefficient domain)
+    ring.Add(pna, pnb, pnb)                           # nb <- NTT(a) + NTT(b)
+    ring.NTT(pb, pb)                                  # b <- NTT(a + b), in place
+    torch.cuda.synchronize()
+    assert torch.equal(b, nb)
+    ring.INTT(pna, pna)                               # back, in place
+    torch.cuda.synchronize()
+    assert torch.equal(na, a)
+    ring.close()
+
+
 def test_errors_match_reference_behaviour(rh):
     ring = rh.Ring(64, QI60[:1])
     with pytest.raises(rh.RingHipError):          # short slice -> panic in ring/ntt.go:212-214
