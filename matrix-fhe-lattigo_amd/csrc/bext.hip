@@ -35,8 +35,16 @@ bext_kernel(const u64* in, int in_rows, int src_limb0, int nsrc, const BextSourc
             u64* out0, int out0_rows, u64* out1, int out1_rows, const u64* other, int other_rows, int N, int add_mode, int post) {
   // targets [0, ntgt_c) are extended (all with the plan-uniform post step `post`); [ntgt_c, ntgt) are the digit limbs of
   // DecomposeAndSplit: no extension, the centred subtraction applies to what the output already holds
-  extern __shared__ u64 ylds[];                     // [nsrc][256], NS == 0 only
+  // dynamic LDS: [ntgt_c * (nsrc + 1)] the vt table (-v*Q mod p for every target and v), then [nsrc][256] the y_i (NS == 0 only).
+  // The per-target vt lookup must not be a global load: its s_waitcnt vmcnt would also wait for the STORES of the previous
+  // targets (loads and stores share that counter on gfx9) and serialise the loop on write latency.
+  extern __shared__ u64 dyn_lds[];
   const int tid = threadIdx.x;
+  const int vt_words = ntgt_c * (nsrc + 1);
+  u64* const vt_lds = dyn_lds;
+  u64* const ylds = dyn_lds + vt_words;
+  for (int i = tid; i < vt_words; i += 256) vt_lds[i] = vt[i];
+  __syncthreads();
   const int k = blockIdx.x * 256 + tid;
   const int poly = blockIdx.y;
   const bool live = k < N;
@@ -106,7 +114,7 @@ bext_kernel(const u64* in, int in_rows, int src_limb0, int nsrc, const BextSourc
       }
     }
     const u64 hhi = mulhi64(rlo * t.pinv, t.p);
-    u64 r = rhi - hhi + t.p + vt[(size_t)j * (nsrc + 1) + v];             // :651-672
+    u64 r = rhi - hhi + t.p + vt_lds[j * (nsrc + 1) + (int)v];            // :651-672
     if (post >= 1) r = cred(r + t.p - t.half, t.p);                       // SubScalarBigint -> subscalarvec
     if (post == 2) {
       const u64 y = live ? other[((size_t)poly * other_rows + t.limb) * N + k] : 0;
@@ -131,20 +139,21 @@ bext_kernel(const u64* in, int in_rows, int src_limb0, int nsrc, const BextSourc
 #define RH_BEXT_ARGS in, in_rows, src_limb0, p.nsrc, p.d_S, p.ntgt_c, p.ntgt, p.d_T, p.d_coef, p.d_vt, out0, out0_rows, out1, out1_rows, other, other_rows, N, add_mode, p.post
 static void bext_dispatch(dim3 grid, hipStream_t st, const BextPlan& p, const u64* in, int in_rows, int src_limb0, u64* out0, int out0_rows,
                           u64* out1, int out1_rows, const u64* other, int other_rows, int N, int add_mode) {
+  const size_t vt_bytes = (size_t)p.ntgt_c * (p.nsrc + 1) * 8;      // at most 64 targets x 33 entries = 16.5 KiB
   switch (p.nsrc) {
-    case 1: bext_kernel<1, true><<<grid, 256, 0, st>>>(RH_BEXT_ARGS); return;
-    case 2: bext_kernel<2, true><<<grid, 256, 0, st>>>(RH_BEXT_ARGS); return;
-    case 3: bext_kernel<3, true><<<grid, 256, 0, st>>>(RH_BEXT_ARGS); return;
-    case 4: bext_kernel<4, true><<<grid, 256, 0, st>>>(RH_BEXT_ARGS); return;
-    case 5: bext_kernel<5, true><<<grid, 256, 0, st>>>(RH_BEXT_ARGS); return;
-    case 6: bext_kernel<6, true><<<grid, 256, 0, st>>>(RH_BEXT_ARGS); return;
-    case 7: bext_kernel<7, true><<<grid, 256, 0, st>>>(RH_BEXT_ARGS); return;
-    case 8: bext_kernel<8, true><<<grid, 256, 0, st>>>(RH_BEXT_ARGS); return;
+    case 1: bext_kernel<1, true><<<grid, 256, vt_bytes, st>>>(RH_BEXT_ARGS); return;
+    case 2: bext_kernel<2, true><<<grid, 256, vt_bytes, st>>>(RH_BEXT_ARGS); return;
+    case 3: bext_kernel<3, true><<<grid, 256, vt_bytes, st>>>(RH_BEXT_ARGS); return;
+    case 4: bext_kernel<4, true><<<grid, 256, vt_bytes, st>>>(RH_BEXT_ARGS); return;
+    case 5: bext_kernel<5, true><<<grid, 256, vt_bytes, st>>>(RH_BEXT_ARGS); return;
+    case 6: bext_kernel<6, true><<<grid, 256, vt_bytes, st>>>(RH_BEXT_ARGS); return;
+    case 7: bext_kernel<7, true><<<grid, 256, vt_bytes, st>>>(RH_BEXT_ARGS); return;
+    case 8: bext_kernel<8, true><<<grid, 256, vt_bytes, st>>>(RH_BEXT_ARGS); return;
     default: break;
   }
-  if (p.nsrc <= 16) bext_kernel<16, false><<<grid, 256, 0, st>>>(RH_BEXT_ARGS);
-  else if (p.nsrc <= 32) bext_kernel<32, false><<<grid, 256, 0, st>>>(RH_BEXT_ARGS);
-  else bext_kernel<0, false><<<grid, 256, (size_t)p.nsrc * 256 * 8, st>>>(RH_BEXT_ARGS);
+  if (p.nsrc <= 16) bext_kernel<16, false><<<grid, 256, vt_bytes, st>>>(RH_BEXT_ARGS);
+  else if (p.nsrc <= 32) bext_kernel<32, false><<<grid, 256, vt_bytes, st>>>(RH_BEXT_ARGS);
+  else bext_kernel<0, false><<<grid, 256, vt_bytes + (size_t)p.nsrc * 256 * 8, st>>>(RH_BEXT_ARGS);
 }
 
 // DecomposeAndSplit, single-prime digit (decompLvl < 0): sign-aware copy/reduce into every limb (:402-436)
