@@ -118,7 +118,9 @@ int rh_ring_ntt_many(rh_ring* r, const uint64_t* const* in_dev, uint64_t* const*
 /* The same on blocks that carry MORE limbs per poly than the level they are used at (in_rows / out_rows limbs per poly, each
  * >= level+1): ring.AtLevel(level) on max-level polys and buffers (ring/ring.go:192-213), the idiomatic use inside the reference's
  * evaluators.  Limbs 0..level of every poly are transformed, the others are untouched.  With rows == level+1 this IS rh_ring_ntt /
- * rh_ring_intt; otherwise the call runs poly by poly (correct, but not the throughput path). */
+ * rh_ring_intt.  Otherwise, standard rings: the forward transform with in_rows == out_rows (N >= 4096) and the inverse transform
+ * (N = 2^14 .. 2^16) run as one batched launch pair with the row strides inside the kernels; the remaining shapes (different strides
+ * forward, small N, conjugate-invariant and 3N rings) run poly by poly -- correct, not the throughput path. */
 int rh_ring_ntt_rows(rh_ring* r, const uint64_t* in_dev, int in_rows, uint64_t* out_dev, int out_rows, int npoly, int level, int lazy);
 int rh_ring_intt_rows(rh_ring* r, const uint64_t* in_dev, int in_rows, uint64_t* out_dev, int out_rows, int npoly, int level, int lazy);
 
@@ -159,7 +161,8 @@ int rh_ring_set_tuning(rh_ring* r, const char* key, long value);
 int rh_ring_vec_op(rh_ring* r, int opcode, const uint64_t* p1_dev, const uint64_t* p2_dev, uint64_t* p3_dev, int npoly,
                    int level, const uint64_t* s0_host, const uint64_t* s1_host);
 
-/* rows-per-poly form (see rh_ring_ntt_rows): every operand block with its own limb count >= level+1 */
+/* rows-per-poly form (see rh_ring_ntt_rows): every operand block with its own limb count >= level+1; one launch, the three row
+ * strides inside the kernel */
 int rh_ring_vec_op_rows(rh_ring* r, int opcode, const uint64_t* p1_dev, int rows1, const uint64_t* p2_dev, int rows2, uint64_t* p3_dev,
                         int rows3, int npoly, int level, const uint64_t* s0_host, const uint64_t* s1_host);
 

@@ -365,13 +365,13 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
     if (phase != 1) {
       // the hand-scheduled body leaves values < 4q unscaled: right whenever column stages follow, and for N = 4096
       // sub-rings of the 3N transform (inv_scale = false), which scale in their own last layer
-      if (r->asm_tile && (S1 > 0 || !r->inv_scale)) ntt_inv_tile_asm<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly, 0);
+      if (r->asm_tile && (S1 > 0 || !r->inv_scale)) ntt_inv_tile_asm<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly, 0, 0);
       else ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, (S1 == 0 && r->inv_scale) ? 1 : 0, npoly);
     }
     const bool acols = phase != 2 && r->asm_cols && r->asm_tile && r->inv_scale;
-    if (S1 == 4 && acols) ntt_inv_cols_asm<4><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows);
-    else if (S1 == 3 && acols) ntt_inv_cols_asm<3><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows);
-    else if (S1 == 2 && acols) ntt_inv_cols_asm<2><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows);
+    if (S1 == 4 && acols) ntt_inv_cols_asm<4><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, 0);
+    else if (S1 == 3 && acols) ntt_inv_cols_asm<3><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, 0);
+    else if (S1 == 2 && acols) ntt_inv_cols_asm<2><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, 0);
     else if (S1 > 0 && phase != 2) launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, logN, r->inv_scale ? 1 : 0);
   }
   return check_launch("ntt");
@@ -541,12 +541,29 @@ int rh_std_intt_limb_strided(rh_ring* r, const u64* in, int in_rows, int limb, u
   const int S1 = r->logN - LT;
   const size_t toff = (size_t)limb * r->N;
   hipStream_t st = rh_stream(r);
-  ntt_inv_tile_asm<<<(unsigned)npoly << S1, 256, 0, st>>>(in + toff, out, r->d_twk_inv + toff, r->d_consts + limb, 1, r->logN, npoly, in_rows);
+  ntt_inv_tile_asm<<<(unsigned)npoly << S1, 256, 0, st>>>(in + toff, out, r->d_twk_inv + toff, r->d_consts + limb, 1, r->logN, npoly, in_rows, 0);
   const dim3 g((unsigned)npoly * 16);
-  if (S1 == 4) ntt_inv_cols_asm<4><<<g, 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb, r->d_consts + limb, 1);
-  else if (S1 == 3) ntt_inv_cols_asm<3><<<g, 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb, r->d_consts + limb, 1);
-  else ntt_inv_cols_asm<2><<<g, 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb, r->d_consts + limb, 1);
+  if (S1 == 4) ntt_inv_cols_asm<4><<<g, 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb, r->d_consts + limb, 1, 0);
+  else if (S1 == 3) ntt_inv_cols_asm<3><<<g, 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb, r->d_consts + limb, 1, 0);
+  else ntt_inv_cols_asm<2><<<g, 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb, r->d_consts + limb, 1, 0);
   return check_launch("strided single-limb inverse transform");
+}
+
+// Inverse canonical transform of limbs 0..Lrows-1 of every poly of a block with in_rows limbs per poly into a block with out_rows limbs per
+// poly (ring.AtLevel views of larger polys): one batched launch pair.  Hand-scheduled bodies only (N = 2^14 .. 2^16).
+int rh_std_intt_rows(rh_ring* r, const u64* in, int in_rows, u64* out, int out_rows, int npoly, int Lrows) {
+  if (!rh_can_intt_limb_strided(r)) return rh_fail(RH_ERR_UNSUPPORTED, "strided inverse transform needs the hand-scheduled bodies");
+  if (npoly <= 0 || Lrows <= 0) return RH_OK;
+  (void)hipGetLastError();
+  const int S1 = r->logN - LT;
+  hipStream_t st = rh_stream(r);
+  const unsigned rows = (unsigned)npoly * (unsigned)Lrows;
+  ntt_inv_tile_asm<<<rows << S1, 256, 0, st>>>(in, out, r->d_twk_inv, r->d_consts, Lrows, r->logN, npoly, in_rows, out_rows);
+  const dim3 g(rows * 16);
+  if (S1 == 4) ntt_inv_cols_asm<4><<<g, 256, 0, st>>>(out, r->d_tw_inv, r->d_lastw, r->d_consts, Lrows, out_rows);
+  else if (S1 == 3) ntt_inv_cols_asm<3><<<g, 256, 0, st>>>(out, r->d_tw_inv, r->d_lastw, r->d_consts, Lrows, out_rows);
+  else ntt_inv_cols_asm<2><<<g, 256, 0, st>>>(out, r->d_tw_inv, r->d_lastw, r->d_consts, Lrows, out_rows);
+  return check_launch("strided inverse transform");
 }
 
 bool rh_can_fuse_submul(const rh_ring* r) { return r->kind == RH_RING_STANDARD && r->logN >= LT && r->fuse_submul; }
@@ -688,14 +705,22 @@ extern "C" int rh_ring_ntt_many(rh_ring* r, const uint64_t* const* in, uint64_t*
   return RH_OK;
 }
 // ---- views at a lower level of blocks allocated with MORE limbs per poly (ring.AtLevel(level) on max-level polys and buffers,
-// ring/ring.go:192-213: the idiomatic use inside the reference's evaluators).  The batched kernels stride blocks by level+1 rows; a
-// block with `rows` > level+1 limbs per poly keeps each poly's leading limbs contiguous, so such a call runs poly by poly (npoly
-// launches of one poly each: correct, not the throughput path -- allocate batches at the level they are used at for that).
+// ring/ring.go:192-213: the idiomatic use inside the reference's evaluators).  Forward transforms with one row stride on both sides
+// (N >= 4096) and inverse transforms through the hand-scheduled bodies (N = 2^14 .. 2^16) are batched (row strides inside the
+// kernels); the remaining shapes run poly by poly (correct, not the throughput path).
 static int ntt_rows(rh_ring* r, const uint64_t* in, int in_rows, uint64_t* out, int out_rows, int npoly, int level, bool inverse, bool lazy) {
   if (!r) return rh_fail(RH_ERR_ARG, "ntt: null argument");
   if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "ntt: level %d out of range [0,%d)", level, r->L);
   if (in_rows < level + 1 || out_rows < level + 1) return rh_fail(RH_ERR_ARG, "ntt: blocks with %d / %d limbs per poly used at level %d", in_rows, out_rows, level);
   if (in_rows == level + 1 && out_rows == level + 1) return ntt_batch(r, in, out, npoly, level, inverse, lazy);
+  if (!in || !out) return rh_fail(RH_ERR_ARG, "ntt: null argument");
+  if (npoly < 0) return rh_fail(RH_ERR_ARG, "ntt: npoly < 0");
+  (void)hipSetDevice(r->device);
+  // batched: forward with one row stride on both sides (the kernels' Ls), inverse through the hand-scheduled bodies
+  if (r->kind == RH_RING_STANDARD && !inverse && in_rows == out_rows && r->logN >= LT)
+    return std_ntt_launch_span(r, in, out, npoly, level + 1, 0, false, lazy, 0, in_rows);
+  if (r->kind == RH_RING_STANDARD && inverse && rh_can_intt_limb_strided(r))    // BackwardLazy is canonical for N >= 16 (ring/ntt.go:197-206)
+    return rh_std_intt_rows(r, in, in_rows, out, out_rows, npoly, level + 1);
   for (int k = 0; k < npoly; ++k)
     if (int rc = ntt_batch(r, in + (size_t)k * in_rows * r->N, out + (size_t)k * out_rows * r->N, 1, level, inverse, lazy)) return rc;
   return RH_OK;
@@ -737,9 +762,9 @@ static int std_intt_mul_launch(rh_ring* r, const u64* a, const u64* b, u64* out,
   } else
   ntt_inv_tile_mul<<<rows << S1, 256, 0, st>>>(a, b, out, r->d_twk_inv, r->d_consts_r, Lrows, logN, S1 == 0 ? 1 : 0, npoly);
   if (S1 >= 2 && S1 <= 4 && r->asm_cols && r->asm_tile) {
-    if (S1 == 4) ntt_inv_cols_asm<4><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows);
-    else if (S1 == 3) ntt_inv_cols_asm<3><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows);
-    else ntt_inv_cols_asm<2><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows);
+    if (S1 == 4) ntt_inv_cols_asm<4><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows, 0);
+    else if (S1 == 3) ntt_inv_cols_asm<3><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows, 0);
+    else ntt_inv_cols_asm<2><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows, 0);
   } else if (S1 > 0) launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows, logN, 1);
   return check_launch("intt_mul");
 }
@@ -846,30 +871,31 @@ extern "C" int rh_ntt_backward_lazy(rh_ring* r, int limb, const uint64_t* p1, ui
 // ------------------------------------------------------------------------------------------------ element-wise
 struct ScalarPack { u64 s[RH_MAX_LIMBS]; };
 
+struct RowStrides { int r1, r2, r3; };                // limbs per poly of the three operand blocks (>= L: ring.AtLevel views)
 template <int OP>
 __global__ void __launch_bounds__(256)
 vec_op_packed(const u64* p1, const u64* p2, u64* p3, unsigned n, ScalarPack s0, ScalarPack s1,
-              const LimbConsts* __restrict__ consts, int L) {
+              const LimbConsts* __restrict__ consts, int L, RowStrides rs) {
   const u32 row = blockIdx.x;
-  const u32 limb = row % (u32)L;
+  const u32 limb = row % (u32)L, poly = row / (u32)L;
   const LimbConsts c = consts[limb];
   const u64 a0 = s0.s[limb], a1 = s1.s[limb];
-  const size_t rowoff = (size_t)row * n;
+  const size_t o1 = ((size_t)poly * rs.r1 + limb) * n, o2 = ((size_t)poly * rs.r2 + limb) * n, o3 = ((size_t)poly * rs.r3 + limb) * n;
   const unsigned npairs = n >> 1;
   for (unsigned i = blockIdx.y * blockDim.x + threadIdx.x; i < npairs; i += gridDim.y * blockDim.x) {
-    const size_t o = rowoff + 2 * (size_t)i;
+    const size_t e = 2 * (size_t)i;
     ulonglong2 x = make_ulonglong2(0, 0), y = x, z = x;
-    if (op_reads_x(OP)) x = *reinterpret_cast<const ulonglong2*>(p1 + o);
-    if (op_reads_y(OP)) y = *reinterpret_cast<const ulonglong2*>(p2 + o);
-    if (op_reads_z(OP)) z = *reinterpret_cast<const ulonglong2*>(p3 + o);
+    if (op_reads_x(OP)) x = *reinterpret_cast<const ulonglong2*>(p1 + o1 + e);
+    if (op_reads_y(OP)) y = *reinterpret_cast<const ulonglong2*>(p2 + o2 + e);
+    if (op_reads_z(OP)) z = *reinterpret_cast<const ulonglong2*>(p3 + o3 + e);
     ulonglong2 w;
     w.x = vec_apply<OP>(x.x, y.x, z.x, a0, a1, c);
     w.y = vec_apply<OP>(x.y, y.y, z.y, a0, a1, c);
-    *reinterpret_cast<ulonglong2*>(p3 + o) = w;
+    *reinterpret_cast<ulonglong2*>(p3 + o3 + e) = w;
   }
 }
 
-typedef void (*vec_fn)(const u64*, const u64*, u64*, unsigned, ScalarPack, ScalarPack, const LimbConsts*, int);
+typedef void (*vec_fn)(const u64*, const u64*, u64*, unsigned, ScalarPack, ScalarPack, const LimbConsts*, int, RowStrides);
 template <int... I>
 static const vec_fn* vec_table(std::integer_sequence<int, I...>) {
   static const vec_fn t[] = {vec_op_packed<I>...};
@@ -877,7 +903,7 @@ static const vec_fn* vec_table(std::integer_sequence<int, I...>) {
 }
 
 int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3, int npoly, int Lrows, int limb0,
-                  const u64* s0, const u64* s1) {
+                  const u64* s0, const u64* s1, int rows1, int rows2, int rows3) {   // rows_k: limbs per poly of operand k (0: Lrows)
   static const vec_fn* table = vec_table(std::make_integer_sequence<int, RH_OP_COUNT>());
   (void)hipGetLastError();
   ScalarPack a, b;
@@ -890,7 +916,8 @@ int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3,
   unsigned chunks = (n / 2 + 256 * 4 - 1) / (256 * 4);
   if (chunks < 1) chunks = 1;
   if (chunks > 64) chunks = 64;
-  hipLaunchKernelGGL(table[opcode], dim3(rows, chunks), dim3(256), 0, rh_stream(r), p1, p2, p3, n, a, b, r->d_consts + limb0, Lrows);
+  const RowStrides rs{rows1 ? rows1 : Lrows, rows2 ? rows2 : Lrows, rows3 ? rows3 : Lrows};
+  hipLaunchKernelGGL(table[opcode], dim3(rows, chunks), dim3(256), 0, rh_stream(r), p1, p2, p3, n, a, b, r->d_consts + limb0, Lrows, rs);
   return check_launch("vec_op");
 }
 
@@ -954,10 +981,11 @@ extern "C" int rh_ring_vec_op_rows(rh_ring* r, int opcode, const uint64_t* p1, i
   const int need = level + 1;
   if ((p1 && rows1 < need) || (p2 && rows2 < need) || rows3 < need) return rh_fail(RH_ERR_ARG, "vec_op: a block has fewer than level+1 = %d limbs per poly", need);
   if ((!p1 || rows1 == need) && (!p2 || rows2 == need) && rows3 == need) return rh_ring_vec_op(r, opcode, p1, p2, p3, npoly, level, s0, s1);
-  for (int k = 0; k < npoly; ++k) {
-    const size_t N = r->N;
-    if (int rc = rh_ring_vec_op(r, opcode, p1 ? p1 + (size_t)k * rows1 * N : nullptr, p2 ? p2 + (size_t)k * rows2 * N : nullptr,
-                                p3 + (size_t)k * rows3 * N, 1, level, s0, s1)) return rc;
-  }
-  return RH_OK;
+  if (!p3) return rh_fail(RH_ERR_ARG, "vec_op: null argument");
+  if (opcode < 0 || opcode >= RH_OP_COUNT) return rh_fail(RH_ERR_ARG, "vec_op: unknown opcode %d", opcode);
+  if (npoly < 0) return rh_fail(RH_ERR_ARG, "vec_op: npoly < 0");
+  if (op_reads_x(opcode) && !p1) return rh_fail(RH_ERR_ARG, "vec_op %d: p1 is null", opcode);
+  if (op_reads_y(opcode) && !p2) return rh_fail(RH_ERR_ARG, "vec_op %d: p2 is null", opcode);
+  (void)hipSetDevice(r->device);
+  return rh_vec_launch(r, opcode, p1, p2, p3, npoly, need, 0, s0, s1, p1 ? rows1 : need, p2 ? rows2 : need, rows3);   // one launch, per-operand row strides
 }

@@ -184,7 +184,7 @@ ntt_fwd_fused_gap_asm(u64* data1, unsigned n1, GapRows g1, u64* data2, unsigned 
 // MUL: the tile's input is MRedLazy(in, in2) formed on load (rh_ring_intt_mul; same contract as inv_tile_body<true>)
 template <bool MUL = false>
 RH_DEV void inv_tile_asm_body(u64* lds, const u32 b, const u64* in, const u64* in2, u64* out, const tw2* __restrict__ twk,
-                              const LimbConsts* __restrict__ consts, int L, int logN, int npoly, int in_Ls = 0) {
+                              const LimbConsts* __restrict__ consts, int L, int logN, int npoly, int in_Ls = 0, int out_Ls = 0) {
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
   const u32 poly = r % (u32)npoly;
@@ -192,7 +192,7 @@ RH_DEV void inv_tile_asm_body(u64* lds, const u32 b, const u64* in, const u64* i
   const size_t base = (((size_t)poly * L + limb) << logN) + ((size_t)tile << LT);
   // in_Ls > 0: the input block has in_Ls rows per poly (a limb gathered out of a larger block); the output is dense
   const u64 pin = uni64((u64)(size_t)(in + (in_Ls ? (((size_t)poly * in_Ls + limb) << logN) + ((size_t)tile << LT) : base)));
-  const u64 pout = uni64((u64)(size_t)(out + base));
+  const u64 pout = uni64((u64)(size_t)(out + (out_Ls ? (((size_t)poly * out_Ls + limb) << logN) + ((size_t)tile << LT) : base)));   // out_Ls: as in_Ls
   const u64 tw = uni64((u64)(size_t)(twk + ((size_t)limb << logN) + ((size_t)tile << LT)));
   const u64 q = uni64(consts[limb].q);
   const u64 nq = (u64)0 - q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
@@ -225,12 +225,13 @@ RH_DEV void inv_tile_asm_body(u64* lds, const u32 b, const u64* in, const u64* i
                [lp0] "s"((u32)lp), [lp1] "s"((u32)(lp >> 32)) : NTT_TILE_ASM_CLOBBERS)
 template <int S1>
 RH_DEV void inv_cols_asm_body(const u32 b, u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
-                              const LimbConsts* __restrict__ consts, int L) {
+                              const LimbConsts* __restrict__ consts, int L, int Ls = 0) {
+  if (Ls == 0) Ls = L;                     // rows per poly of the block (>= L)
   static_assert(has_asm_cols(S1), "asm column stages exist for S1 = 2..4");
   constexpr int logN = LT + S1;
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
-  const size_t base = (((size_t)(r >> 4) * L + limb) << logN) + (r & 15) * 256;
+  const size_t base = (((size_t)(r >> 4) * Ls + limb) << logN) + (r & 15) * 256;
   const u64 pin = uni64((u64)(size_t)(data + base));
   const u64 tw = uni64((u64)(size_t)(twn + ((size_t)limb << logN)));
   const u64 q = uni64(consts[limb].q);
@@ -244,15 +245,15 @@ RH_DEV void inv_cols_asm_body(const u32 b, u64* data, const tw2* __restrict__ tw
 }
 template <int S1>
 __global__ void __launch_bounds__(256)
-ntt_inv_cols_asm(u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw, const LimbConsts* __restrict__ consts, int L) {
-  inv_cols_asm_body<S1>(blockIdx.x, data, twn, lastw, consts, L);
+ntt_inv_cols_asm(u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw, const LimbConsts* __restrict__ consts, int L, int Ls) {
+  inv_cols_asm_body<S1>(blockIdx.x, data, twn, lastw, consts, L, Ls);
 }
 
 __global__ void __launch_bounds__(256)
 ntt_inv_tile_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts,
-                 int L, int logN, int npoly, int in_Ls) {
+                 int L, int logN, int npoly, int in_Ls, int out_Ls) {
   __shared__ u64 lds[LDS_WORDS];
-  inv_tile_asm_body<false>(lds, blockIdx.x, in, nullptr, out, twk, consts, L, logN, npoly, in_Ls);
+  inv_tile_asm_body<false>(lds, blockIdx.x, in, nullptr, out, twk, consts, L, logN, npoly, in_Ls, out_Ls);
 }
 __global__ void __launch_bounds__(256)
 ntt_inv_tile_mul_asm(const u64* in, const u64* in2, u64* out, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts,

@@ -96,6 +96,49 @@ def test_levels_use_leading_limbs(rh, oracle):
     ring.close()
 
 
+@pytest.mark.parametrize("N", [256, 4096, 8192, 16384, 65536])
+def test_at_level_views_are_batched_and_exact(rh, oracle, N):
+    # rh_ring_*_rows on a batch: forward with one row stride on both sides and the inverse (N = 2^14..2^16) run as ONE batched launch
+    # pair, the element-wise family as one launch with per-operand strides; other shapes fall back to poly-by-poly.  All against the oracle.
+    mods = QI60[:4]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(N)
+    B = 5
+    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    srs = [oracle.SubRingConsts(N, q) for q in mods]
+    v = ring.AtLevel(2)                                            # three of the four limbs
+    want = np.stack([np.stack([oracle.ntt(a[k, i], srs[i]) for i in range(3)]) for k in range(B)])
+    pa = rh.DevicePoly.from_numpy(ring, a)
+    po = rh.DevicePoly.from_numpy(ring, np.zeros_like(a))
+    v.NTT(pa, po)                                                  # out of place, both blocks with 4 limbs per poly
+    assert np.array_equal(po.numpy()[:, :3], want) and not po.numpy()[:, 3].any()
+    assert np.array_equal(pa.numpy(), a)
+    v.NTT(pa, pa)                                                  # in place
+    assert np.array_equal(pa.numpy()[:, :3], want) and np.array_equal(pa.numpy()[:, 3], a[:, 3])
+    dense = v.NewPoly(B)
+    v.INTT(pa, dense)                                              # 4-limb block -> dense 3-limb block
+    assert np.array_equal(dense.numpy(), a[:, :3])
+    v.INTT(pa, pa)                                                 # in place on the 4-limb block
+    assert np.array_equal(pa.numpy(), a)
+    v.NTT(dense, po)                                               # dense -> 4-limb block (different strides: poly by poly)
+    assert np.array_equal(po.numpy()[:, :3], want)
+    v.NTTLazy(pa, po)                                              # exact lazy representatives, strided
+    lz = po.numpy()[:, :3]
+    for k in (0, B - 1):
+        for i in range(3):
+            assert np.array_equal(lz[k, i], oracle.ntt(a[k, i], srs[i], lazy=True))
+    # element-wise: 4-limb x 3-limb -> 4-limb, then a scalar op into the dense block
+    v.MulCoeffsMontgomery(pa, dense, po)
+    g = po.numpy()
+    for k in (0, 2, B - 1):
+        for i in range(3):
+            assert np.array_equal(g[k, i], oracle.vec_op(rh.OPS["MUL_MONT"], a[k, i], a[k, i], a[k, i], 0, 0, mods[i]))
+    v.MulRNSScalarMontgomery(pa, [3, 5, 9], dense)
+    for i in range(3):
+        assert np.array_equal(dense.numpy()[B - 1, i], oracle.vec_op(rh.OPS["MUL_SCALAR_MONT"], a[B - 1, i], None, a[B - 1, i], [3, 5, 9][i], 0, mods[i]))
+    ring.close()
+
+
 def test_at_level_on_a_batch_with_more_limbs(rh, oracle):
     # ring.AtLevel(level) on max-level polys (ring/ring.go:192-213), the idiomatic use inside the reference's evaluators: NTT, INTT and
     # the element-wise family take blocks with more limbs per poly than the view's level (rh_ring_*_rows: limbs 0..level of every
