@@ -24,6 +24,10 @@ typedef unsigned __int128 u128;
 
 RH_DEV u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
 
+// wave-uniform values the compiler cannot prove uniform -> SGPRs (operands of the hand-scheduled bodies)
+RH_DEV u32 uni32(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
+RH_DEV u64 uni64(u64 x) { return ((u64)uni32((u32)(x >> 32)) << 32) | uni32((u32)x); }
+
 // ---- reference primitives (ring/modular_reduction.go) --------------------------------------------------------
 
 RH_DEV u64 cred(u64 a, u64 q) { return a >= q ? a - q : a; }                       // :200-205

@@ -9,9 +9,6 @@
 #include "ntt_kernels.hip.hpp"
 #include "ntt_tile_asm.inc"
 
-// wave-uniform values the compiler cannot prove uniform (loop-carried item index of the persistent kernel) -> SGPRs
-RH_DEV u32 uni32(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
-RH_DEV u64 uni64(u64 x) { return ((u64)uni32((u32)(x >> 32)) << 32) | uni32((u32)x); }
 
 // gap_len > 0: the L transformed rows of a poly skip the limbs [gap0, gap0 + gap_len) of its Ls rows (the digit's own limbs of a
 // hybrid key-switch decomposition): row l is limb l + (l >= gap0 ? gap_len : 0)

@@ -674,6 +674,144 @@ def gen_cols_inv(S1=4):
         emit("global_store_dwordx2 v%d, %s, %%[pin]" % (TW0 + k, pair(X(k))))
 
 
+def gen_3n_cols_post_inv(S1):
+    """3N transform, inverse, b = 1 (ntt3n.hip: ntt3n_cols_post_inv<S1>): the column stages (unscaled, values < 4q) of the six
+    sub-transforms of a limb, then the radix-3 layer and the split merge (post_b1), 6 * 2^S1 coefficients per thread.
+    Data: x[j][k] = row[j * n2 + col + 4096 k] in v[2 (j R + k)]; two temp sets and one spare pair each above them; v0..v127 in all.
+    Operands: wbase (wave's first thread id, SGPR), pin / pout (row base + 256 cb columns, bytes), tw (the limb's six sub-ring
+    natural-order tables, n2 entries apart), l3p (Limb3N of the limb), tp (radix-3 inverse pairs z1, z2 of halves 0 and 1),
+    nq0, nq1, nq, nq2, nq4, q4.  SGPRs: s[36:63] / s[64:91] twiddle buffers, s[92:95] running pointers, s[96:99] carries."""
+    R = 1 << S1
+    logn2 = 12 + S1
+    sB, twB = (1 << logn2) * 8, (1 << logn2) * 16
+    XJ = lambda j, k: 2 * (j * R + k)
+    base = 12 * R
+    Ta, Tb = Tmp(base), Tmp(base + NTMP)
+    Ta.cc, Tb.cc = "s[96:97]", "s[98:99]"
+    E = (base + 2 * NTMP, base + 2 * NTMP + 2)
+    OFF = Tb.T                                                  # R <= 8 offset registers, live only while loads / stores issue
+    BUF = (36, 64)
+    quad = lambda b, i: ("s%d" % (b + 4 * i), "s%d" % (b + 4 * i + 1), "s%d" % (b + 4 * i + 2), "s%d" % (b + 4 * i + 3))
+
+    def tid_offsets():
+        emit("v_mbcnt_lo_u32_b32 v%d, -1, 0" % OFF)
+        emit("v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (OFF, OFF))
+        emit("v_add_u32 v%d, %%[wbase], v%d" % (OFF, OFF))
+        emit("v_lshlrev_b32 v%d, 3, v%d" % (OFF, OFF))
+        for k in range(1, R):
+            emit("v_add_u32 v%d, %d, v%d" % (OFF + k, 32768 * k, OFF))
+
+    def load_tw(buf):                                           # natural-order entries 1 .. R-1 of the table at s[94:95]
+        for i in range(1, R):
+            emit("s_load_dwordx4 s[%d:%d], s[94:95], %d" % (buf + 4 * (i - 1), buf + 4 * (i - 1) + 3, 16 * i))
+
+    def sub_steps(x, y, t):                                     # x <- x - y (64-bit, borrow through the temp set's carry pair)
+        return ["v_sub_co_u32 v%d, %s, v%d, v%d" % (x, t.cc, x, y), "@CARRY",
+                "v_subb_co_u32 v%d, %s, v%d, v%d, %s" % (x + 1, t.cc, x + 1, y + 1, t.cc)]
+
+    def emit_pairs(items, fn):
+        """fn(item, tempset, spare) -> instruction list; consecutive items run interleaved on the two temp sets"""
+        for i in range(0, len(items), 2):
+            a = fn(items[i], Ta, E[0])
+            if i + 1 < len(items):
+                for ins in interleave(a, fn(items[i + 1], Tb, E[1])):
+                    emit(ins)
+            else:
+                for ins in single(a):
+                    emit(ins)
+
+    tid_offsets()
+    emit("s_mov_b64 s[92:93], %[pin]")
+    emit("s_mov_b64 s[94:95], %[tw]")
+    emit("s_nop 4")
+    load_tw(BUF[0])
+    for j in range(6):
+        for k in range(R):
+            emit("global_load_dwordx2 %s, v%d, s[92:93]" % (pair(XJ(j, k)), OFF + k))
+        if j < 5:
+            emit("s_add_u32 s92, s92, %d" % sB)
+            emit("s_addc_u32 s93, s93, 0")
+            emit("s_nop 4")
+    for t in (Ta, Tb):
+        emit("v_mov_b32 v%d, 0" % (t.H + 1))
+        emit("v_mov_b32 v%d, 0" % (t.G + 1))
+    # ---- column stages of sub-transform j: inv_cols_body(scale = 0), twiddle tw[2^st + g]
+    for j in range(6):
+        buf = BUF[j & 1]
+        emit("s_waitcnt lgkmcnt(0)")
+        if j < 5:
+            emit("s_add_u32 s94, s94, %d" % twB)
+            emit("s_addc_u32 s95, s95, 0")
+            emit("s_nop 4")
+            load_tw(BUF[(j + 1) & 1])
+        else:                                                   # the radix-3 constants ride behind the last sub-transform
+            emit("s_load_dwordx4 s[36:39], %[l3p], 16")         # w3
+            for i in range(4):
+                emit("s_load_dwordx4 s[%d:%d], %%[tp], %d" % (40 + 4 * i, 43 + 4 * i, 16 * i))
+        emit("s_waitcnt vmcnt(%d)" % (R * (5 - j)))
+        for it in range(S1):
+            st = S1 - 1 - it
+            h = R >> (st + 1)
+            bfs = []
+            for g in range(1 << st):
+                sg = quad(buf, (1 << st) + g - 1)
+                for e in range(h):
+                    bfs.append((XJ(j, g * 2 * h + e), XJ(j, g * 2 * h + e + h), sg))
+            emit_pairs(bfs, lambda b, t, sp: inv_butterfly_steps(b[0], b[1], None, t, b[2]))
+    # ---- radix-3 layer (post_b1, first loop), all columns; the merge constants load meanwhile into the second buffer
+    emit("s_waitcnt lgkmcnt(0)")
+    for i, off in enumerate((32, 48, 64)):                      # inv_b1, inv_b0z, inv_s
+        emit("s_load_dwordx4 s[%d:%d], %%[l3p], %d" % (64 + 4 * i, 67 + 4 * i, off))
+    W3 = quad(36, 0)
+
+    def radix3(item, t, sp):
+        k, h = item
+        B0, B1, B2 = XJ(3 * h, k), XJ(3 * h + 1, k), XJ(3 * h + 2, k)
+        z1, z2 = quad(40, 2 * h), quad(40, 2 * h + 1)
+        ins = ["v_lshl_add_u64 %s, %s, 0, %%[q4]" % (pair(sp), pair(B1))] + sub_steps(sp, B2, t)     # sp = B1 + 4q - B2
+        ins += shoup_mul_steps(sp, W3, t)                                                            # tt
+        ins += ["v_mov_b32 v%d, v%d" % (t.R, B0), "v_mov_b32 v%d, v%d" % (t.R + 1, B0 + 1)]          # R = B0
+        ins += ["v_lshl_add_u64 %s, %s, 0, %s" % (pair(B0), pair(B0), pair(B1))] + csub_steps(B0, "nq4", t)
+        ins += ["v_lshl_add_u64 %s, %s, 0, %s" % (pair(B0), pair(B0), pair(B2))] + csub_steps(B0, "nq4", t)
+        ins += ["v_lshl_add_u64 %s, %s, 0, %%[q4]" % (pair(t.S), pair(t.R))]                         # S = B0 + 4q
+        ins += ["v_sub_co_u32 v%d, %s, v%d, v%d" % (B1, t.cc, t.S, B1), "@CARRY",
+                "v_subb_co_u32 v%d, %s, v%d, v%d, %s" % (B1 + 1, t.cc, t.S + 1, B1 + 1, t.cc)] + csub_steps(B1, "nq4", t)   # B0 - B1
+        ins += ["v_sub_co_u32 v%d, %s, v%d, v%d" % (B2, t.cc, t.S, B2), "@CARRY",
+                "v_subb_co_u32 v%d, %s, v%d, v%d, %s" % (B2 + 1, t.cc, t.S + 1, B2 + 1, t.cc)] + csub_steps(B2, "nq4", t)   # B0 - B2
+        ins += ["v_lshl_add_u64 %s, %s, 0, %%[q4]" % (pair(B1), pair(B1))] + sub_steps(B1, sp, t) + csub_steps(B1, "nq4", t)  # s1
+        ins += ["v_lshl_add_u64 %s, %s, 0, %s" % (pair(B2), pair(B2), pair(sp))] + csub_steps(B2, "nq4", t)                    # s2
+        ins += shoup_mul_steps(B1, z1, t) + shoup_mul_steps(B2, z2, t)
+        return ins
+    emit_pairs([(k, h) for k in range(R) for h in (0, 1)], radix3)
+    # ---- split merge (post_b1, second loop): canonical outputs
+    emit("s_waitcnt lgkmcnt(0)")
+    IB1, IB0Z, IS = quad(64, 0), quad(64, 1), quad(64, 2)
+
+    def merge(item, t, sp):
+        k, jj = item
+        lo, hi = XJ(jj, k), XJ(jj + 3, k)
+        ins = ["v_lshl_add_u64 %s, %s, 0, %%[q4]" % (pair(hi), pair(hi))] + sub_steps(hi, lo, t)      # d = hi + 4q - lo
+        ins += ["v_mov_b32 v%d, v%d" % (sp, hi), "v_mov_b32 v%d, v%d" % (sp + 1, hi + 1)]
+        ins += shoup_mul_steps(hi, IB1, t) + shoup_mul_steps(sp, IB0Z, t) + shoup_mul_steps(lo, IS, t)
+        ins += ["v_lshl_add_u64 %s, %s, 0, %%[q4]" % (pair(lo), pair(lo))] + sub_steps(lo, sp, t)
+        ins += csub_steps(lo, "nq4", t) + csub_steps(lo, "nq2", t) + csub_steps(lo, "nq", t)
+        ins += csub_steps(hi, "nq2", t) + csub_steps(hi, "nq", t)
+        return ins
+    emit_pairs([(k, jj) for k in range(R) for jj in range(3)], merge)
+    # ---- stores
+    tid_offsets()
+    emit("s_mov_b64 s[92:93], %[pout]")
+    emit("s_nop 4")
+    for j in range(6):
+        for k in range(R):
+            emit("global_store_dwordx2 v%d, %s, s[92:93]" % (OFF + k, pair(XJ(j, k))))
+        if j < 5:
+            emit("s_add_u32 s92, s92, %d" % sB)
+            emit("s_addc_u32 s93, s93, 0")
+            emit("s_nop 4")
+    emit("s_waitcnt vmcnt(0)")
+
+
 def render(name, lines):
     body = "\n".join('  "%s\\n\\t"' % l for l in lines)
     return "#define %s \\\n%s\n" % (name, body.replace("\n", " \\\n"))
@@ -729,4 +867,11 @@ text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_LAZY_ASM_BODY", fwd_
 text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v, clob_s)
 path = sys.argv[1] if len(sys.argv) > 1 else "ntt_tile_asm.inc"
 open(path, "w").write(text)
+text3 = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  3N transform: inverse column stages + radix-3 layer + split merge.\n"
+for s1 in (1, 2, 3):
+    del out[:]
+    gen_3n_cols_post_inv(s1)
+    text3 += render("NTT3N_COLS_POST_INV%d_ASM_BODY" % (1 << s1), list(out))
+text3 += "#define NTT3N_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (", ".join('"v%d"' % i for i in range(128)), clob_s)
+open(os.path.join(os.path.dirname(path), "ntt3n_asm.inc"), "w").write(text3)
 print("wrote", path, "forward:", len(fwd), "VALU", sum(1 for l in fwd if l.startswith("v_")), "| inverse:", len(inv), "VALU", sum(1 for l in inv if l.startswith("v_")))
