@@ -406,7 +406,7 @@ def run_keyswitch(args):
             "dtype": "u64", "data": "synthetic", "verified": verified,
             "config": {"workload": "rlwe.Evaluator.GadgetProduct, N=2^%d, Q=Qi60[0:24], P=Pi60[0:6], beta=%d, batch %d polys per step (whole job), "
                                    "uniform key shared by the batch" % (args.logn, beta, B),
-                       "parallelism": "limb-shard x%d (round-robin over Q++P), all-gather of source limbs per digit and of the P part" % world,
+                       "parallelism": "limb-shard x%d (round-robin over Q++P), one all-gather of the source limbs and one of the P parts per product" % world,
                        "dist_backend": args.dist_backend if world > 1 else None, "rccl_ranks" if args.dist_backend == "nccl" else "dist_ranks": ranks_seen},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * world),
                          "traffic": None, "kernel": "whole gadget product (%d limb transforms + key multiply-accumulate + basis extensions per poly)" % limb_ntts,

@@ -278,6 +278,12 @@ int rh_kshard_digit_range(const rh_kshard* ks, int digit, int* st, int* ed); /* 
 int rh_kshard_digit(rh_kshard* ks, int digit, const uint64_t* src_dev, const uint64_t* cx_loc, const uint64_t* evkQ_loc,
                     const uint64_t* evkP_loc, uint64_t* ct0_loc, uint64_t* ct1_loc, uint64_t* accP0_loc, uint64_t* accP1_loc,
                     int npoly);
+
+/* All digits in one call: src_all_dev = EVERY limb of INTT(cx), (npoly, levelQ + 1, N) in chain order (ONE all-gather of the owners'
+ * limbs instead of one per digit); the other arguments as for rh_kshard_digit.  Same results as the beta rh_kshard_digit calls, with
+ * the structure of the single-GPU product: one pipelined transform of all digit blocks, one multiply-accumulate over all digits. */
+int rh_kshard_product(rh_kshard* ks, const uint64_t* src_all_dev, const uint64_t* cx_loc, const uint64_t* evkQ_loc,
+                      const uint64_t* evkP_loc, uint64_t* ct0_loc, uint64_t* ct1_loc, uint64_t* accP0_loc, uint64_t* accP1_loc, int npoly);
 /* ModDownQPtoQNTT (ring/basis_extension.go:241-258) for the owned Q limbs.  srcP_dev: (npoly, levelP+1, N), the
  * INTTLazy of the P part gathered from its owners. */
 int rh_kshard_moddown(rh_kshard* ks, const uint64_t* srcP_dev, const uint64_t* ctQ_in_loc, uint64_t* ctQ_out_loc, int npoly);

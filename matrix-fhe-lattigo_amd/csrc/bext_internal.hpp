@@ -41,3 +41,6 @@ int rh_bext_launch_sign(hipStream_t st, int N, const BextPlan& p, const u64* in,
 // keyswitch.hip: acc_c (=|+=) MRedLazy(evk_c, c2) for both components
 int rh_gadget_mac(rh_ring* r, const u64* c2, const u64* e0, const u64* e1, u64* a0, u64* a1, int npoly, int L, int first);
 int rh_overflow_margin(const std::vector<u64>& m, int level);
+// keyswitch.hip: all beta digits in one pass, accumulators in registers, the reference's Reduce schedule; see the definition
+int rh_gadget_mac_all(rh_ring* r, const u64* c2, size_t digit_stride, const u64* evk, int beta, int overf, u64* a0, u64* a1, int npoly, int L,
+                      const u64* cx, const int* own_digit, int digit_limbs);

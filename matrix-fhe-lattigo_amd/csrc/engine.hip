@@ -497,26 +497,25 @@ bool rh_can_ntt_digits(const rh_ring* r) {
   const int S1 = r->logN - LT;
   return r->kind == RH_RING_STANDARD && r->asm_tile && r->asm_cols && r->digit_pipeline && S1 >= 2 && S1 <= 4;
 }
-int rh_std_ntt_fwd_digits(rh_ring* r, u64* data, size_t digit_stride, int npoly, int beta, int LQ, int LP, bool lazy_out) {
+int rh_std_ntt_fwd_blocks(rh_ring* r, u64* data, size_t block_stride, int npoly, int nblocks, int Ls, const int* gap0, const int* gap_len,
+                          bool lazy_out) {                  // block j: npoly polys of Ls rows, rows [gap0[j], gap0[j] + gap_len[j]) left alone
   if (!rh_can_ntt_digits(r)) return rh_fail(RH_ERR_UNSUPPORTED, "digit-block transform needs the hand-scheduled bodies (2^14 <= N <= 2^16)");
-  if (npoly <= 0 || beta <= 0) return RH_OK;
+  if (npoly <= 0 || nblocks <= 0) return RH_OK;
   (void)hipGetLastError();
   const int S1 = r->logN - LT;
   hipStream_t st = rh_stream(r);
-  auto rows = [&](int j) {                          // digit j: its transformed rows
-    GapRows g; g.Ls = LQ; g.gap0 = (u32)(j * LP);
-    int gl = LQ - j * LP; if (gl > LP) gl = LP; if (gl < 0) gl = 0;
-    g.gap_len = (u32)gl; g.L = LQ - gl;
+  auto rows = [&](int j) {                          // block j: its transformed rows
+    GapRows g; g.Ls = Ls; g.gap0 = (u32)gap0[j]; g.gap_len = (u32)gap_len[j]; g.L = Ls - gap_len[j];
     return g;
   };
-  for (int j = 0; j <= beta; ++j) {
-    GapRows g1 = j < beta ? rows(j) : GapRows{1, 1, 0, 0}, g2 = j >= 1 ? rows(j - 1) : GapRows{1, 1, 0, 0};
-    const unsigned n1 = j < beta ? (unsigned)npoly * g1.L * 16 : 0, n2 = j >= 1 ? ((unsigned)npoly * g2.L) << S1 : 0;
+  for (int j = 0; j <= nblocks; ++j) {
+    GapRows g1 = j < nblocks ? rows(j) : GapRows{1, 1, 0, 0}, g2 = j >= 1 ? rows(j - 1) : GapRows{1, 1, 0, 0};
+    const unsigned n1 = j < nblocks ? (unsigned)npoly * g1.L * 16 : 0, n2 = j >= 1 ? ((unsigned)npoly * g2.L) << S1 : 0;
     const unsigned grid = n1 > n2 ? n1 : n2;
     if (!grid) continue;
     if (!g1.L) g1.L = 1;
     if (!g2.L) g2.L = 1;
-    u64* d1 = data + (size_t)(j < beta ? j : 0) * digit_stride; u64* d2 = data + (size_t)(j >= 1 ? j - 1 : 0) * digit_stride;
+    u64* d1 = data + (size_t)(j < nblocks ? j : 0) * block_stride; u64* d2 = data + (size_t)(j >= 1 ? j - 1 : 0) * block_stride;
 #define RH_GAP(S, Z) ntt_fwd_fused_gap_asm<S, Z><<<grid, 256, 0, st>>>(d1, n1, g1, d2, n2, npoly, g2, r->d_tw_fwd, r->d_twk_fwd, r->d_consts)
     switch (S1) {
       case 2: if (lazy_out) RH_GAP(2, true); else RH_GAP(2, false); break;
@@ -526,6 +525,15 @@ int rh_std_ntt_fwd_digits(rh_ring* r, u64* data, size_t digit_stride, int npoly,
 #undef RH_GAP
   }
   return check_launch("ntt_fwd_fused_gap_asm");
+}
+int rh_std_ntt_fwd_digits(rh_ring* r, u64* data, size_t digit_stride, int npoly, int beta, int LQ, int LP, bool lazy_out) {
+  if (beta <= 0) return RH_OK;
+  std::vector<int> g0(beta), gl(beta);
+  for (int j = 0; j < beta; ++j) {                  // digit j skips its own limbs [j LP, min((j+1) LP, LQ))
+    int n = LQ - j * LP; if (n > LP) n = LP; if (n < 0) n = 0;
+    g0[j] = j * LP; gl[j] = n;
+  }
+  return rh_std_ntt_fwd_blocks(r, data, digit_stride, npoly, beta, LQ, g0.data(), gl.data(), lazy_out);
 }
 
 // Inverse canonical transform of ONE limb of every poly of a block with in_rows limbs per poly into a dense block of npoly rows

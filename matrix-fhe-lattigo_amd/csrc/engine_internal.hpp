@@ -76,6 +76,8 @@ int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows,
 int rh_std_ntt_fwd_strided(rh_ring* r, u64* data, int npoly, int Lrows, int limb0, int Ls);
 bool rh_can_ntt_digits(const rh_ring* r);
 int rh_std_ntt_fwd_digits(rh_ring* r, u64* data, size_t digit_stride, int npoly, int beta, int LQ, int LP, bool lazy_out = false);
+int rh_std_ntt_fwd_blocks(rh_ring* r, u64* data, size_t block_stride, int npoly, int nblocks, int Ls, const int* gap0, const int* gap_len,
+                          bool lazy_out = false);
 bool rh_can_intt_limb_strided(const rh_ring* r);
 int rh_std_intt_limb_strided(rh_ring* r, const u64* in, int in_rows, int limb, u64* out, int npoly);
 bool rh_can_fuse_submul(const rh_ring* r);

@@ -49,6 +49,7 @@ int rh_gadget_mac(rh_ring* r, const u64* c2, const u64* e0, const u64* e1, u64* 
 // acc_c = sum_i MRedLazy(evk_c[i], c2[i]) with the reference's Reduce schedule (after every `overf` digits and at the end,
 // core/rlwe/evaluator_gadget_product.go:166-187) kept in registers -- the accumulators are written once instead of being
 // read and rewritten per digit.  poly is the fast block index, so the workgroups that share a key row run together.
+struct LimbDigit { signed char d[RH_MAX_LIMBS]; };   // per limb: the digit whose own limbs include it (-1: none)
 // BETA > 0: the digit count at compile time -- the 3 * BETA 16-byte loads of an element pair are issued before the first multiply.
 // Not limited by the vector ALUs (a variant with ONE Montgomery reduction per output, 0.4 x the instructions, ran 8 % slower at
 // 68 VGPRs) nor by key re-reads (PMC: fetch + write = the algorithmic 3.1 GB per launch): 4.8 TB/s over 4 + 2 streams.
@@ -56,7 +57,7 @@ template <int BETA, int PP>
 __global__ void __launch_bounds__(256)
 gadget_mac_all_kernel(const u64* c2, size_t digit_stride, const u64* __restrict__ evk, size_t evk_stride, int beta, int overf,
                       u64* acc0, u64* acc1, unsigned n, const LimbConsts* __restrict__ consts, int L, int npoly,
-                      const u64* cx, int digit_limbs) {   // cx != null: limb l of digit l / digit_limbs is read from cx (:467-468), not from c2
+                      const u64* cx, LimbDigit own) {   // cx != null: limb l is read from cx (:467-468), not from c2, for digit own.d[l]
   // PP polys per workgroup (BETA > 0): the 2 * BETA key words of an element pair are loaded once and used for PP polys
   const u32 groups = ((u32)npoly + PP - 1) / PP;
   const u32 poly0 = (blockIdx.x % groups) * PP, limb = blockIdx.x / groups;
@@ -97,7 +98,7 @@ gadget_mac_all_kernel(const u64* c2, size_t digit_stride, const u64* __restrict_
         const size_t ro = ((size_t)(poly0 + pp) * L + limb) * n;
         ulonglong2 x[BETA];
 #pragma unroll
-        for (int d = 0; d < BETA; ++d) x[d] = ld((cx && (int)limb / digit_limbs == d) ? cx + ro : c2 + (size_t)d * digit_stride + ro);
+        for (int d = 0; d < BETA; ++d) x[d] = ld((cx && own.d[limb] == d) ? cx + ro : c2 + (size_t)d * digit_stride + ro);
         a = {0, 0}; b = {0, 0}; red = 0;
 #pragma unroll
         for (int d = 0; d < BETA; ++d) term(x[d], k0[d], k1[d]);
@@ -107,20 +108,24 @@ gadget_mac_all_kernel(const u64* c2, size_t digit_stride, const u64* __restrict_
       const size_t ro = ((size_t)poly0 * L + limb) * n;               // PP == 1
       a = {0, 0}; b = {0, 0}; red = 0;
       for (int d = 0; d < beta; ++d)
-        term(ld((cx && (int)limb / digit_limbs == d) ? cx + ro : c2 + (size_t)d * digit_stride + ro),
+        term(ld((cx && own.d[limb] == d) ? cx + ro : c2 + (size_t)d * digit_stride + ro),
              ld(evk + ((size_t)d * 2) * evk_stride + eo), ld(evk + ((size_t)d * 2 + 1) * evk_stride + eo));
       finish(ro);
     }
   }
 }
 
-static int mac_all(rh_ring* r, const u64* c2, size_t digit_stride, const u64* evk, int beta, int overf, u64* a0, u64* a1, int npoly, int L,
-                   const u64* cx = nullptr, int digit_limbs = 1) {
+// own_digit[l] (l < L): the digit whose own limbs include limb l (read from cx instead of c2), -1: none; NULL with cx: limb l belongs to
+// digit l / digit_limbs (the unsharded chain)
+int rh_gadget_mac_all(rh_ring* r, const u64* c2, size_t digit_stride, const u64* evk, int beta, int overf, u64* a0, u64* a1, int npoly, int L,
+                      const u64* cx, const int* own_digit, int digit_limbs) {
   const unsigned n = (unsigned)r->N;
   unsigned chunks = (n / 2 + 1023) / 1024; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
+  LimbDigit own;
+  for (int l = 0; l < RH_MAX_LIMBS; ++l) own.d[l] = (signed char)(l < L && cx ? (own_digit ? own_digit[l] : l / (digit_limbs > 0 ? digit_limbs : 1)) : -1);
   const int PPE = npoly >= 8 ? 4 : 1;             // polys per workgroup (same-box A/B at batch 64: 1 / 2 / 4 / 8 -> 9.04 / 8.93 / 8.89 / 8.92 ms per product)
 #define RH_MAC_ALL(B, PP) gadget_mac_all_kernel<B, PP><<<dim3(((unsigned)npoly + PP - 1) / PP * L, chunks), 256, 0, rh_stream(r)>>>( \
-    c2, digit_stride, evk, (size_t)r->L * n, beta, overf, a0, a1, n, r->d_consts, L, npoly, cx, digit_limbs)
+    c2, digit_stride, evk, (size_t)r->L * n, beta, overf, a0, a1, n, r->d_consts, L, npoly, cx, own)
 #define RH_MAC_PP(B) do { if (PPE == 4) RH_MAC_ALL(B, 4); else RH_MAC_ALL(B, 1); } while (0)
   switch (beta) {
     case 2: RH_MAC_PP(2); break;
@@ -133,6 +138,10 @@ static int mac_all(rh_ring* r, const u64* c2, size_t digit_stride, const u64* ev
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_mac_all_kernel launch failed: %s", hipGetErrorString(e));
   return RH_OK;
+}
+static int mac_all(rh_ring* r, const u64* c2, size_t digit_stride, const u64* evk, int beta, int overf, u64* a0, u64* a1, int npoly, int L,
+                   const u64* cx = nullptr, int digit_limbs = 1) {
+  return rh_gadget_mac_all(r, c2, digit_stride, evk, beta, overf, a0, a1, npoly, L, cx, nullptr, digit_limbs);
 }
 
 int rh_overflow_margin(const std::vector<u64>& m, int level) {     // QiOverflowMargin / PiOverflowMargin, core/rlwe/params.go

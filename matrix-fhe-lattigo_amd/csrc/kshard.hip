@@ -27,7 +27,7 @@ struct rh_kshard {
   std::map<int, BextPlan> digit_plans;
   BextPlan md_plan; bool have_md = false;
   std::vector<u64> md_scalars;                           // q_k - (P^-1 mod q_k) Montgomery form, per owned Q limb
-  u64* buf[3] = {nullptr, nullptr, nullptr}; size_t buf_words[3] = {0, 0, 0};   // c2Q, c2P, buffQ
+  u64* buf[5] = {}; size_t buf_words[5] = {};           // c2Q, c2P, buffQ; 3, 4: all digits' c2Q / c2P (rh_kshard_product)
   int reduce = 0, QiOverF = 1, PiOverF = 1;
   std::recursive_mutex mu;                               // one key switch at a time per handle (digits are fed in order)
 };
@@ -77,7 +77,7 @@ extern "C" void rh_kshard_destroy(rh_kshard* ks) {
   if (!ks) return;
   for (auto& kv : ks->digit_plans) rh_bext_free_plan(kv.second);
   if (ks->have_md) rh_bext_free_plan(ks->md_plan);
-  for (int i = 0; i < 3; ++i) if (ks->buf[i]) (void)hipFree(ks->buf[i]);
+  for (int i = 0; i < 5; ++i) if (ks->buf[i]) (void)hipFree(ks->buf[i]);
   delete ks;
 }
 
@@ -177,6 +177,51 @@ extern "C" int rh_kshard_digit(rh_kshard* ks, int digit, const uint64_t* src, co
     if (ks->reduce % ks->QiOverF != 0) if (int rc = reduce_accs(ks, true, ct0_loc, ct1_loc, npoly)) return rc;
     if (ks->reduce % ks->PiOverF != 0) if (int rc = reduce_accs(ks, false, accP0_loc, accP1_loc, npoly)) return rc;
   }
+  return RH_OK;
+}
+
+// All digits of gadgetProductMultiplePLazy (:154-188) for the owned limbs in one call.  src_all: (npoly, levelQ + 1, N) = EVERY limb of
+// INTT(cx) in chain order (one all-gather of the owners' limbs instead of one per digit); the other arguments as for rh_kshard_digit.
+// Per digit the basis extension onto the owned limbs, then ONE pipelined transform of all digit blocks (each skips the digit's own
+// limbs, which the multiply-accumulate reads from cx_loc) and one multiply-accumulate over all digits with the accumulators in
+// registers and the reference's Reduce schedule: the structure of the single-GPU product (keyswitch.hip), same bits.
+extern "C" int rh_kshard_product(rh_kshard* ks, const uint64_t* src_all, const uint64_t* cx_loc, const uint64_t* evkQ_loc,
+                                 const uint64_t* evkP_loc, uint64_t* ct0_loc, uint64_t* ct1_loc, uint64_t* accP0_loc, uint64_t* accP1_loc,
+                                 int npoly) {
+  if (!ks || !src_all || !cx_loc || !evkQ_loc || !ct0_loc || !ct1_loc) return rh_fail(RH_ERR_ARG, "rh_kshard_product: null argument");
+  if (ks->P && (!evkP_loc || !accP0_loc || !accP1_loc)) return rh_fail(RH_ERR_ARG, "rh_kshard_product: null P-part argument");
+  if (npoly <= 0) return RH_OK;
+  rh_ring* RQ = ks->Q; rh_ring* RP = ks->P;
+  (void)hipSetDevice(RQ->device);
+  std::lock_guard<std::recursive_mutex> lk(ks->mu);
+  RhCallScope scope(rh_stream(RQ));
+  const int N = RQ->N, nQ = RQ->L, nP = RP ? RP->L : 0, beta = ks->beta, LQ = ks->levelQ + 1;
+  const size_t wq = (size_t)npoly * nQ * N, wp = (size_t)npoly * nP * N;
+  u64 *c2Q, *c2P = nullptr;
+  if (int rc = ks_buf(ks, 3, (size_t)beta * wq, &c2Q)) return rc;
+  if (nP) if (int rc = ks_buf(ks, 4, (size_t)beta * wp, &c2P)) return rc;
+  std::vector<int> gap0(beta), gap_len(beta), own_digit(nQ, -1), zero(beta, 0);
+  for (int d = 0; d < beta; ++d) {
+    int st, ed; (void)rh_kshard_digit_range(ks, d, &st, &ed);
+    BextPlan* p; bool single;
+    if (int rc = digit_plan(ks, d, &p, &single)) return rc;
+    u64* q = c2Q + (size_t)d * wq; u64* pp = nP ? c2P + (size_t)d * wp : nullptr;
+    if (single) { if (int rc = rh_bext_launch_sign(rh_stream(RQ), N, *p, src_all, LQ, st, q, nQ, pp, nP, npoly)) return rc; }
+    else if (int rc = rh_bext_launch_raw(rh_stream(RQ), N, *p, src_all, LQ, st, q, nQ, pp, nP, nullptr, 0, npoly, BEXT_ADD_RAW)) return rc;
+    gap0[d] = nQ; gap_len[d] = 0;                       // the owned limbs of the digit are a contiguous run of local indices (ownQ ascends)
+    for (int k = 0; k < nQ; ++k)
+      if (ks->ownQ[k] >= st && ks->ownQ[k] < ed) { if (!gap_len[d]) gap0[d] = k; ++gap_len[d]; own_digit[k] = d; }
+    if (!gap_len[d]) gap0[d] = 0;
+  }
+  // (a single-prime digit's sign-aware copy also fills the digit's own limb of its block; like the others it is neither transformed nor read)
+  if (rh_can_ntt_digits(RQ)) { if (int rc = rh_std_ntt_fwd_blocks(RQ, c2Q, wq, npoly, beta, nQ, gap0.data(), gap_len.data(), true)) return rc; }
+  else if (int rc = rh_std_ntt_launch(RQ, c2Q, c2Q, beta * npoly, nQ, 0, false, false, 0)) return rc;
+  if (nP) {
+    if (rh_can_ntt_digits(RP)) { if (int rc = rh_std_ntt_fwd_blocks(RP, c2P, wp, npoly, beta, nP, zero.data(), zero.data(), true)) return rc; }
+    else if (int rc = rh_std_ntt_launch(RP, c2P, c2P, beta * npoly, nP, 0, false, false, 0)) return rc;
+  }
+  if (int rc = rh_gadget_mac_all(RQ, c2Q, wq, evkQ_loc, beta, ks->QiOverF, ct0_loc, ct1_loc, npoly, nQ, cx_loc, own_digit.data(), 1)) return rc;
+  if (nP) if (int rc = rh_gadget_mac_all(RP, c2P, wp, evkP_loc, beta, ks->PiOverF, accP0_loc, accP1_loc, npoly, nP, nullptr, nullptr, 1)) return rc;
   return RH_OK;
 }
 

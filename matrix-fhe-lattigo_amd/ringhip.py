@@ -116,6 +116,7 @@ def lib():
         "rh_kshard_destroy": (None, [vp]), "rh_kshard_num_digits": (i, [vp]),
         "rh_kshard_digit_range": (i, [vp, i, C.POINTER(i), C.POINTER(i)]),
         "rh_kshard_digit": (i, [vp, i, vp, vp, vp, vp, vp, vp, vp, vp, i]),
+        "rh_kshard_product": (i, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i]),
         "rh_kshard_moddown": (i, [vp, vp, vp, vp, i]),
     }
     for name, (res, args) in sig.items():

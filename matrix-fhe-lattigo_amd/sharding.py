@@ -71,12 +71,13 @@ def gather_limbs(local, own, base, st, ed, world, dist):
     if mine:
         block[:, :len(mine)] = local[:, mine]
     parts = all_gather_blocks(block, world, dist)
+    if world == 1:
+        return parts[0] if cmax == ed - st else parts[0][:, :ed - st].contiguous()
     src = torch.empty((npoly, ed - st, N), dtype=local.dtype, device=local.device)
-    pos = [0] * world
-    for g in range(st, ed):
-        r = qp_owner(base + g, world)
-        src[:, g - st] = parts[r][:, pos[r]]
-        pos[r] += 1
+    for r in range(world):                            # one indexed copy per rank: its limbs of the range, in chain order
+        idx = [g - st for g in range(st, ed) if qp_owner(base + g, world) == r]
+        if idx:
+            src[:, idx] = parts[r][:, :len(idx)]
     return src
 
 
@@ -85,8 +86,8 @@ class LimbShardedKeySwitch:
     round-robin over the ranks of one node: rank r owns limbs {i : i mod world == r} and the matching slice of the
     evaluation key.  All arithmetic is the HIP library's (rh_kshard_*, csrc/kshard.hip); this class only moves limbs:
 
-      * per digit, an all-gather of the digit's alpha source limbs of INTT(cx)   (alpha*8*N bytes per poly),
-      * before ModDown, an all-gather of the k+1 limbs of each P-part accumulator.
+      * one all-gather of every limb of INTT(cx) (8*N bytes per limb and poly; digit by digit with per_digit=True),
+      * before ModDown, one all-gather of the k+1 limbs of both P-part accumulators.
 
     Collectives run through torch.distributed on device tensors (backend "nccl" = RCCL over xGMI); with the "gloo"
     backend (tests) the same blocks are staged through the host.  Outputs stay limb-sharded.
@@ -147,9 +148,12 @@ class LimbShardedKeySwitch:
         return gather_limbs(local, own, base, st, ed, self.world, self.dist)
 
     # ---- the product ---------------------------------------------------------------------------------------
-    def GadgetProduct(self, cx, evkQ, evkP, ct0, ct1):
+    def GadgetProduct(self, cx, evkQ, evkP, ct0, ct1, per_digit=False):
         """cx: owned limbs of the NTT-domain input, (npoly, owned Q, N); evkQ / evkP: owned key slices
-        (beta, 2, owned, N) on the device; ct0 / ct1: outputs, owned Q limbs (NTT domain, canonical)."""
+        (beta, 2, owned, N) on the device; ct0 / ct1: outputs, owned Q limbs (NTT domain, canonical).
+        Default: TWO exchanges per product -- every limb of INTT(cx) in one all-gather (rh_kshard_product: all digits in one call,
+        the single-GPU product's structure), then the P parts of both accumulators in one all-gather before ModDown.
+        per_digit=True: the digit-by-digit form (one gather per digit, rh_kshard_digit), kept for comparison."""
         torch, rh, L = self.torch, self.rh, self.rh.lib()
         npoly, nq, npl = cx.shape[0], len(self.ownQ), len(self.ownP)
         cxinv = torch.empty_like(cx)
@@ -157,16 +161,23 @@ class LimbShardedKeySwitch:
         acc0 = torch.empty((npoly, max(npl, 1), self.N), dtype=torch.int64, device=self.device)
         acc1 = torch.empty_like(acc0)
         pP = lambda t: t.data_ptr() if npl else None
-        for d in range(self.beta):
-            st, ed = self.digit_range(d)
-            src = self._gather_limbs(cxinv, self.ownQ, 0, st, ed)
-            rh._check(L.rh_kshard_digit(self._h, d, src.data_ptr(), cx.data_ptr(), evkQ.data_ptr(), pP(evkP) if npl else None,
-                                        ct0.data_ptr(), ct1.data_ptr(), pP(acc0), pP(acc1), npoly))
-        for acc, ct in ((acc0, ct0), (acc1, ct1)):                                              # eval.ModDown (:33-46)
-            if npl:
-                self.ringP.INTTLazy(self._dp(self.ringP, acc), self._dp(self.ringP, acc))
-            srcP = self._gather_limbs(acc, self.ownP, len(self.Q), 0, self.levelP + 1)
-            rh._check(L.rh_kshard_moddown(self._h, srcP.data_ptr(), ct.data_ptr(), ct.data_ptr(), npoly))
+        if per_digit:
+            for d in range(self.beta):
+                st, ed = self.digit_range(d)
+                src = self._gather_limbs(cxinv, self.ownQ, 0, st, ed)
+                rh._check(L.rh_kshard_digit(self._h, d, src.data_ptr(), cx.data_ptr(), evkQ.data_ptr(), pP(evkP) if npl else None,
+                                            ct0.data_ptr(), ct1.data_ptr(), pP(acc0), pP(acc1), npoly))
+        else:
+            src = cxinv if self.world == 1 else self._gather_limbs(cxinv, self.ownQ, 0, 0, self.levelQ + 1)
+            rh._check(L.rh_kshard_product(self._h, src.data_ptr(), cx.data_ptr(), evkQ.data_ptr(), pP(evkP) if npl else None,
+                                          ct0.data_ptr(), ct1.data_ptr(), pP(acc0), pP(acc1), npoly))
+        # eval.ModDown (:33-46): the P parts of both accumulators travel together
+        both = torch.cat((acc0, acc1), dim=0)                                                   # (2 npoly, owned P, N)
+        if npl:
+            self.ringP.INTTLazy(self._dp(self.ringP, both), self._dp(self.ringP, both))
+        srcP = self._gather_limbs(both, self.ownP, len(self.Q), 0, self.levelP + 1)
+        for c, ct in enumerate((ct0, ct1)):
+            rh._check(L.rh_kshard_moddown(self._h, srcP[c * npoly:(c + 1) * npoly].data_ptr(), ct.data_ptr(), ct.data_ptr(), npoly))
 
     def close(self):
         if getattr(self, "_h", None):

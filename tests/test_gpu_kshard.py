@@ -48,13 +48,17 @@ def _run_shard(rh, sharding, N, Q, P, cx, evkQ, evkP, rank, world, dist):
     dkp = ks.to_device(kp) if kp is not None else None
     ct0, ct1 = torch.empty_like(dcx), torch.empty_like(dcx)
     ks.GadgetProduct(dcx, dkq, dkp, ct0, ct1)
+    d0, d1 = torch.empty_like(dcx), torch.empty_like(dcx)
+    ks.GadgetProduct(dcx, dkq, dkp, d0, d1, per_digit=True)             # the digit-by-digit form gives the same bits
     torch.cuda.synchronize()
+    assert torch.equal(d0, ct0) and torch.equal(d1, ct1)
     res = ct0.cpu().numpy().view(np.uint64), ct1.cpu().numpy().view(np.uint64), list(ks.ownQ), list(ks.ownP), ks.beta
     ks.close()
     return res
 
 
-@pytest.mark.parametrize("N,nq,np_", [(4096, 5, 2), (64, 6, 3), (8192, 7, 1 + 1)])
+# N >= 2^14: the pipelined digit-block transform (rows skip the digit's own limbs); (7, 3): digits of 3, 3, 1 limbs (single-prime branch)
+@pytest.mark.parametrize("N,nq,np_", [(4096, 5, 2), (64, 6, 3), (8192, 7, 1 + 1), (16384, 7, 3), (16384, 6, 2)])
 def test_single_rank_shard_path_equals_unsharded(rh, N, nq, np_):
     from matrix_fhe_lattigo_amd import sharding
     Q, P, beta, cx, evkQ, evkP = _case(N, nq, np_, 2, N + nq)
@@ -93,7 +97,7 @@ def _worker(rank, world, port, q, N, nq, np_):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,N,nq,np_", [(2, 4096, 5, 2), (4, 64, 5, 2), (3, 8192, 6, 3)])
+@pytest.mark.parametrize("world,N,nq,np_", [(2, 4096, 5, 2), (4, 64, 5, 2), (3, 8192, 6, 3), (2, 16384, 7, 3)])
 def test_multi_rank_limb_shard_gloo(world, N, nq, np_):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
