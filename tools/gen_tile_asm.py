@@ -812,6 +812,139 @@ def gen_3n_cols_post_inv(S1):
     emit("s_waitcnt vmcnt(0)")
 
 
+def gen_3n_pre_cols_fwd(S1):
+    """3N transform, forward, b = 1 (ntt3n.hip: ntt3n_pre_cols_fwd<S1>): split + radix-3 layer (pre_b1) on the six values of every column,
+    then the column stages of the six sub-transforms (outputs < 8q, any representative: the tile stages reduce).  Same register map,
+    operands and SGPR use as gen_3n_cols_post_inv; tp = the forward radix-3 pairs."""
+    R = 1 << S1
+    logn2 = 12 + S1
+    sB, twB = (1 << logn2) * 8, (1 << logn2) * 16
+    loc = {(j, k): 2 * (j * R + k) for j in range(6) for k in range(R)}        # register of x[j][k]; the radix-3 layer renames
+    base = 12 * R
+    Ta, Tb = Tmp(base), Tmp(base + NTMP)
+    Ta.cc, Tb.cc = "s[96:97]", "s[98:99]"
+    E = (base + 2 * NTMP, base + 2 * NTMP + 2)
+    OFF = Tb.T
+    quad = lambda b, i: ("s%d" % (b + 4 * i), "s%d" % (b + 4 * i + 1), "s%d" % (b + 4 * i + 2), "s%d" % (b + 4 * i + 3))
+
+    def tid_offsets():
+        emit("v_mbcnt_lo_u32_b32 v%d, -1, 0" % OFF)
+        emit("v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (OFF, OFF))
+        emit("v_add_u32 v%d, %%[wbase], v%d" % (OFF, OFF))
+        emit("v_lshlrev_b32 v%d, 3, v%d" % (OFF, OFF))
+        for k in range(1, R):
+            emit("v_add_u32 v%d, %d, v%d" % (OFF + k, 32768 * k, OFF))
+
+    def load_tw(buf):
+        for i in range(1, R):
+            emit("s_load_dwordx4 s[%d:%d], s[94:95], %d" % (buf + 4 * (i - 1), buf + 4 * (i - 1) + 3, 16 * i))
+
+    def sub_steps(x, y, t):
+        return ["v_sub_co_u32 v%d, %s, v%d, v%d" % (x, t.cc, x, y), "@CARRY",
+                "v_subb_co_u32 v%d, %s, v%d, v%d, %s" % (x + 1, t.cc, x + 1, y + 1, t.cc)]
+
+    def rsub_steps(x, a, t):                                    # x <- a - x
+        return ["v_sub_co_u32 v%d, %s, v%d, v%d" % (x, t.cc, a, x), "@CARRY",
+                "v_subb_co_u32 v%d, %s, v%d, v%d, %s" % (x + 1, t.cc, a + 1, x + 1, t.cc)]
+
+    def add_steps(x, y):
+        return ["v_lshl_add_u64 %s, %s, 0, %s" % (pair(x), pair(x), pair(y))]
+
+    def addq4(x):
+        return ["v_lshl_add_u64 %s, %s, 0, %%[q4]" % (pair(x), pair(x))]
+
+    def emit_pairs(items, fn):
+        for i in range(0, len(items), 2):
+            a = fn(items[i], Ta, E[0])
+            if i + 1 < len(items):
+                for ins in interleave(a, fn(items[i + 1], Tb, E[1])):
+                    emit(ins)
+            else:
+                for ins in single(a):
+                    emit(ins)
+
+    tid_offsets()
+    emit("s_mov_b64 s[92:93], %[pin]")
+    emit("s_mov_b64 s[94:95], %[tw]")
+    emit("s_nop 4")
+    emit("s_load_dwordx4 s[36:39], %[l3p], 0")                 # zeta
+    emit("s_load_dwordx4 s[40:43], %[l3p], 16")                # w3
+    for i in range(4):
+        emit("s_load_dwordx4 s[%d:%d], %%[tp], %d" % (44 + 4 * i, 47 + 4 * i, 16 * i))
+    load_tw(64)                                                 # sub-transform 0's column twiddles
+    for j in range(6):
+        for k in range(R):
+            emit("global_load_dwordx2 %s, v%d, s[92:93]" % (pair(loc[(j, k)]), OFF + k))
+        if j < 5:
+            emit("s_add_u32 s92, s92, %d" % sB)
+            emit("s_addc_u32 s93, s93, 0")
+            emit("s_nop 4")
+    for t in (Ta, Tb):
+        emit("v_mov_b32 v%d, 0" % (t.H + 1))
+        emit("v_mov_b32 v%d, 0" % (t.G + 1))
+    emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    ZETA, W3 = quad(36, 0), quad(36, 1)
+    # ---- inputs < 8q -> < 4q, then the split: lo' = lo + z hi, hi' = lo + hi - z hi
+    emit_pairs([(j, k) for k in range(R) for j in range(6)], lambda it, t, sp: csub_steps(loc[it], "nq4", t))
+
+    def split(item, t, sp):
+        k, jj = item
+        lo, hi = loc[(jj, k)], loc[(jj + 3, k)]
+        ins = ["v_mov_b32 v%d, v%d" % (sp, hi), "v_mov_b32 v%d, v%d" % (sp + 1, hi + 1)] + shoup_mul_steps(sp, ZETA, t)   # tt
+        ins += add_steps(hi, lo) + csub_steps(hi, "nq4", t)                                  # lo + hi
+        ins += addq4(hi) + sub_steps(hi, sp, t) + csub_steps(hi, "nq4", t)                   # - tt
+        ins += add_steps(lo, sp) + csub_steps(lo, "nq4", t)                                  # lo + tt
+        return ins
+    emit_pairs([(k, jj) for k in range(R) for jj in range(3)], split)
+
+    def radix3(item, t, sp):
+        k, h = item
+        b0, b1, b2 = loc[(3 * h, k)], loc[(3 * h + 1, k)], loc[(3 * h + 2, k)]
+        z1, z2 = quad(44, 2 * h), quad(44, 2 * h + 1)
+        ins = shoup_mul_steps(b1, z1, t) + shoup_mul_steps(b2, z2, t)                         # t1, t2 in place
+        ins += ["v_lshl_add_u64 %s, %s, 0, %%[q4]" % (pair(sp), pair(b1))] + sub_steps(sp, b2, t) + shoup_mul_steps(sp, W3, t)   # t3
+        ins += ["v_mov_b32 v%d, v%d" % (t.R, b0), "v_mov_b32 v%d, v%d" % (t.R + 1, b0 + 1)]  # R = b0
+        ins += add_steps(b0, b1) + csub_steps(b0, "nq4", t) + add_steps(b0, b2) + csub_steps(b0, "nq4", t)      # x0
+        ins += ["v_lshl_add_u64 %s, %s, 0, %%[q4]" % (pair(t.S), pair(t.R))]                 # S = b0 + 4q
+        ins += rsub_steps(b2, t.S, t) + csub_steps(b2, "nq4", t) + add_steps(b2, sp) + csub_steps(b2, "nq4", t)  # x1 = (b0 - t2) + t3, in b2's registers
+        ins += rsub_steps(b1, t.S, t) + csub_steps(b1, "nq4", t) + addq4(b1) + sub_steps(b1, sp, t) + csub_steps(b1, "nq4", t)   # x2 = (b0 - t1) - t3, in b1's
+        return ins
+    emit_pairs([(k, h) for k in range(R) for h in (0, 1)], radix3)
+    for k in range(R):                                          # x1 / x2 sit in each other's registers
+        for h in (0, 1):
+            loc[(3 * h + 1, k)], loc[(3 * h + 2, k)] = loc[(3 * h + 2, k)], loc[(3 * h + 1, k)]
+    # ---- column stages of sub-transform j (fwd_cols_body: stage st, group g -> tw[2^st + g])
+    BUF = (64, 36)
+    for j in range(6):
+        emit("s_waitcnt lgkmcnt(0)")
+        if j < 5:
+            emit("s_add_u32 s94, s94, %d" % twB)
+            emit("s_addc_u32 s95, s95, 0")
+            emit("s_nop 4")
+            load_tw(BUF[(j + 1) & 1])
+        buf = BUF[j & 1]
+        for st in range(S1):
+            h = R >> (st + 1)
+            bfs = []
+            for g in range(1 << st):
+                sg = quad(buf, (1 << st) + g - 1)
+                for e in range(h):
+                    bfs.append((loc[(j, g * 2 * h + e)], loc[(j, g * 2 * h + e + h)], sg))
+            emit_pairs(bfs, lambda b, t, sp: butterfly_steps(b[0], b[1], None, t, b[2]))
+    # ---- stores
+    tid_offsets()
+    emit("s_mov_b64 s[92:93], %[pout]")
+    emit("s_nop 4")
+    for j in range(6):
+        for k in range(R):
+            emit("global_store_dwordx2 v%d, %s, s[92:93]" % (OFF + k, pair(loc[(j, k)])))
+        if j < 5:
+            emit("s_add_u32 s92, s92, %d" % sB)
+            emit("s_addc_u32 s93, s93, 0")
+            emit("s_nop 4")
+    emit("s_waitcnt vmcnt(0)")
+
+
 def render(name, lines):
     body = "\n".join('  "%s\\n\\t"' % l for l in lines)
     return "#define %s \\\n%s\n" % (name, body.replace("\n", " \\\n"))
@@ -867,11 +1000,14 @@ text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_LAZY_ASM_BODY", fwd_
 text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v, clob_s)
 path = sys.argv[1] if len(sys.argv) > 1 else "ntt_tile_asm.inc"
 open(path, "w").write(text)
-text3 = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  3N transform: inverse column stages + radix-3 layer + split merge.\n"
+text3 = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  3N transform: column stages fused with the radix-3 layer and the split / merge, both directions.\n"
 for s1 in (1, 2, 3):
     del out[:]
     gen_3n_cols_post_inv(s1)
     text3 += render("NTT3N_COLS_POST_INV%d_ASM_BODY" % (1 << s1), list(out))
+    del out[:]
+    gen_3n_pre_cols_fwd(s1)
+    text3 += render("NTT3N_PRE_COLS_FWD%d_ASM_BODY" % (1 << s1), list(out))
 text3 += "#define NTT3N_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (", ".join('"v%d"' % i for i in range(128)), clob_s)
 open(os.path.join(os.path.dirname(path), "ntt3n_asm.inc"), "w").write(text3)
 print("wrote", path, "forward:", len(fwd), "VALU", sum(1 for l in fwd if l.startswith("v_")), "| inverse:", len(inv), "VALU", sum(1 for l in inv if l.startswith("v_")))
