@@ -14,6 +14,7 @@
 #include "ntt_kernels.hip.hpp"
 #include "vec_kernels.hip.hpp"
 #include "ntt_kernels_asm.hip.hpp"
+#include "ntt3n_kernels_asm.hip.hpp"
 #include "engine_internal.hpp"
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -574,6 +575,12 @@ int rh_std_intt_rows(rh_ring* r, const u64* in, int in_rows, u64* out, int out_r
   return check_launch("strided inverse transform");
 }
 
+// ---- 3N transform (ntt3n.hip), b = 1: the hand-scheduled layer kernels live in this translation unit with the tile bodies they fuse with
+void rh_3n_launch_layer(bool inverse, int S1, unsigned nblocks, hipStream_t st, const u64* in, u64* out, const N3Layer& a) {
+#define RH_3NL(S) do { if (inverse) ntt3n_layer_asm<S, true><<<nblocks, 256, 0, st>>>(in, out, a); else ntt3n_layer_asm<S, false><<<nblocks, 256, 0, st>>>(in, out, a); } while (0)
+  if (S1 == 1) RH_3NL(1); else if (S1 == 2) RH_3NL(2); else RH_3NL(3);
+#undef RH_3NL
+}
 bool rh_can_fuse_submul(const rh_ring* r) { return r->kind == RH_RING_STANDARD && r->logN >= LT && r->fuse_submul; }
 // Forward canonical transform of `buf` (in place up to its tile stages) fused with out = MRed(2q - y + NTT(buf), s_limb):
 // column stages as usual, then ntt_fwd_tile_submul.  y / out: (poly, limb) blocks with y_rows / out_rows limbs per poly.

@@ -93,6 +93,7 @@ int rh_upload_consts(rh_ring* r, const std::vector<LimbConsts>& hc);
 void rh_rescale_teardown(rh_ring* r);
 int rh_rescale_reserve(rh_ring* r, int npoly);
 int rh_ring3n_reserve(rh_ring* r, int npoly);
+void rh_3n_launch_layer(bool inverse, int S1, unsigned nblocks, hipStream_t st, const u64* in, u64* out, const N3Layer& a);
 // 3N-cyclotomic transform (ntt3n.hip)
 int rh_ring3n_setup(rh_ring* r, std::vector<LimbConsts>& hc);
 void rh_ring3n_teardown(rh_ring* r);

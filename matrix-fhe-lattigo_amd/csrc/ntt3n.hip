@@ -17,15 +17,6 @@
 #include <cstring>
 #include "engine_internal.hpp"
 #include "hostmath.hpp"
-#include "ntt3n_asm.inc"
-
-struct Limb3N {          // per-limb constants of the non-radix-2 layers (Shoup pairs, standard form)
-  tw2 zeta;              // omega^(N/2)
-  tw2 w3;                // omega^N (primitive cube root)
-  tw2 inv_b1;            // (z^5 - z)^-1 * (N/2)^-1
-  tw2 inv_b0z;           // z * (z^5 - z)^-1 * (N/2)^-1
-  tw2 inv_s;             // (N/2)^-1
-};
 
 struct rh_ring3n_state {
   int a = 0, b = 0, nb = 0, n2 = 0, log_n2 = 0;
@@ -328,31 +319,6 @@ ntt3n_cols_post_inv(const u64* in, u64* out, int N, const tw2* __restrict__ r3, 
   }
 }
 
-// The same kernel with a hand-scheduled body (tools/gen_tile_asm.py: gen_3n_cols_post_inv): identical arithmetic (Shoup butterflies with
-// the approximate quotient, values < 4q between layers, canonical outputs), about half the instructions of the compiled one.
-template <int S1>
-__global__ void __launch_bounds__(256)
-ntt3n_cols_post_inv_asm(const u64* in, u64* out, int N, const tw2* __restrict__ r3, int r3_stride, const Limb3N* __restrict__ l3,
-                        const LimbConsts* __restrict__ consts, int L, const tw2* __restrict__ sub_tw) {
-  constexpr int log_n2 = 12 + S1;
-  const u32 limb = blockIdx.x % (u32)L, rr = blockIdx.x / (u32)L;
-  const size_t base = ((size_t)(rr >> 4) * L + limb) * N + (rr & 15) * 256;
-  const u64 pin = uni64((u64)(size_t)(in + base)), pout = uni64((u64)(size_t)(out + base));
-  const u64 tw = uni64((u64)(size_t)(sub_tw + ((size_t)(limb * 6) << log_n2)));
-  const u64 l3p = uni64((u64)(size_t)(l3 + limb)), tp = uni64((u64)(size_t)(r3 + (size_t)limb * r3_stride));
-  const u64 q = uni64(consts[limb].q);
-  const u64 nq = (u64)0 - q, nq2 = (u64)0 - 2 * q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
-  const u32 wbase = uni32(threadIdx.x & ~63u);
-#define RH_3N_POST_ASM(BODY)                                                                                                     \
-  asm volatile(BODY : : [wbase] "s"(wbase), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw), [l3p] "s"(l3p), [tp] "s"(tp),      \
-               [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4)      \
-               : NTT3N_ASM_CLOBBERS)
-  if constexpr (S1 == 3) RH_3N_POST_ASM(NTT3N_COLS_POST_INV8_ASM_BODY);
-  else if constexpr (S1 == 2) RH_3N_POST_ASM(NTT3N_COLS_POST_INV4_ASM_BODY);
-  else RH_3N_POST_ASM(NTT3N_COLS_POST_INV2_ASM_BODY);
-#undef RH_3N_POST_ASM
-}
-
 // ---- tiled permutation (log_n2 >= 10): a tile is {j_low: 32} x {j_high: 32} x {nb blocks} for one j_mid.
 // Reads are 256 B runs (32 consecutive j), writes are nb*256 B runs (32 consecutive bitrev(j) x nb ranks).
 #define PT 5
@@ -536,37 +502,9 @@ static int ensure_tmp(rh_ring3n_state* s, size_t words) {
 // (N = 3*2^k) transform needs a transposition SOMEWHERE (natural-order output of a column-first decomposition is a comb of
 // stride 2^S1 * nb words per tile), and the only place where it costs nothing is the host boundary.  rh_ring_ntt3n_reorder converts.
 // Supported for b = 1 rings with n2 >= 4096 (N >= 24576); the host-limb interface always speaks the reference order.
-// forward twin (gen_3n_pre_cols_fwd)
-template <int S1>
-__global__ void __launch_bounds__(256)
-ntt3n_pre_cols_fwd_asm(const u64* in, u64* out, int N, const tw2* __restrict__ r3, int r3_stride, const Limb3N* __restrict__ l3,
-                       const LimbConsts* __restrict__ consts, int L, const tw2* __restrict__ sub_tw) {
-  constexpr int log_n2 = 12 + S1;
-  const u32 limb = blockIdx.x % (u32)L, rr = blockIdx.x / (u32)L;
-  const size_t base = ((size_t)(rr >> 4) * L + limb) * N + (rr & 15) * 256;
-  const u64 pin = uni64((u64)(size_t)(in + base)), pout = uni64((u64)(size_t)(out + base));
-  const u64 tw = uni64((u64)(size_t)(sub_tw + ((size_t)(limb * 6) << log_n2)));
-  const u64 l3p = uni64((u64)(size_t)(l3 + limb)), tp = uni64((u64)(size_t)(r3 + (size_t)limb * r3_stride));
-  const u64 q = uni64(consts[limb].q);
-  const u64 nq = (u64)0 - q, nq2 = (u64)0 - 2 * q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
-  const u32 wbase = uni32(threadIdx.x & ~63u);
-#define RH_3N_PRE_ASM(BODY)                                                                                                      \
-  asm volatile(BODY : : [wbase] "s"(wbase), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw), [l3p] "s"(l3p), [tp] "s"(tp),      \
-               [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4)      \
-               : NTT3N_ASM_CLOBBERS)
-  if constexpr (S1 == 3) RH_3N_PRE_ASM(NTT3N_PRE_COLS_FWD8_ASM_BODY);
-  else if constexpr (S1 == 2) RH_3N_PRE_ASM(NTT3N_PRE_COLS_FWD4_ASM_BODY);
-  else RH_3N_PRE_ASM(NTT3N_PRE_COLS_FWD2_ASM_BODY);
-#undef RH_3N_PRE_ASM
-}
 static void launch_pre_cols_fwd(rh_ring* r, int S1sub, dim3 g, hipStream_t st, const u64* in, u64* out, int N, const tw2* r3, int r3_stride,
                                 const Limb3N* l3, const LimbConsts* c, int Lrows, const tw2* stw, int log_n2) {
-  if (r->asm_tile) {
-    if (S1sub == 1) ntt3n_pre_cols_fwd_asm<1><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw);
-    else if (S1sub == 2) ntt3n_pre_cols_fwd_asm<2><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw);
-    else ntt3n_pre_cols_fwd_asm<3><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw);
-    return;
-  }
+  if (r->asm_tile) { rh_3n_launch_layer(false, S1sub, g.x, st, in, out, N3Layer{r3, r3_stride, l3, c, Lrows, stw, N}); return; }
   if (S1sub == 1) ntt3n_pre_cols_fwd<1><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw, log_n2);
   else if (S1sub == 2) ntt3n_pre_cols_fwd<2><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw, log_n2);
   else ntt3n_pre_cols_fwd<3><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw, log_n2);
@@ -574,12 +512,7 @@ static void launch_pre_cols_fwd(rh_ring* r, int S1sub, dim3 g, hipStream_t st, c
 
 static void launch_cols_post_inv(rh_ring* r, int S1sub, dim3 g, hipStream_t st, const u64* in, u64* out, int N, const tw2* r3, int r3_stride,
                                  const Limb3N* l3, const LimbConsts* c, int Lrows, const tw2* stw, int log_n2) {
-  if (r->asm_tile) {                                  // hand-scheduled body (tuning asm_tile = 0: the compiled kernel)
-    if (S1sub == 1) ntt3n_cols_post_inv_asm<1><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw);
-    else if (S1sub == 2) ntt3n_cols_post_inv_asm<2><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw);
-    else ntt3n_cols_post_inv_asm<3><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw);
-    return;
-  }
+  if (r->asm_tile) { rh_3n_launch_layer(true, S1sub, g.x, st, in, out, N3Layer{r3, r3_stride, l3, c, Lrows, stw, N}); return; }   // hand-scheduled body (tuning asm_tile = 0: the compiled kernel)
   if (S1sub == 1) ntt3n_cols_post_inv<1><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw, log_n2);
   else if (S1sub == 2) ntt3n_cols_post_inv<2><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw, log_n2);
   else ntt3n_cols_post_inv<3><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw, log_n2);
