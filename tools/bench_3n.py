@@ -2,18 +2,13 @@
 """3N transform timing: bench_3n.py <log2(N/3)> <limbs> <batch> [block_order 0/1]   (profiling aid: rocprofv3 --kernel-trace --stats -- python3 tools/bench_3n.py 13 1 1024)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import matrix_fhe_lattigo_amd as rh
-import oracle
-from test_oracle_ntt3n import find_prime_3n
+from primes3n import moduli_3n
 a, L, B = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 N = 3 << a
-mods, q = [], find_prime_3n(N, 60)
-while len(mods) < L:
-    if oracle.lib().orc_is_prime(q):
-        mods.append(q)
-    q += 3 * N
+mods = moduli_3n(N, L)
 dev = torch.device("cuda", 0); stream = torch.cuda.current_stream()
 ring = rh.Ring(N, mods, kind=rh.Matrix3N); ring.set_stream(stream.cuda_stream)
 if len(sys.argv) > 4:

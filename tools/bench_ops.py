@@ -132,16 +132,10 @@ del pq, pp, poq, pop, xq, xp, oq, op_, p0, p1, c0, c1, evq, evp
 be.close(); rq.close(); rp.close(); torch.cuda.empty_cache()
 
 # ---- config 2 / 4 rings: 3N transform ----
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-from test_oracle_ntt3n import find_prime_3n
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from primes3n import moduli_3n
 for N, L, B in ((3 << 13, 1, 1024), (3 << 16, 24, 16)):
-    mods = []
-    import oracle
-    q = find_prime_3n(N, 60)
-    while len(mods) < L:
-        if oracle.lib().orc_is_prime(q):
-            mods.append(q)
-        q += 3 * N
+    mods = moduli_3n(N, L)
     ring = rh.Ring(N, mods, kind=rh.Matrix3N); ring.set_stream(stream.cuda_stream)
     x = rand_block(B, mods, N)
     px = rh.DevicePoly.from_torch(ring, x)
