@@ -53,7 +53,16 @@ for op, nops in (("ADD", 3), ("MUL_MONT", 3), ("MUL_MONT_THEN_ADD", 4), ("MFORM"
 po = rh.DevicePoly.from_torch(ring, torch.empty((B, L - 1, N), dtype=torch.int64, device=dev))
 res.append(entry("DivRoundByLastModulusNTT N=2^16 L=16->15 (1 INTT + 15 NTT + 2 elementwise passes)",
                  timed(lambda: ring.DivRoundByLastModulusNTT(pa, po), reps=5), 8.0 * N * (2 * (L - 1) + 1) * B + 16.0 * N * L * B, B, "poly"))
+# automorphism in the NTT domain (ring/automorphism.go:12-109): an index gather over every limb
+res.append(entry("AutomorphismNTT (X -> X^5) N=2^16 L=16", timed(lambda: ring.AutomorphismNTT(pa, 5, pc)), 16.0 * N * L * B, B, "poly"))
 del pa, pb, pc, a, b, c, po
+ring.close(); torch.cuda.empty_cache()
+# conjugate-invariant ring (ring/ntt.go:716-1311): fold + the negacyclic core on the 4N-th-root tables.  QI60 moduli are 1 mod 2^18 = 4N.
+ring = rh.Ring(N, QI60[:L], kind=rh.ConjugateInvariant); ring.set_stream(stream.cuda_stream)
+a = rand_block(B, QI60[:L], N); pa = rh.DevicePoly.from_torch(ring, a)
+res.append(entry("conjugate-invariant Ring.NTT N=2^16 L=16", timed(lambda: ring.NTT(pa, pa)), 16.0 * N * L * B, B, "poly"))
+res.append(entry("conjugate-invariant Ring.INTT N=2^16 L=16", timed(lambda: ring.INTT(pa, pa)), 16.0 * N * L * B, B, "poly"))
+del pa, a
 ring.close(); torch.cuda.empty_cache()
 
 # ---- config 3: N = 2^15, 16 limbs: c = INTT(NTT(a) * NTT(b)) as schemes/ckks/evaluator.go:821-834 sequences it ----
