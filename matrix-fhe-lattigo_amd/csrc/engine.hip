@@ -673,6 +673,28 @@ static int ci_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
   if (!rows) return RH_OK;
   unsigned chunks = ((unsigned)r->N / 2 + 256) / 256; if (chunks > 64) chunks = 64;
   (void)hipGetLastError();
+  const int S1 = r->logN - LT;
+  if (r->asm_tile && r->asm_cols && r->fuse_ci && S1 >= 2 && S1 <= 4) {
+    // the fold rides in the column stages (a thread owns the column pair (c, 4096 - c) the fold couples; column 0 apart): no pass of its own
+    hipStream_t st = rh_stream(r);
+    const size_t toff = (size_t)limb0 * r->N;
+    const CiFoldTw* cf = reinterpret_cast<const CiFoldTw*>(r->d_cifold + limb0);
+    const LimbConsts* c = r->d_consts + limb0;
+    const unsigned g8 = rows * 8, g0 = (rows + 63) / 64;
+#define RH_CI(S, INV, SRC, TW, LW) do { ntt_cols_ci_asm<S, INV><<<g8, 256, 0, st>>>(SRC, out, TW, LW, cf, c, Lrows);  \
+                                        ci_col0_kernel<S, INV><<<g0, 64, 0, st>>>(SRC, out, TW, LW, cf, c, Lrows, rows); } while (0)
+    if (!inverse) {
+      if (S1 == 4) RH_CI(4, false, in, r->d_tw_fwd + toff, nullptr); else if (S1 == 3) RH_CI(3, false, in, r->d_tw_fwd + toff, nullptr);
+      else RH_CI(2, false, in, r->d_tw_fwd + toff, nullptr);
+      if (int rc = check_launch("ntt_cols_ci_asm")) return rc;
+      return rh_std_ntt_launch(r, out, out, npoly, Lrows, limb0, false, false, 2);          // tile stages
+    }
+    if (int rc = rh_std_ntt_launch(r, in, out, npoly, Lrows, limb0, true, false, 2)) return rc;   // tile stages
+    if (S1 == 4) RH_CI(4, true, out, r->d_tw_inv + toff, r->d_lastw + limb0); else if (S1 == 3) RH_CI(3, true, out, r->d_tw_inv + toff, r->d_lastw + limb0);
+    else RH_CI(2, true, out, r->d_tw_inv + toff, r->d_lastw + limb0);
+#undef RH_CI
+    return check_launch("ntt_cols_ci_asm");
+  }
   if (!inverse) {
     ci_fold_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(in, out, r->logN, r->d_cifold + limb0, r->d_consts + limb0, Lrows, 0);
     return rh_std_ntt_launch(r, out, out, npoly, Lrows, limb0, false, false, 0);
@@ -818,6 +840,7 @@ extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
   if (!strcmp(key, "auto_span_rows")) { if (value < 1) return rh_fail(RH_ERR_ARG, "auto_span_rows must be >= 1"); r->auto_span_rows = (int)value; return RH_OK; }
   if (!strcmp(key, "fuse_submul")) { r->fuse_submul = (int)value; return RH_OK; }
   if (!strcmp(key, "digit_pipeline")) { r->digit_pipeline = (int)value; return RH_OK; }
+  if (!strcmp(key, "fuse_ci")) { r->fuse_ci = (int)value; return RH_OK; }
   if (!strcmp(key, "perm_inv_shape")) { r->perm_inv_shape = (int)value; return RH_OK; }
   if (!strcmp(key, "perm_fwd_shape")) { r->perm_fwd_shape = (int)value; return RH_OK; }
   if (!strcmp(key, "fuse3n")) { r->fuse3n = (int)value; return RH_OK; }

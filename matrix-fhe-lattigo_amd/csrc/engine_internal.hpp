@@ -43,6 +43,7 @@ struct rh_ring {
   std::vector<void*> rescale_tables;      // per level, rescale.hip
   u64* d_rs[2] = {nullptr, nullptr}; size_t rs_words[2] = {0, 0};
   int fuse_submul = 1;            // ModDown / rescale: subtract-multiply fused into the forward tile kernel's epilogue
+  int fuse_ci = 1;                // conjugate-invariant ring: the fold inside the column stages (N = 2^14 .. 2^16)
   int digit_pipeline = 1;         // key switch: all digit blocks transformed by one pipelined stream of launches (N = 2^14 .. 2^16)
   int perm_fwd_shape = 44;        // 3N permutation tiles as 10*A + B: block-order runs of 2^A words, rank-order runs of nb * 2^B words
   int perm_inv_shape = 44;        // (4, 4) measured best on MI355X for both directions (12 KiB tiles, 13 workgroups per CU): 1.06 -> 0.91 ms at the config 4 ring

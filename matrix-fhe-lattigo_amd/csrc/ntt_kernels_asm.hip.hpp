@@ -8,6 +8,7 @@
 #include "ring_types.hip.hpp"
 #include "ntt_kernels.hip.hpp"
 #include "ntt_tile_asm.inc"
+#include "ntt_ci_asm.inc"
 
 
 // gap_len > 0: the L transformed rows of a poly skip the limbs [gap0, gap0 + gap_len) of its Ls rows (the digit's own limbs of a
@@ -272,3 +273,114 @@ ntt_inv_fused_asm(const u64* in1, const u64* in1b, u64* out1, unsigned n1, int n
   if (blockIdx.x < n1) inv_tile_asm_body<MUL>(lds, blockIdx.x, in1, in1b, out1, twk, consts, L, logN, npoly1);
 }
 
+// ---- conjugate-invariant ring (ring/ntt.go:716-1311): the fold fused with the column stages (tools/gen_tile_asm.py: gen_cols_ci).
+// Unit b = (limb, group g < 8, poly): thread t owns columns c = 256 g + t + 1 and 4096 - c, whose elements the fold couples.
+// Column 0 (its own mirror image, with the two special coefficients 0 and N/2) is ci_col0_kernel.
+struct CiFoldTw { tw2 f, b; };            // = CiFold (engine_internal.hpp): fold twiddles roots_fwd[1] / roots_bwd[1]
+template <int S1, bool INV>
+__global__ void __launch_bounds__(256)
+ntt_cols_ci_asm(const u64* in, u64* out, const tw2* __restrict__ twn, const tw2* __restrict__ lastw, const CiFoldTw* __restrict__ fold,
+                const LimbConsts* __restrict__ consts, int L) {
+  static_assert(has_asm_cols(S1), "asm column stages exist for S1 = 2..4");
+  constexpr int logN = LT + S1;
+  const u32 b = blockIdx.x;
+  const u32 limb = b % (u32)L, rr = b / (u32)L, g = rr & 7;
+  const size_t row = ((size_t)(rr >> 3) * L + limb) << logN;
+  const size_t offa = row + 256 * g + 1, offb = row + 256 * (15 - g);
+  const u64 pina = uni64((u64)(size_t)(in + offa)), pinb = uni64((u64)(size_t)(in + offb));
+  const u64 pouta = uni64((u64)(size_t)(out + offa)), poutb = uni64((u64)(size_t)(out + offb));
+  const u64 tw = uni64((u64)(size_t)(twn + ((size_t)limb << logN)));
+  const u64 q = uni64(consts[limb].q);
+  const u64 nq = (u64)0 - q, nq2 = (u64)0 - 2 * q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
+  const tw2 F = INV ? fold[limb].b : fold[limb].f;
+  const u64 fw = uni64(F.w), fp = uni64(F.wp);
+  const u32 tid = threadIdx.x;
+  if constexpr (INV) {
+    const u64 iw = uni64(consts[limb].ninv_w), ip = uni64(consts[limb].ninv_wp);
+    const u64 lw = uni64(lastw[limb].w), lp = uni64(lastw[limb].wp);
+#define RH_CI_INV_ASM(BODY)                                                                                                      \
+    asm volatile(BODY : : [tid] "v"(tid), [pina] "s"(pina), [pinb] "s"(pinb), [pouta] "s"(pouta), [poutb] "s"(poutb), [tw] "s"(tw), \
+                 [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4),     \
+                 [fw0] "s"((u32)fw), [fw1] "s"((u32)(fw >> 32)), [fp0] "s"((u32)fp), [fp1] "s"((u32)(fp >> 32)),                \
+                 [iw0] "s"((u32)iw), [iw1] "s"((u32)(iw >> 32)), [ip0] "s"((u32)ip), [ip1] "s"((u32)(ip >> 32)),                \
+                 [lw0] "s"((u32)lw), [lw1] "s"((u32)(lw >> 32)), [lp0] "s"((u32)lp), [lp1] "s"((u32)(lp >> 32)) : NTT_TILE_ASM_CLOBBERS)
+    if constexpr (S1 == 4) RH_CI_INV_ASM(NTT_CI_COLS16_INV_ASM_BODY);
+    else if constexpr (S1 == 3) RH_CI_INV_ASM(NTT_CI_COLS8_INV_ASM_BODY);
+    else RH_CI_INV_ASM(NTT_CI_COLS4_INV_ASM_BODY);
+#undef RH_CI_INV_ASM
+  } else {
+#define RH_CI_FWD_ASM(BODY)                                                                                                      \
+    asm volatile(BODY : : [tid] "v"(tid), [pina] "s"(pina), [pinb] "s"(pinb), [pouta] "s"(pouta), [poutb] "s"(poutb), [tw] "s"(tw), \
+                 [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4),     \
+                 [fw0] "s"((u32)fw), [fw1] "s"((u32)(fw >> 32)), [fp0] "s"((u32)fp), [fp1] "s"((u32)(fp >> 32)) : NTT_TILE_ASM_CLOBBERS)
+    if constexpr (S1 == 4) RH_CI_FWD_ASM(NTT_CI_COLS16_FWD_ASM_BODY);
+    else if constexpr (S1 == 3) RH_CI_FWD_ASM(NTT_CI_COLS8_FWD_ASM_BODY);
+    else RH_CI_FWD_ASM(NTT_CI_COLS4_FWD_ASM_BODY);
+#undef RH_CI_FWD_ASM
+  }
+}
+// column 0 of every (poly, limb) row: coefficients 4096 k, k < R.  Coefficient 0 is not folded (forward) / doubled (inverse), N/2 folds
+// with itself, k folds with R - k; column stages as fwd_cols_body<ShoupPolicy> / inv_cols_body(scale = 1).  One thread per row.
+template <int S1, bool INV>
+__global__ void __launch_bounds__(64)
+ci_col0_kernel(const u64* in, u64* out, const tw2* __restrict__ twn, const tw2* __restrict__ lastw, const CiFoldTw* __restrict__ fold,
+               const LimbConsts* __restrict__ consts, int L, unsigned rows) {
+  constexpr int R = 1 << S1, logN = LT + S1;
+  const unsigned row = blockIdx.x * 64 + threadIdx.x;
+  if (row >= rows) return;
+  const u32 limb = row % (u32)L;
+  const LimbConsts c = consts[limb];
+  const tw2* tw = twn + ((size_t)limb << logN);
+  const tw2 F = INV ? fold[limb].b : fold[limb].f;
+  ShoupPolicy p; p.init(c);
+  const u64 q4 = 4 * c.q;
+  const size_t base = (size_t)row << logN;
+  u64 x[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) x[k] = in[base + ((size_t)k << LT)];
+  auto fold_all = [&](bool canonical) {
+    for (int k = 1; k < R / 2; ++k) {
+      const u64 a = csub(x[k], q4), b = csub(x[R - k], q4);
+      const u64 va = a + q4 - shoup_mul(b, F.w, F.wp, c.nq), vb = b + q4 - shoup_mul(a, F.w, F.wp, c.nq);
+      x[k] = canonical ? canon8(va, c.q) : va; x[R - k] = canonical ? canon8(vb, c.q) : vb;
+    }
+    const u64 m = csub(x[R / 2], q4);
+    const u64 vm = m + q4 - shoup_mul(m, F.w, F.wp, c.nq);
+    x[R / 2] = canonical ? canon8(vm, c.q) : vm;
+  };
+  if constexpr (!INV) {
+    fold_all(false);                                            // x[0] unchanged (ring/ntt.go:770)
+#pragma unroll
+    for (int s = 0; s < S1; ++s) {
+      const int h = R >> (s + 1);
+#pragma unroll
+      for (int g = 0; g < (1 << s); ++g) {
+        const tw2 w = tw[(1 << s) + g];
+#pragma unroll
+        for (int e = 0; e < h; ++e) p.fwd(x[g * 2 * h + e], x[g * 2 * h + e + h], w, false);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int s = S1 - 1; s >= 1; --s) {
+      const int hh = R >> (s + 1);
+#pragma unroll
+      for (int g = 0; g < (1 << s); ++g) {
+        const tw2 w = tw[(1 << s) + g];
+#pragma unroll
+        for (int e = 0; e < hh; ++e) p.inv(x[g * 2 * hh + e], x[g * 2 * hh + e + hh], w);
+      }
+    }
+    const tw2 wl = lastw[limb];
+#pragma unroll
+    for (int e = 0; e < R / 2; ++e) {
+      const u64 U = x[e], V = x[e + R / 2], d = U + q4 - V;
+      x[e] = canon4(shoup_mul(U + V, c.ninv_w, c.ninv_wp, c.nq), c.q);
+      x[e + R / 2] = canon4(shoup_mul(d, wl.w, wl.wp, c.nq), c.q);
+    }
+    x[0] = cred(2 * x[0], c.q);                                 // p2[0] = CRed(p2[0] << 1) (:1157)
+    fold_all(true);
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) out[base + ((size_t)k << LT)] = x[k];
+}

@@ -35,7 +35,8 @@ def test_oracle_ci_matches_standard_ring(oracle, logN):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("logN", [4, 8, 12, 13, 15])
+# logN >= 14: the fold runs inside the hand-scheduled column stages (a thread owns the column pair the fold couples, column 0 apart)
+@pytest.mark.parametrize("logN", [4, 8, 12, 13, 14, 15, 16])
 def test_gpu_ci_vs_oracle(rh, oracle, logN):
     N, mods = 1 << logN, QI60[:3]
     ring = rh.Ring(N, mods, kind=rh.ConjugateInvariant)
@@ -53,6 +54,16 @@ def test_gpu_ci_vs_oracle(rh, oracle, logN):
     assert np.array_equal(o.numpy() % np.array(mods, dtype=np.uint64)[None, :, None], exp)
     ring.INTT(o, o)
     assert np.array_equal(o.numpy(), a)
+    ring.NTT(p, p)                                                # in place, then back out of place
+    assert np.array_equal(p.numpy(), exp)
+    ring.INTT(p, o)
+    assert np.array_equal(o.numpy(), a) and np.array_equal(p.numpy(), exp)
+    ring.set_tuning("fuse_ci", 0)                                 # the fold as a pass of its own: same bits
+    ring.INTT(p, p)
+    assert np.array_equal(p.numpy(), a)
+    ring.NTT(p, p)
+    assert np.array_equal(p.numpy(), exp)
+    ring.set_tuning("fuse_ci", 1)
     assert np.array_equal(ring.SubRings[1].NTT(a[0, 1]), exp[0, 1])
     assert np.array_equal(ring.SubRings[2].INTT(exp[1, 2]), a[1, 2])
     ring.close()

@@ -945,6 +945,108 @@ def gen_3n_pre_cols_fwd(S1):
     emit("s_waitcnt vmcnt(0)")
 
 
+def gen_cols_ci(S1, inverse):
+    """Conjugate-invariant ring (ring/ntt.go:716-1311): the fold fused with the column stages.  The fold couples coefficient jx with N - jx,
+    i.e. element k of column c with element R-1-k of column 4096 - c: a thread owns BOTH columns (c = 256 g + t + 1 and 4096 - c, g < 8),
+    A[k] in v[2k], B[k] in v[2 (R + k)].  Forward: va = a + 4q - F b, vb = b + 4q - F a (ci_fold_kernel, engine.hip), then the column
+    stages of gen_cols on both columns.  Inverse: the stages of gen_cols_inv (N^-1 folded in, canonical), then the fold with canonical
+    outputs.  Column 0 (its own mirror) is a separate small kernel.  Operands: tid, pina / pinb (bytes: row base + (256 g + 1) columns,
+    row base + 256 (15 - g) columns), pouta / poutb, tw, nq0, nq1, nq, nq2, nq4, q4, fw0 fw1 fp0 fp1 (the fold twiddle, Shoup pair),
+    inverse also iw0 iw1 ip0 ip1 lw0 lw1 lp0 lp1."""
+    R = 1 << S1
+    A = lambda k: 2 * k
+    B = lambda k: 2 * (R + k)
+    base = 4 * R
+    Ta, Tb = Tmp(base), Tmp(base + NTMP)
+    Ta.cc, Tb.cc = "s[96:97]", "s[98:99]"
+    E = (base + 2 * NTMP, base + 2 * NTMP + 2, base + 2 * NTMP + 4, base + 2 * NTMP + 6)
+    OA, OB = base, base + R                                     # 2R <= 32 offset registers in the temp area while loads / stores issue
+    F = ("%[fw0]", "%[fw1]", "%[fp0]", "%[fp1]")
+
+    def offsets():
+        emit("v_lshlrev_b32 v%d, 3, %%[tid]" % OA)
+        emit("v_sub_u32 v%d, 2040, v%d" % (OB, OA))            # (255 - t) * 8
+        for k in range(1, R):
+            emit("v_add_u32 v%d, %d, v%d" % (OA + k, 32768 * k, OA))
+            emit("v_add_u32 v%d, %d, v%d" % (OB + k, 32768 * k, OB))
+
+    def sub_steps(x, y, t):
+        return ["v_sub_co_u32 v%d, %s, v%d, v%d" % (x, t.cc, x, y), "@CARRY",
+                "v_subb_co_u32 v%d, %s, v%d, v%d, %s" % (x + 1, t.cc, x + 1, y + 1, t.cc)]
+
+    def emit_pairs(items, fn):
+        for i in range(0, len(items), 2):
+            a = fn(items[i], Ta, (E[0], E[1]))
+            if i + 1 < len(items):
+                for ins in interleave(a, fn(items[i + 1], Tb, (E[2], E[3]))):
+                    emit(ins)
+            else:
+                for ins in single(a):
+                    emit(ins)
+
+    def fold(item, t, sp):
+        a, b = A(item), B(R - 1 - item)
+        ea, eb = sp
+        ins = [] if inverse else csub_steps(a, "nq4", t) + csub_steps(b, "nq4", t)
+        ins += ["v_mov_b32 v%d, v%d" % (ea, a), "v_mov_b32 v%d, v%d" % (ea + 1, a + 1),
+                "v_mov_b32 v%d, v%d" % (eb, b), "v_mov_b32 v%d, v%d" % (eb + 1, b + 1)]
+        ins += shoup_mul_steps(ea, F, t) + shoup_mul_steps(eb, F, t)
+        ins += ["v_lshl_add_u64 %s, %s, 0, %%[q4]" % (pair(a), pair(a))] + sub_steps(a, eb, t)
+        ins += ["v_lshl_add_u64 %s, %s, 0, %%[q4]" % (pair(b), pair(b))] + sub_steps(b, ea, t)
+        if inverse:
+            for x in (a, b):
+                ins += csub_steps(x, "nq4", t) + csub_steps(x, "nq2", t) + csub_steps(x, "nq", t)
+        return ins
+
+    if inverse:
+        for slot in range(1, R - 1):
+            emit("s_load_dwordx4 s[%d:%d], %%[tw], %d" % (36 + 4 * slot, 39 + 4 * slot, 16 * (slot + 1)))
+    else:
+        for slot in range(R - 1):
+            emit("s_load_dwordx4 s[%d:%d], %%[tw], %d" % (36 + 4 * slot, 39 + 4 * slot, 16 * (slot + 1)))
+    offsets()
+    for k in range(R):
+        emit("global_load_dwordx2 %s, v%d, %%[pina]" % (pair(A(k)), OA + k))
+        emit("global_load_dwordx2 %s, v%d, %%[pinb]" % (pair(B(R - 1 - k)), OB + R - 1 - k))
+    for t in (Ta, Tb):
+        emit("v_mov_b32 v%d, 0" % (t.H + 1))
+        emit("v_mov_b32 v%d, 0" % (t.G + 1))
+    emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    sgq = lambda slot: ("s%d" % (36 + 4 * slot), "s%d" % (37 + 4 * slot), "s%d" % (38 + 4 * slot), "s%d" % (39 + 4 * slot))
+    if not inverse:
+        emit_pairs(list(range(R)), fold)
+        for st in range(S1):
+            h = R >> (st + 1)
+            bfs = []
+            for g in range(1 << st):
+                sg = sgq((1 << st) - 1 + g)
+                for e in range(h):
+                    for X_ in (A, B):                           # the two columns alternate on the two temp sets
+                        bfs.append((X_(g * 2 * h + e), X_(g * 2 * h + e + h), sg))
+            emit_pairs(bfs, lambda b, t, sp: butterfly_steps(b[0], b[1], None, t, b[2]))
+    else:
+        for u in range(S1 - 1, 0, -1):
+            h = (R >> 1) >> u
+            bfs = []
+            for g in range(1 << u):
+                sg = sgq((1 << u) - 1 + g)
+                for e in range(h):
+                    for X_ in (A, B):
+                        bfs.append((X_(g * 2 * h + e), X_(g * 2 * h + e + h), sg))
+            emit_pairs(bfs, lambda b, t, sp: inv_butterfly_steps(b[0], b[1], None, t, b[2]))
+        last = []
+        for e in range(R >> 1):
+            for X_ in (A, B):
+                last.append((X_(e), X_(e + (R >> 1))))
+        emit_pairs(last, lambda b, t, sp: scaled_last_butterfly_steps(b[0], b[1], t))
+        emit_pairs(list(range(R)), fold)
+    offsets()
+    for k in range(R):
+        emit("global_store_dwordx2 v%d, %s, %%[pouta]" % (OA + k, pair(A(k))))
+        emit("global_store_dwordx2 v%d, %s, %%[poutb]" % (OB + k, pair(B(k))))
+    emit("s_waitcnt vmcnt(0)")
+
+
 def render(name, lines):
     body = "\n".join('  "%s\\n\\t"' % l for l in lines)
     return "#define %s \\\n%s\n" % (name, body.replace("\n", " \\\n"))
@@ -1010,4 +1112,11 @@ for s1 in (1, 2, 3):
     text3 += render("NTT3N_PRE_COLS_FWD%d_ASM_BODY" % (1 << s1), list(out))
 text3 += "#define NTT3N_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (", ".join('"v%d"' % i for i in range(128)), clob_s)
 open(os.path.join(os.path.dirname(path), "ntt3n_asm.inc"), "w").write(text3)
+textc = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  Conjugate-invariant ring: fold fused with the column stages, both directions.\n"
+for s1 in (2, 3, 4):
+    for ci_inv in (False, True):
+        del out[:]
+        gen_cols_ci(s1, ci_inv)
+        textc += render("NTT_CI_COLS%d_%s_ASM_BODY" % (1 << s1, "INV" if ci_inv else "FWD"), list(out))
+open(os.path.join(os.path.dirname(path), "ntt_ci_asm.inc"), "w").write(textc)
 print("wrote", path, "forward:", len(fwd), "VALU", sum(1 for l in fwd if l.startswith("v_")), "| inverse:", len(inv), "VALU", sum(1 for l in inv if l.startswith("v_")))
