@@ -92,6 +92,9 @@ int rh_dev_alloc(rh_ring* r, size_t words, uint64_t** dptr);
 int rh_dev_free(rh_ring* r, uint64_t* dptr);
 int rh_dev_upload(rh_ring* r, uint64_t* dst_dev, const uint64_t* src_host, size_t words);
 int rh_dev_download(rh_ring* r, uint64_t* dst_host, const uint64_t* src_dev, size_t words);
+/* Poly.CopyLvl (ring/poly.go) on device blocks: limbs 0..level of every poly, blocks with src_rows / dst_rows >= level+1 limbs per poly;
+ * asynchronous on the ring's stream */
+int rh_ring_copy_rows(rh_ring* r, uint64_t* dst_dev, int dst_rows, const uint64_t* src_dev, int src_rows, int npoly, int level);
 
 /* ---- NumberTheoreticTransformer interface, one limb, host pointers (ring/ntt.go:17-22; SubRing.NTT/NTTLazy/INTT/
  * INTTLazy ring/subring_ops.go:235-252).  p1 and p2 hold N words each and may alias.  Synchronous.
@@ -173,7 +176,8 @@ int rh_ring_vec_op_rows(rh_ring* r, int opcode, const uint64_t* p1_dev, int rows
  *                                          (:112-126) and their Many forms (:56-88, :160-192); p0 is modified in
  *                                          place exactly as the reference modifies its input / buffer
  *   rh_ring_div_by_last_modulus_many_ntt  NTT domain: DivFloorByLastModulusManyNTT(:32-52), DivRoundByLastModulusNTT
- *                                          (:92-108), DivRoundByLastModulusManyNTT(:130-156); p0 is not modified   */
+ *                                          (:92-108), DivRoundByLastModulusManyNTT(:130-156); p0 is not modified
+ * All three ring types (the 3N ring is what schemes/matrix_ckks/evaluator.go:235 rescales on); the fused kernels are the standard ring's. */
 int rh_ring_div_by_last_modulus_many(rh_ring* r, int round, int level, int nb, uint64_t* p0_dev, uint64_t* p1_dev, int p1_rows, int npoly);
 int rh_ring_div_by_last_modulus_many_ntt(rh_ring* r, int round, int level, int nb, const uint64_t* p0_dev, uint64_t* p1_dev, int p1_rows, int npoly);
 

@@ -282,6 +282,19 @@ extern "C" int rh_dev_upload(rh_ring* r, uint64_t* dst, const uint64_t* src, siz
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "upload: %s", hipGetErrorString(e));
   return RH_OK;
 }
+// Poly.CopyLvl on device blocks (ring/poly.go): limbs 0..level of every poly of src (src_rows limbs per poly) into dst (dst_rows limbs per
+// poly), asynchronous on the ring's stream
+extern "C" int rh_ring_copy_rows(rh_ring* r, uint64_t* dst, int dst_rows, const uint64_t* src, int src_rows, int npoly, int level) {
+  if (!r || !dst || !src) return rh_fail(RH_ERR_ARG, "rh_ring_copy_rows: null argument");
+  if (level < 0 || level >= r->L || dst_rows < level + 1 || src_rows < level + 1 || npoly < 0) return rh_fail(RH_ERR_ARG, "rh_ring_copy_rows: bad level / rows / npoly");
+  if (npoly == 0) return RH_OK;
+  (void)hipSetDevice(r->device);
+  const size_t N = (size_t)r->N;
+  hipError_t e = hipMemcpy2DAsync(dst, (size_t)dst_rows * N * 8, src, (size_t)src_rows * N * 8, (size_t)(level + 1) * N * 8, (size_t)npoly,
+                                  hipMemcpyDeviceToDevice, rh_stream(r));
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "rh_ring_copy_rows: %s", hipGetErrorString(e));
+  return RH_OK;
+}
 extern "C" int rh_dev_download(rh_ring* r, uint64_t* dst, const uint64_t* src, size_t words) {
   if (!r || !dst || !src) return rh_fail(RH_ERR_ARG, "rh_dev_download: null argument");
   hipError_t e = hipMemcpyAsync(dst, src, words * 8, hipMemcpyDeviceToHost, rh_stream(r));
@@ -704,6 +717,16 @@ static int ci_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
   return check_launch("ci_fold_kernel");
 }
 
+// canonical transform of limbs [limb0, limb0 + Lrows) of a dense block, for a ring of any type (rescale.hip)
+int rh_ring_ntt_any(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse) {
+  if (r->kind == RH_RING_3N) {
+    std::lock_guard<std::recursive_mutex> lk(r->mu);
+    return rh_ring3n_ntt_launch(r, in, out, npoly, Lrows, limb0, inverse, r->block_order3n != 0);
+  }
+  if (r->kind == RH_RING_CI) return ci_ntt_launch(r, in, out, npoly, Lrows, limb0, inverse);
+  return rh_std_ntt_launch(r, in, out, npoly, Lrows, limb0, inverse, false, 0);
+}
+
 static int ntt_batch(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, bool inverse, bool lazy, int phase = 0) {
   if (!r || !in || !out) return rh_fail(RH_ERR_ARG, "ntt: null argument");
   if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "ntt: level %d out of range [0,%d)", level, r->L);
@@ -829,7 +852,7 @@ extern "C" int rh_ring_reserve(rh_ring* r, int npoly) {
   if (!r || npoly < 0) return rh_fail(RH_ERR_ARG, "rh_ring_reserve: bad argument");
   (void)hipSetDevice(r->device);
   std::lock_guard<std::recursive_mutex> lk(r->mu);
-  if (r->kind == RH_RING_3N) return rh_ring3n_reserve(r, npoly);
+  if (r->kind == RH_RING_3N) if (int rc = rh_ring3n_reserve(r, npoly)) return rc;
   return rh_rescale_reserve(r, npoly);
 }
 

@@ -103,7 +103,6 @@ static int ensure_scratch(rh_ring* r, int which, size_t words) {
 
 static int check_args(rh_ring* r, int level, int nb, const void* p0, const void* p1, int npoly, int p1_rows) {
   if (!r || !p0 || !p1) return rh_fail(RH_ERR_ARG, "rescale: null argument");
-  if (r->kind != RH_RING_STANDARD) return rh_fail(RH_ERR_UNSUPPORTED, "rescale: standard rings only");
   if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "rescale: level %d out of range [0,%d)", level, r->L);
   if (nb < 0 || nb > level) return rh_fail(RH_ERR_ARG, "rescale: nbRescales %d exceeds level %d", nb, level);
   if (npoly < 0) return rh_fail(RH_ERR_ARG, "rescale: npoly < 0");
@@ -159,6 +158,16 @@ extern "C" int rh_ring_div_by_last_modulus_many_ntt(rh_ring* r, int round, int l
     if (int rc = ensure_scratch(r, 1, (size_t)npoly * level * N)) return rc;
     RescaleLimb* T; if (int rc = rescale_table(r, level, &T)) return rc;
     u64* tmp = r->d_rs[0]; u64* buff = r->d_rs[1];
+    if (r->kind != RH_RING_STANDARD) {
+      // 3N and conjugate-invariant rings (schemes/matrix_ckks/evaluator.go:235 rescales on the 3N ring): the same steps with the ring's own
+      // transform -- INTT of the last limb, re-expansion under every remaining modulus, NTT, subtract-multiply (ring/scaling.go:97-124)
+      gather_limb_kernel<<<grid, 256, 0, rh_stream(r)>>>(p0, level + 1, level, tmp, N);
+      if (int rc = rh_ring_ntt_any(r, tmp, tmp, npoly, 1, level, true)) return rc;
+      rescale_expand_kernel<<<grid, 256, 0, rh_stream(r)>>>(round ? 1 : 0, tmp, buff, level, level, N, r->moduli[level], T);
+      if (level > 0) if (int rc = rh_ring_ntt_any(r, buff, buff, npoly, level, 0, false)) return rc;
+      rescale_finish_kernel<<<grid, 256, 0, rh_stream(r)>>>(buff, level, p0, level + 1, p1, p1_rows, level, N, T);
+      return launched("rescale (NTT domain)");
+    }
     if (rh_can_intt_limb_strided(r)) {               // the inverse tile stages read the last limb where it lies
       if (int rc = rh_std_intt_limb_strided(r, p0, level + 1, level, tmp, npoly)) return rc;
     } else {
@@ -181,7 +190,7 @@ extern "C" int rh_ring_div_by_last_modulus_many_ntt(rh_ring* r, int round, int l
   // nb > 1: INTT everything, divide nb times in the coefficient domain, NTT what is left (:44-51, :142-150)
   if (int rc = ensure_scratch(r, 1, (size_t)npoly * (level + 1) * N)) return rc;
   u64* buff = r->d_rs[1];
-  if (int rc = rh_std_ntt_launch(r, p0, buff, npoly, level + 1, 0, true, false, 0)) return rc;
+  if (int rc = rh_ring_ntt_any(r, p0, buff, npoly, level + 1, 0, true)) return rc;
   for (int j = 0; j < nb; ++j) {
     const int lv = level - j;
     RescaleLimb* T; if (int rc = rescale_table(r, lv, &T)) return rc;
@@ -192,15 +201,14 @@ extern "C" int rh_ring_div_by_last_modulus_many_ntt(rh_ring* r, int round, int l
   if (int rc = ensure_scratch(r, 0, (size_t)npoly * out_limbs * N)) return rc;
   u64* cmp = r->d_rs[0];
   if (int rc = copy_leading_limbs(r, cmp, out_limbs, buff, level + 1, out_limbs, npoly)) return rc;
-  if (int rc = rh_std_ntt_launch(r, cmp, cmp, npoly, out_limbs, 0, false, false, 0)) return rc;
+  if (int rc = rh_ring_ntt_any(r, cmp, cmp, npoly, out_limbs, 0, false)) return rc;
   if (int rc = copy_leading_limbs(r, p1, p1_rows, cmp, out_limbs, out_limbs, npoly)) return rc;
   return launched("rescale many (NTT domain)");
 }
 
-// rh_ring_reserve, standard rings: the rescale scratch for batches of up to npoly polys and the per-level constant tables, so
+// rh_ring_reserve: the rescale scratch for batches of up to npoly polys and the per-level constant tables, so
 // that no later call allocates (hipMalloc / hipFree synchronise the device and cannot be captured in a HIP graph)
 int rh_rescale_reserve(rh_ring* r, int npoly) {
-  if (r->kind != RH_RING_STANDARD) return RH_OK;
   if (int rc = ensure_scratch(r, 0, (size_t)npoly * r->L * r->N)) return rc;
   if (int rc = ensure_scratch(r, 1, (size_t)npoly * r->L * r->N)) return rc;
   for (int lv = 1; lv < r->L; ++lv) { RescaleLimb* T; if (int rc = rescale_table(r, lv, &T)) return rc; }

@@ -83,6 +83,7 @@ def lib():
         "rh_ring_set_stream": (i, [vp, vp]), "rh_ring_sync": (i, [vp]), "rh_ring_reserve": (i, [vp, i]),
         "rh_dev_alloc": (i, [vp, sz, C.POINTER(vp)]), "rh_dev_free": (i, [vp, vp]),
         "rh_dev_upload": (i, [vp, vp, U64P, sz]), "rh_dev_download": (i, [vp, U64P, vp, sz]),
+        "rh_ring_copy_rows": (i, [vp, vp, i, vp, i, i, i]),
         "rh_ntt_forward": (i, [vp, i, U64P, U64P]), "rh_ntt_forward_lazy": (i, [vp, i, U64P, U64P]),
         "rh_ntt_backward": (i, [vp, i, U64P, U64P]), "rh_ntt_backward_lazy": (i, [vp, i, U64P, U64P]),
         "rh_ring_ntt": (i, [vp, vp, vp, i, i, i]), "rh_ring_intt": (i, [vp, vp, vp, i, i, i]),
@@ -331,6 +332,12 @@ class Ring:
     def NTT3NReorder(self, p1, p2, to_reference=True):
         """3N rings: NTT-domain block between block order (tuning ntt3n_block_order) and the Go transformer's order; out of place"""
         self._chk(p1, p2); _check(lib().rh_ring_ntt3n_reorder(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 1 if to_reference else 0))
+
+    def CopyLvl(self, p1, p2):
+        """p2 <- limbs 0..level of p1 (Poly.CopyLvl, ring/poly.go), blocks may carry more limbs per poly"""
+        if p1.npoly != p2.npoly:
+            raise RingHipError("CopyLvl: blocks differ in poly count")
+        _check(lib().rh_ring_copy_rows(self._h, p2.ptr, p2.limbs, p1.ptr, p1.limbs, p1.npoly, self.level))
 
     def NTTMany(self, pairs):
         """Ring.NTT(p1, p2) for every (p1, p2) of `pairs` in one call (rh_ring_ntt_many): one software pipeline through all blocks"""

@@ -75,6 +75,42 @@ class MatrixCKKSEvaluator:
         ctOut.IsNTT = False
 
 
+    def levelsConsumedPerRescaling(self):
+        """evaluator.go:313-319"""
+        return 1
+
+    def Rescale(self, op0, opOut):
+        """evaluator.go:208-243: divides every component by the last modulus of its level with ring.DivRoundByLastModulusManyNTT on the
+        3N ring (`nbRescales` = levelsConsumedPerRescaling() times); opOut's components hold op0.Level() + 1 - nbRescales limbs.  Like the
+        reference it calls the NTT-domain form whatever the ciphertext's IsNTT says, and copies the flag.  (Scale bookkeeping is host-side
+        metadata of the reference's Ciphertext and not part of this mirror.)"""
+        nb = self.levelsConsumedPerRescaling()
+        if op0.Level() <= nb - 1:
+            raise RingHipError("cannot Rescale: input Ciphertext level is too low")
+        if op0.Degree() != opOut.Degree():
+            raise RingHipError("cannot Rescale: opOut must have the degree of op0")
+        rq = self.ringQ.AtLevel(op0.Level())
+        for vin, vout in zip(op0.Value, opOut.Value):
+            rq.DivRoundByLastModulusManyNTT(nb, vin, vout)
+        opOut.IsNTT = op0.IsNTT
+
+    def Add(self, ct0, ct1, ctOut):
+        """evaluator.go:60-102: component-wise ring.Add over the common degree, the longer ciphertext's remaining components copied
+        (CopyLvl); ctOut holds max(degree) + 1 components and takes ct0's domain flag"""
+        if ct0.Level() != ct1.Level():
+            raise RingHipError("ciphertexts must be at the same level for addition")
+        hi, lo = max(ct0.Degree(), ct1.Degree()), min(ct0.Degree(), ct1.Degree())
+        if ctOut.Degree() != hi:
+            raise RingHipError("ctOut must have degree %d" % hi)
+        rq = self.ringQ.AtLevel(ct0.Level())
+        for i in range(lo + 1):
+            rq.Add(ct0.Value[i], ct1.Value[i], ctOut.Value[i])
+        longer = ct0 if ct0.Degree() > ct1.Degree() else ct1
+        for i in range(lo + 1, hi + 1):
+            rq.CopyLvl(longer.Value[i], ctOut.Value[i])
+        ctOut.IsNTT = ct0.IsNTT
+
+
 def ckks_tensor_degree1(ringQ, ct0, ct1, c0, c1, c2, c00, c01):
     """schemes/ckks/evaluator.go:821-834 (degree-1 x degree-1 tensoring of mulRelin; all operands in the NTT domain):
     c00 = MForm(ct0[0]); c01 = MForm(ct0[1]); c0 = c00*ct1[0]; c1 = c00*ct1[1] + c01*ct1[0]; c2 = c01*ct1[1]."""

@@ -97,3 +97,37 @@ def test_rescale_with_moduli_of_different_sizes(rh, oracle, round_):
     sub.INTT(chk, chk)
     assert np.array_equal(chk.numpy(), exp)
     ring.close()
+
+
+@pytest.mark.parametrize("kind,N,block_order", [("3n", 3 << 6, 0), ("3n", 3 << 13, 0), ("3n", 3 << 14, 1), ("ci", 1 << 14, 0), ("ci", 256, 0)])
+@pytest.mark.parametrize("nb", [1, 2])
+def test_rescale_on_3n_and_conjugate_invariant_rings(rh, oracle, kind, N, block_order, nb):
+    # schemes/matrix_ckks/evaluator.go:235 rescales on the 3N ring (ring.DivRoundByLastModulusManyNTT through the ring's own transform); the
+    # same for the conjugate-invariant ring.  NTT(input) -> Div...ManyNTT -> INTT == the coefficient-domain division (RNS per coefficient,
+    # the ring type does not enter), which is pinned against the oracle.
+    from test_gpu_schemes import primes_3n
+    L, B = 4, 2
+    if kind == "3n":
+        mods = primes_3n(oracle, N, L)
+        ring = rh.Ring(N, mods, kind=rh.Matrix3N)
+        if block_order:
+            ring.set_tuning("ntt3n_block_order", 1)
+    else:
+        mods = QI60[:L]
+        ring = rh.Ring(N, mods, kind=rh.ConjugateInvariant)
+    rng = np.random.default_rng(N + nb)
+    a = np.stack([np.stack([rng.integers(0, 1 << 62, size=N, dtype=np.uint64) % np.uint64(q) for q in mods]) for _ in range(B)])
+    for round_ in (0, 1):
+        exp = np.stack([oracle.div_by_last_modulus_many(a[k], mods, nb, round_) for k in range(B)])
+        pc = rh.DevicePoly.from_numpy(ring, a)                    # coefficient domain
+        p1 = rh.DevicePoly(ring, B, L - nb)
+        (ring.DivRoundByLastModulusMany if round_ else ring.DivFloorByLastModulusMany)(nb, pc, p1)
+        assert np.array_equal(p1.numpy(), exp)
+        pn = rh.DevicePoly.from_numpy(ring, a)
+        ring.NTT(pn, pn)
+        po = rh.DevicePoly(ring, B, L - nb)
+        (ring.DivRoundByLastModulusManyNTT if round_ else ring.DivFloorByLastModulusManyNTT)(nb, pn, po)
+        sub = ring.AtLevel(L - nb - 1)
+        sub.INTT(po, po)
+        assert np.array_equal(po.numpy(), exp)
+    ring.close()

@@ -206,3 +206,37 @@ def test_intt_mul_equals_the_three_ring_calls(rh, oracle, logN, L, B):
     ring.INTTMul(pa, pb, pa)                                                           # output aliases an input
     assert np.array_equal(pa.numpy(), ref.numpy())
     ring.close()
+
+
+def test_matrix_ckks_rescale_and_add(rh, oracle):
+    # matrix_ckks.Evaluator.Rescale (evaluator.go:208-243: DivRoundByLastModulusManyNTT on the 3N ring, one level) and Add (:60-102,
+    # unequal degrees: the longer ciphertext's components are copied)
+    N, L, B = 3 << 13, 3, 2
+    mods = primes_3n(oracle, N, L)
+    ring = rh.Ring(N, mods, kind=rh.Matrix3N)
+    ev = rh.MatrixCKKSEvaluator(ring)
+    rng = np.random.default_rng(8)
+    mk = lambda: np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    c0, c1, d0 = mk(), mk(), mk()
+    ct = rh.Ciphertext([rh.DevicePoly.from_numpy(ring, c0), rh.DevicePoly.from_numpy(ring, c1)], is_ntt=True)
+    for v in ct.Value:
+        ring.NTT(v, v)
+    out = rh.Ciphertext([rh.DevicePoly(ring, B, L - 1), rh.DevicePoly(ring, B, L - 1)])
+    ev.Rescale(ct, out)
+    assert out.IsNTT and out.Level() == L - 2
+    sub = ring.AtLevel(L - 2)
+    for v, src in zip(out.Value, (c0, c1)):
+        sub.INTT(v, v)
+        exp = np.stack([oracle.div_by_last_modulus_many(src[k], mods, 1, 1) for k in range(B)])
+        assert np.array_equal(v.numpy(), exp)
+    with pytest.raises(rh.RingHipError):                        # level too low (:217-219)
+        ev.Rescale(rh.Ciphertext([ring.AtLevel(0).NewPoly(B)]), rh.Ciphertext([ring.AtLevel(0).NewPoly(B)]))
+    # Add: degree 1 + degree 0
+    x = rh.Ciphertext([rh.DevicePoly.from_numpy(ring, c0), rh.DevicePoly.from_numpy(ring, c1)])
+    y = rh.Ciphertext([rh.DevicePoly.from_numpy(ring, d0)])
+    s = rh.Ciphertext([ring.NewPoly(B), ring.NewPoly(B)])
+    ev.Add(x, y, s)
+    for i, q in enumerate(mods):
+        assert np.array_equal(s.Value[0].numpy()[:, i], (c0[:, i] + d0[:, i]) % np.uint64(q))
+    assert np.array_equal(s.Value[1].numpy(), c1)
+    ring.close()
