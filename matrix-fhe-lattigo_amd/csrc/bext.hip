@@ -371,12 +371,12 @@ int rh_bext_moddown_ntt_add(rh_bext* be, int levelQ, int levelP, const u64* p1Q,
   if (!be) return rh_fail(RH_ERR_ARG, "null basis extender");
   RhBextGuard guard(be);
   if (int rc = check_levels(be, levelQ, levelP, true)) return rc;
-  if (be->Q->kind != RH_RING_STANDARD || be->P->kind != RH_RING_STANDARD) return rh_fail(RH_ERR_UNSUPPORTED, "ModDownQPtoQNTT needs standard rings");
+  if (be->Q->kind != be->P->kind) return rh_fail(RH_ERR_ARG, "ModDownQPtoQNTT: ringQ and ringP differ in ring type");
   const size_t N = be->Q->N;
   if (int rc = ensure_buf(be, 0, (size_t)npoly * (levelQ + 1) * N)) return rc;
   if (int rc = ensure_buf(be, 1, (size_t)npoly * (levelP + 1) * N)) return rc;
   u64* buffQ = be->buf[0]; u64* buffP = be->buf[1];
-  if (int rc = rh_std_ntt_launch(be->P, p1P, buffP, npoly, levelP + 1, 0, true, true, 0)) return rc;          // ringP.INTTLazy
+  if (int rc = rh_ring_ntt_any(be->P, p1P, buffP, npoly, levelP + 1, 0, true)) return rc;          // ringP.INTTLazy (canonical for N >= 16; any ring type)
   BextPlan* p; if (int rc = get_modup_plan(be, 0, 1, levelP, levelQ, &p)) return rc;
   if (int rc = launch_plan(be, *p, buffP, levelP + 1, 0, buffQ, levelQ + 1, nullptr, 0, nullptr, 0, npoly, BEXT_ADD_CRED)) return rc;
   // ringQ.NTTLazy(buffQ, buffQ): the following MRed yields the canonical residue for any representative (< 8q) of the
@@ -386,7 +386,7 @@ int rh_bext_moddown_ntt_add(rh_bext* be, int levelQ, int levelP, const u64* p1Q,
   for (int i = 0; i <= levelQ; ++i) sc[i] = be->Q->moduli[i] - moddown_const(Ps, be->Q->moduli[i]);
   if (rh_can_fuse_submul(be->Q))                 // the subtract-multiply rides in the forward tile kernel's epilogue
     return rh_std_ntt_submul_launch(be->Q, buffQ, npoly, levelQ + 1, 0, p1Q, levelQ + 1, p2Q, levelQ + 1, sc.data(), false, addend, levelQ + 1);
-  if (int rc = rh_std_ntt_launch(be->Q, buffQ, buffQ, npoly, levelQ + 1, 0, false, false, 0)) return rc;
+  if (int rc = rh_ring_ntt_any(be->Q, buffQ, buffQ, npoly, levelQ + 1, 0, false)) return rc;
   if (!addend) return rh_vec_launch(be->Q, RH_OP_SUB_THEN_MUL_SCALAR_MONT_TWO_MODULUS, buffQ, p1Q, p2Q, npoly, levelQ + 1, 0, sc.data(), nullptr);
   // the output may be the addend's own buffer: finish in the scratch, add last
   if (int rc = rh_vec_launch(be->Q, RH_OP_SUB_THEN_MUL_SCALAR_MONT_TWO_MODULUS, buffQ, p1Q, buffQ, npoly, levelQ + 1, 0, sc.data(), nullptr)) return rc;

@@ -157,13 +157,13 @@ static int decompose_single_ntt(rh_bext* be, int levelQ, int levelP, int i, cons
   const int LQ = levelQ + 1, LP = levelP + 1, N = RQ->N;
   if (int rc = rh_bext_decompose_and_split(be, levelQ, levelP, LP, i, cxInv, c2Q, c2P, npoly)) return rc;
   const int st = i * LP; int ed = st + LP; if (ed > LQ) ed = LQ;
-  if (RQ->logN >= 12) {          // the digit's own limbs are overwritten below: transform only the limbs around them
+  if (RQ->kind == RH_RING_STANDARD && RQ->logN >= 12) {          // the digit's own limbs are overwritten below: transform only the limbs around them
     if (int rc = rh_std_ntt_fwd_strided(RQ, c2Q, npoly, st, 0, LQ)) return rc;
     if (int rc = rh_std_ntt_fwd_strided(RQ, c2Q + (size_t)ed * N, npoly, LQ - ed, ed, LQ)) return rc;
-  } else if (int rc = rh_std_ntt_launch(RQ, c2Q, c2Q, npoly, LQ, 0, false, false, 0)) return rc;
+  } else if (int rc = rh_ring_ntt_any(RQ, c2Q, c2Q, npoly, LQ, 0, false)) return rc;
   if (copy_digit && hipMemcpy2DAsync(c2Q + (size_t)st * N, (size_t)LQ * N * 8, cx + (size_t)st * N, (size_t)LQ * N * 8, (size_t)(ed - st) * N * 8, npoly,
                                      hipMemcpyDeviceToDevice, rh_stream(RQ)) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_product: digit copy failed");
-  return rh_std_ntt_launch(RP, c2P, c2P, npoly, LP, 0, false, false, 0);
+  return rh_ring_ntt_any(RP, c2P, c2P, npoly, LP, 0, false);
 }
 
 // DecomposeSingleNTT for every digit: the basis extensions digit by digit, then ONE pipelined transform of all the Q blocks
@@ -192,7 +192,7 @@ static int decompose_all_ntt(rh_bext* be, int levelQ, int levelP, int beta, cons
         return rh_fail(RH_ERR_DEVICE, "gadget_product: digit copy failed");
     }
   if (rh_can_ntt_digits(RP)) return rh_std_ntt_fwd_digits(RP, decP, wp, npoly, beta, LP, 0, lazy);   // no limb skipped
-  return rh_std_ntt_launch(RP, decP, decP, beta * npoly, LP, 0, false, false, 0);
+  return rh_ring_ntt_any(RP, decP, decP, beta * npoly, LP, 0, false);
 }
 
 // the Reduce schedule of gadgetProductMultiplePLazy(Hoisted) (:166-187, :408-428)
@@ -205,7 +205,7 @@ static int ks_check(rh_bext* be, int levelQ, int levelP, int beta_key, const cha
   if (!be) return rh_fail(RH_ERR_ARG, "%s: null basis extender", who);
   rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
   if (!RP) return rh_fail(RH_ERR_ARG, "%s: basis extender has no P ring", who);
-  if (RQ->kind != RH_RING_STANDARD) return rh_fail(RH_ERR_UNSUPPORTED, "%s: standard rings only", who);
+  if (RQ->kind != RP->kind) return rh_fail(RH_ERR_ARG, "%s: ringQ and ringP differ in ring type", who);   // 3N / conjugate-invariant rings: the same steps through the ring's own transform
   if (levelQ < 0 || levelQ >= RQ->L || levelP < 1 || levelP >= RP->L) return rh_fail(RH_ERR_ARG, "%s: need 0 <= levelQ < %d and 1 <= levelP < %d", who, RQ->L, RP->L);
   *beta = (levelQ + levelP + 1) / (levelP + 1);                    // BaseRNSDecompositionVectorSize, params.go:635-642
   if (beta_key >= 0 && *beta > beta_key) return rh_fail(RH_ERR_ARG, "%s: key has %d digits, level needs %d", who, beta_key, *beta);
@@ -226,7 +226,7 @@ extern "C" int rh_bext_decompose_ntt(rh_bext* be, int levelQ, int levelP, const 
   u64* other;
   if (int rc = rh_bext_scratch(be, 2, wq, &other)) return rc;
   // :437-445: the missing domain of c2 goes to BuffInvNTT
-  if (int rc = rh_std_ntt_launch(RQ, c2, other, npoly, LQ, 0, c2_is_ntt != 0, false, 0)) return rc;
+  if (int rc = rh_ring_ntt_any(RQ, c2, other, npoly, LQ, 0, c2_is_ntt != 0)) return rc;
   const u64* polyNTT = c2_is_ntt ? c2 : other;
   const u64* polyInv = c2_is_ntt ? other : c2;
   (void)wp;
@@ -259,9 +259,9 @@ static int hoisted_tail(rh_bext* be, int levelQ, int levelP, const uint64_t* dec
   if (out_ntt) return rh_bext_moddown_ntt_pair(be, levelQ, levelP, ct0, ct1, aP0, out0, out1, npoly, add0, add1);
   // coefficient-domain ciphertext (:114-118, then ModDown INTT -> INTT :62-66): ringQP.INTT on both components, ModDownQPtoQ
   if (add0 || add1) return rh_fail(RH_ERR_UNSUPPORTED, "gadget product: the fused Add exists for NTT-domain ciphertexts only");
-  if (int rc = rh_std_ntt_launch(RQ, ct0, ct0, npoly, LQ, 0, true, false, 0)) return rc;
-  if (int rc = rh_std_ntt_launch(RQ, ct1, ct1, npoly, LQ, 0, true, false, 0)) return rc;
-  if (int rc = rh_std_ntt_launch(RP, aP0, aP0, 2 * npoly, LP, 0, true, false, 0)) return rc;
+  if (int rc = rh_ring_ntt_any(RQ, ct0, ct0, npoly, LQ, 0, true)) return rc;
+  if (int rc = rh_ring_ntt_any(RQ, ct1, ct1, npoly, LQ, 0, true)) return rc;
+  if (int rc = rh_ring_ntt_any(RP, aP0, aP0, 2 * npoly, LP, 0, true)) return rc;
   if (int rc = rh_bext_moddown_qp_to_q(be, levelQ, levelP, ct0, aP0, out0, npoly)) return rc;
   return rh_bext_moddown_qp_to_q(be, levelQ, levelP, ct1, aP1, out1, npoly);
 }
@@ -304,7 +304,7 @@ static int gadget_product_impl(rh_bext* be, int levelQ, int levelP, const uint64
   u64* other;
   if (int rc = rh_bext_scratch(be, 2, wq, &other)) return rc;
   // ctQP.IsNTT: cxNTT = cx, cxInvNTT = INTT(cx) (:134-138); else cxInvNTT = cx, cxNTT = NTT(cx) (:139-143)
-  if (int rc = rh_std_ntt_launch(RQ, cx, other, npoly, LQ, 0, is_ntt, false, 0)) return rc;
+  if (int rc = rh_ring_ntt_any(RQ, cx, other, npoly, LQ, 0, is_ntt)) return rc;
   const u64* cxNTT = is_ntt ? cx : other; const u64* cxInv = is_ntt ? other : cx;
   if (int rc = decompose_all_ntt(be, levelQ, levelP, beta, cxNTT, cxInv, decQ, decP, npoly, false)) return rc;
   if (!is_ntt) return hoisted_tail(be, levelQ, levelP, decQ, decP, evkQ, evkP, beta_key, ct0, ct1, npoly, cxNTT, nullptr, nullptr, nullptr, nullptr, false);
@@ -359,7 +359,7 @@ extern "C" int rh_bext_gadget_product_single_p(rh_bext* be, int levelQ, int leve
   if (!be || !cx || !evkQ || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "gadget_product_single_p: null argument");
   RhBextGuard guard(be);
   rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
-  if (RQ->kind != RH_RING_STANDARD) return rh_fail(RH_ERR_UNSUPPORTED, "gadget_product_single_p: standard rings only");
+  if (RP && RQ->kind != RP->kind) return rh_fail(RH_ERR_ARG, "gadget_product_single_p: ringQ and ringP differ in ring type");
   if (levelQ < 0 || levelQ >= RQ->L) return rh_fail(RH_ERR_ARG, "gadget_product_single_p: levelQ %d out of range [0,%d)", levelQ, RQ->L);
   if (levelP != 0 && levelP != -1) return rh_fail(RH_ERR_ARG, "gadget_product_single_p: levelP must be 0 or -1 (levelP >= 1: rh_bext_gadget_product)");
   if (levelP == 0 && (!RP || !evkP)) return rh_fail(RH_ERR_ARG, "gadget_product_single_p: levelP = 0 needs a P ring and the key's P part");
@@ -381,7 +381,7 @@ extern "C" int rh_bext_gadget_product_single_p(rh_bext* be, int levelQ, int leve
   const u64* cxInv = cx;
   if (cx_is_ntt) {
     if (int rc = rh_bext_scratch(be, 2, wq, &cxInvBuf)) return rc;
-    if (int rc = rh_std_ntt_launch(RQ, cx, cxInvBuf, npoly, LQ, 0, true, false, 0)) return rc;          // ringQ.INTT(cx, cxInvNTT) (:201-203)
+    if (int rc = rh_ring_ntt_any(RQ, cx, cxInvBuf, npoly, LQ, 0, true)) return rc;          // ringQ.INTT(cx, cxInvNTT) (:201-203)
     cxInv = cxInvBuf;
   }
   const int QiOverF = rh_overflow_margin(RQ->moduli, levelQ) >> 1;
@@ -399,8 +399,8 @@ extern "C" int rh_bext_gadget_product_single_p(rh_bext* be, int levelQ, int leve
         if (hipGetLastError() != hipSuccess) return rh_fail(RH_ERR_DEVICE, "mask_broadcast_kernel launch failed");
       }
       if (pw2 || j == 0) {                                             // s.NTTLazy under every modulus (:258-262, :285-289)
-        if (int rc = rh_std_ntt_launch(RQ, c2Q, c2Q, npoly, LQ, 0, false, false, 0)) return rc;
-        if (LP) if (int rc = rh_std_ntt_launch(RP, c2P, c2P, npoly, LP, 0, false, false, 0)) return rc;
+        if (int rc = rh_ring_ntt_any(RQ, c2Q, c2Q, npoly, LQ, 0, false)) return rc;
+        if (LP) if (int rc = rh_ring_ntt_any(RP, c2P, c2P, npoly, LP, 0, false)) return rc;
       }
       if (int rc = rh_gadget_mac(RQ, c2Q, evkQ + ((size_t)e * 2) * evq, evkQ + ((size_t)e * 2 + 1) * evq, ct0, ct1, npoly, LQ, e == 0)) return rc;
       if (LP) if (int rc = rh_gadget_mac(RP, c2P, evkP + ((size_t)e * 2) * evp, evkP + ((size_t)e * 2 + 1) * evp, aP0, aP1, npoly, LP, e == 0)) return rc;
@@ -416,10 +416,10 @@ extern "C" int rh_bext_gadget_product_single_p(rh_bext* be, int levelQ, int leve
     return rh_bext_moddown_ntt_pair(be, levelQ, levelP, ct0, ct1, aP0, ct0, ct1, npoly, nullptr, nullptr);
   }
   // coefficient-domain ciphertext: ringQP.INTT (:114-118), then ModDownQPtoQ / plain copy
-  if (int rc = rh_std_ntt_launch(RQ, ct0, ct0, npoly, LQ, 0, true, false, 0)) return rc;
-  if (int rc = rh_std_ntt_launch(RQ, ct1, ct1, npoly, LQ, 0, true, false, 0)) return rc;
+  if (int rc = rh_ring_ntt_any(RQ, ct0, ct0, npoly, LQ, 0, true)) return rc;
+  if (int rc = rh_ring_ntt_any(RQ, ct1, ct1, npoly, LQ, 0, true)) return rc;
   if (!LP) return RH_OK;
-  if (int rc = rh_std_ntt_launch(RP, aP0, aP0, 2 * npoly, LP, 0, true, false, 0)) return rc;
+  if (int rc = rh_ring_ntt_any(RP, aP0, aP0, 2 * npoly, LP, 0, true)) return rc;
   if (int rc = rh_bext_moddown_qp_to_q(be, levelQ, levelP, ct0, aP0, ct0, npoly)) return rc;
   return rh_bext_moddown_qp_to_q(be, levelQ, levelP, ct1, aP1, ct1, npoly);
 }

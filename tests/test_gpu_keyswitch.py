@@ -140,3 +140,84 @@ def test_gadget_product_single_p_and_bit_decomposition(rh, oracle, N, nq, levelQ
     ev.close(); rq.close()
     if rp is not None:
         rp.close()
+
+
+def _generic_gadget_product(oracle, N, Q, P, levelQ, levelP, cx, evkQ, evkP, fq, iq, fp, ip):
+    """GadgetProduct over a ring of any type: fq / iq (fp / ip) = forward / inverse transform of limb i of the Q (P) chain.  Every
+    intermediate is a canonical residue: sum_d evk_d * c2_d * 2^-64 (what the reference's lazy accumulation and closing Reduce leave),
+    ModDown as NTT(ModDownQPtoQ(INTT ...)) -- the transform is linear, so these are the bits of ModDownQPtoQNTT."""
+    LQ, LP = levelQ + 1, levelP + 1
+    Ql, Pl = Q[:LQ], P[:LP]
+    beta = (levelQ + levelP + 1) // (levelP + 1)
+    cxinv = np.stack([iq(cx[i], i) for i in range(LQ)])
+    accQ = [[np.zeros(N, dtype=object) for _ in range(LQ)] for _ in range(2)]
+    accP = [[np.zeros(N, dtype=object) for _ in range(LP)] for _ in range(2)]
+    for d in range(beta):
+        c2q, c2p = oracle.decompose_and_split(levelQ, levelP, LP, d, cxinv, Q, P)
+        st, ed = d * LP, min(d * LP + LP, LQ)
+        c2q = [cx[i] if st <= i < ed else fq(c2q[i], i) for i in range(LQ)]
+        c2p = [fp(c2p[j], j) for j in range(LP)]
+        for c in (0, 1):
+            for i, q in enumerate(Ql):
+                accQ[c][i] = (accQ[c][i] + evkQ[d, c, i].astype(object) * c2q[i].astype(object)) % q
+            for j, p in enumerate(Pl):
+                accP[c][j] = (accP[c][j] + evkP[d, c, j].astype(object) * c2p[j].astype(object)) % p
+    out = []
+    for c in (0, 1):
+        aq = np.stack([iq(((accQ[c][i] * pow(1 << 64, -1, q)) % q).astype(np.uint64), i) for i, q in enumerate(Ql)])
+        ap = np.stack([ip(((accP[c][j] * pow(1 << 64, -1, p)) % p).astype(np.uint64), j) for j, p in enumerate(Pl)])
+        md = oracle.moddown_qp_to_q(aq, ap, Ql, Pl)
+        out.append(np.stack([fq(md[i], i) for i in range(LQ)]))
+    return out
+
+
+@pytest.mark.parametrize("kind,N", [("ci", 256), ("ci", 4096), ("ci", 16384), ("3n", 3 << 6), ("3n", 3 << 13)])
+def test_gadget_product_on_conjugate_invariant_and_3n_rings(rh, oracle, kind, N):
+    # the key switch is generic over the ring type in the reference (rlwe.Evaluator works on whatever ringQ / ringP it is given): same
+    # steps through the ring's own transform.  Direct product, the hoisted one, and the product with addends.
+    from test_oracle_ntt3n import find_prime_3n, omega_for
+    nq, np_, npoly = 5, 2, 2
+    if kind == "ci":
+        Q, P = QI60[:nq], PI60[:np_]
+        rq, rp = rh.Ring(N, Q, kind=rh.ConjugateInvariant), rh.Ring(N, P, kind=rh.ConjugateInvariant)
+        srQ = [oracle.SubRingConsts(N, q, nthroot=4 * N) for q in Q]; srP = [oracle.SubRingConsts(N, p, nthroot=4 * N) for p in P]
+        fq = lambda x, i: oracle.ntt_ci(x, srQ[i]); iq = lambda x, i: oracle.intt_ci(x, srQ[i])
+        fp = lambda x, j: oracle.ntt_ci(x, srP[j]); ip = lambda x, j: oracle.intt_ci(x, srP[j])
+    else:
+        mods, q = [], find_prime_3n(N, 60)
+        while len(mods) < nq + np_:
+            if oracle.lib().orc_is_prime(q):
+                mods.append(q)
+            q += 3 * N
+        Q, P = mods[:nq], mods[nq:]
+        wQ, wP = [omega_for(q, N) for q in Q], [omega_for(p, N) for p in P]
+        rq, rp = rh.Ring(N, Q, kind=rh.Matrix3N, omega3n=wQ), rh.Ring(N, P, kind=rh.Matrix3N, omega3n=wP)
+        fq = lambda x, i: oracle.ntt3n_forward(x, Q[i], wQ[i]); iq = lambda x, i: oracle.ntt3n_backward(x, Q[i], wQ[i])
+        fp = lambda x, j: oracle.ntt3n_forward(x, P[j], wP[j]); ip = lambda x, j: oracle.ntt3n_backward(x, P[j], wP[j])
+    levelQ, levelP = nq - 1, np_ - 1
+    beta = (levelQ + levelP + 1) // (levelP + 1)
+    rng = np.random.default_rng(N + nq)
+    cx = np.stack([np.stack([uniform_mod(rng, q, N) for q in Q]) for _ in range(npoly)])
+    add = np.stack([np.stack([uniform_mod(rng, q, N) for q in Q]) for _ in range(npoly)])
+    evkQ, evkP = _rand_key(rng, beta, Q, N), _rand_key(rng, beta, P, N)
+    be = rh.BasisExtender(rq, rp)
+    dq = rh.DevicePoly.from_numpy(rq, evkQ.reshape(beta * 2, nq, N)); dp = rh.DevicePoly.from_numpy(rp, evkP.reshape(beta * 2, np_, N))
+    pcx = rh.DevicePoly.from_numpy(rq, cx)
+    ct0, ct1 = rh.DevicePoly(rq, npoly, nq), rh.DevicePoly(rq, npoly, nq)
+    be.GadgetProduct(levelQ, levelP, pcx, dq.ptr, dp.ptr, beta, ct0, ct1)
+    g0, g1 = ct0.numpy(), ct1.numpy()
+    e0, e1 = _generic_gadget_product(oracle, N, Q, P, levelQ, levelP, cx[1], evkQ, evkP, fq, iq, fp, ip)
+    assert np.array_equal(g0[1], e0) and np.array_equal(g1[1], e1)
+    a0, a1 = rh.DevicePoly.from_numpy(rq, add), rh.DevicePoly.from_numpy(rq, add)
+    be.GadgetProductThenAdd(levelQ, levelP, pcx, dq.ptr, dp.ptr, beta, a0, a1, a0, a1)
+    for i, q in enumerate(Q):
+        assert np.array_equal(a0.numpy()[1, i], (e0[i] + add[1, i]) % np.uint64(q))
+        assert np.array_equal(a1.numpy()[1, i], (e1[i] + add[1, i]) % np.uint64(q))
+    # hoisted == direct
+    ev = rh.rlwe.Evaluator(rq, rp)
+    gct = rh.rlwe.GadgetCiphertext(rq, rp, evkQ, evkP)
+    dec = ev.DecomposeNTT(levelQ, levelP, pcx, True)
+    h = rh.Ciphertext([rq.NewPoly(npoly), rq.NewPoly(npoly)], is_ntt=True)
+    ev.GadgetProductHoisted(levelQ, dec, gct, h)
+    assert np.array_equal(h.Value[0].numpy(), g0) and np.array_equal(h.Value[1].numpy(), g1)
+    ev.close(); be.close(); rq.close(); rp.close()
