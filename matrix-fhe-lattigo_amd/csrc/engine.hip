@@ -830,10 +830,14 @@ static int std_intt_mul_launch(rh_ring* r, const u64* a, const u64* b, u64* out,
 }
 extern "C" int rh_ring_intt_mul(rh_ring* r, const uint64_t* a, const uint64_t* b, uint64_t* out, int npoly, int level) {
   if (!r || !a || !b || !out) return rh_fail(RH_ERR_ARG, "intt_mul: null argument");
-  if (r->kind != RH_RING_STANDARD) return rh_fail(RH_ERR_UNSUPPORTED, "intt_mul: standard rings only");
   if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "intt_mul: level %d out of range [0,%d)", level, r->L);
   if (npoly < 0) return rh_fail(RH_ERR_ARG, "intt_mul: npoly < 0");
   (void)hipSetDevice(r->device);
+  if (r->kind != RH_RING_STANDARD) {                 // 3N / conjugate-invariant rings: the three calls as they are, through the ring's own transform
+    if (int rc = rh_vec_launch(r, RH_OP_MFORM, a, nullptr, out, npoly, level + 1, 0, nullptr, nullptr)) return rc;
+    if (int rc = rh_vec_launch(r, RH_OP_MUL_MONT, out, b, out, npoly, level + 1, 0, nullptr, nullptr)) return rc;
+    return rh_ring_ntt_any(r, out, out, npoly, level + 1, 0, true);
+  }
   return std_intt_mul_launch(r, a, b, out, npoly, level + 1);
 }
 

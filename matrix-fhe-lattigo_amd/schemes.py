@@ -127,12 +127,12 @@ def ckks_polymul(ringQ, a, b, c, tmp=None, fused=True):
     (schemes/ckks/evaluator.go:821-834).  a and b are transformed in place (they end in the NTT domain).
     fused (default): MForm, MulCoeffsMontgomery and the inverse transform as ONE call (Ring.INTTMul: the product is formed on
     load by the inverse transform's first kernel) -- same canonical values; fused=False: the five ring calls as written."""
-    if fused and ringQ.kind == 0:
+    if fused:
         ringQ.NTTMany([(a, a), (b, b)])
     else:
         ringQ.NTT(a, a)
         ringQ.NTT(b, b)
-    if fused and ringQ.kind == 0:
+    if fused:
         ringQ.INTTMul(a, b, c)
         return
     ringQ.MForm(a, tmp)

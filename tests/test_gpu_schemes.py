@@ -240,3 +240,29 @@ def test_matrix_ckks_rescale_and_add(rh, oracle):
         assert np.array_equal(s.Value[0].numpy()[:, i], (c0[:, i] + d0[:, i]) % np.uint64(q))
     assert np.array_equal(s.Value[1].numpy(), c1)
     ring.close()
+
+
+@pytest.mark.parametrize("kind", ["ci", "3n"])
+def test_intt_mul_and_polymul_on_other_ring_types(rh, oracle, kind):
+    # Ring.INTTMul / ckks_polymul on the conjugate-invariant and the 3N ring: the three ring calls through the ring's own transform
+    B, L = 2, 2
+    if kind == "ci":
+        N, mods = 4096, QI60[:L]
+        ring = rh.Ring(N, mods, kind=rh.ConjugateInvariant)
+    else:
+        N = 3 << 10
+        mods = primes_3n(oracle, N, L)
+        ring = rh.Ring(N, mods, kind=rh.Matrix3N)
+    rng = np.random.default_rng(3)
+    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    b = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    pa, pb = rh.DevicePoly.from_numpy(ring, a), rh.DevicePoly.from_numpy(ring, b)
+    ring.NTT(pa, pa); ring.NTT(pb, pb)
+    t, ref, got = ring.NewPoly(B), ring.NewPoly(B), ring.NewPoly(B)
+    ring.MForm(pa, t); ring.MulCoeffsMontgomery(t, pb, ref); ring.INTT(ref, ref)
+    ring.INTTMul(pa, pb, got)
+    assert np.array_equal(got.numpy(), ref.numpy())
+    qa, qb, c = rh.DevicePoly.from_numpy(ring, a), rh.DevicePoly.from_numpy(ring, b), ring.NewPoly(B)
+    rh.schemes.ckks_polymul(ring, qa, qb, c)
+    assert np.array_equal(c.numpy(), ref.numpy())
+    ring.close()
