@@ -430,8 +430,58 @@ class Ring:
     def MFormLazy(self, p1, p2): self.vec_op("MFORM_LAZY", p1, None, p2)
     def IMForm(self, p1, p2): self.vec_op("IMFORM", p1, None, p2)
     def MulRNSScalarMontgomery(self, p1, scalar, p2): self.vec_op("MUL_SCALAR_MONT", p1, None, p2, s0=scalar)
-    def AddScalar(self, p1, scalar, p2): self.vec_op("ADD_SCALAR", p1, None, p2, s0=scalar)
-    def SubScalar(self, p1, scalar, p2): self.vec_op("SUB_SCALAR", p1, None, p2, s0=scalar)
+    def AddScalar(self, p1, scalar, p2): self.vec_op("ADD_SCALAR", p1, None, p2, s0=self._per_limb(scalar))
+    def SubScalar(self, p1, scalar, p2): self.vec_op("SUB_SCALAR", p1, None, p2, s0=self._per_limb(scalar))
+
+    # ---- scalar forms of ring/operations.go: the per-limb constant is formed on the host exactly as the reference forms it ----
+    def _per_limb(self, scalar):
+        """a uint64 scalar handed to every limb as it is (AddScalar / SubScalar :151-155, :186-190), or an RNSScalar (one word per limb)"""
+        if np.ndim(scalar) == 0:
+            return [int(scalar)] * (self.level + 1)
+        return scalar
+
+    def _qs(self):
+        return [int(q) for q in self.moduli[:self.level + 1]]
+
+    def _mform_scalars(self, values):
+        """MForm(v_i, q_i) = v_i * 2^64 mod q_i for the limbs of this view (ring/modular_reduction.go:11-24)"""
+        return [(int(v) << 64) % q for v, q in zip(values, self._qs())]
+
+    def AddScalarBigint(self, p1, scalar, p2):
+        """:158-163"""
+        self.vec_op("ADD_SCALAR", p1, None, p2, s0=[int(scalar) % q for q in self._qs()])
+
+    def SubScalarBigint(self, p1, scalar, p2):
+        """:193-198"""
+        self.vec_op("SUB_SCALAR", p1, None, p2, s0=[int(scalar) % q for q in self._qs()])
+
+    def MulScalar(self, p1, scalar, p2):
+        """:201-205: MulScalarMontgomery by MForm(scalar)"""
+        self.vec_op("MUL_SCALAR_MONT", p1, None, p2, s0=self._mform_scalars([int(scalar)] * (self.level + 1)))
+
+    def MulScalarThenAdd(self, p1, scalar, p2):
+        """:208-212: p2 += p1 * scalar"""
+        self.vec_op("MUL_SCALAR_MONT_THEN_ADD", p1, None, p2, s0=self._mform_scalars([int(scalar)] * (self.level + 1)))
+
+    def MulScalarThenSub(self, p1, scalar, p2):
+        """:223-228: p2 -= p1 * scalar, as p2 += p1 * MForm(q - BRedAdd(scalar))"""
+        qs = self._qs()
+        self.vec_op("MUL_SCALAR_MONT_THEN_ADD", p1, None, p2, s0=self._mform_scalars([q - int(scalar) % q for q in qs]))
+
+    def MulScalarBigint(self, p1, scalar, p2):
+        """:231-237"""
+        self.vec_op("MUL_SCALAR_MONT", p1, None, p2, s0=self._mform_scalars([int(scalar) % q for q in self._qs()]))
+
+    def MulScalarBigintThenAdd(self, p1, scalar, p2):
+        """:240-247"""
+        self.vec_op("MUL_SCALAR_MONT_THEN_ADD", p1, None, p2, s0=self._mform_scalars([int(scalar) % q for q in self._qs()]))
+
+    def EvalPolyScalar(self, p1, scalar, p2):
+        """:269-275: p2 = p1[0] + p1[1] * scalar + ... by Horner (p1: list of blocks)"""
+        self.CopyLvl(p1[-1], p2)
+        for i in range(len(p1) - 1, 0, -1):
+            self.MulScalar(p2, scalar, p2)
+            self.Add(p2, p1[i - 1], p2)
 
 
 class BasisExtender:

@@ -65,3 +65,39 @@ def test_lazy_inputs_full_range(rh, oracle):
         for i, q in enumerate(mods):
             assert np.array_equal(got[0, i], oracle.vec_op(rh.OPS[name], x[0, i], y[0, i], z[0, i], 0, 0, q)), name
     ring.close()
+
+
+def test_scalar_forms_of_ring_operations(rh):
+    # ring/operations.go:151-275: AddScalar(Bigint), SubScalar(Bigint), MulScalar(ThenAdd / ThenSub), MulScalarBigint(ThenAdd), EvalPolyScalar
+    # against plain integer arithmetic
+    N, mods = 256, QI60[:3]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(12)
+    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(2)])
+    b = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(2)])
+    big = (1 << 200) + 12345678901234567890
+    sm = 0xFFFFFFFFFFFFFFF1                                       # a uint64 scalar above every modulus
+    A = [[int(x) for x in a[1, i]] for i in range(3)]
+    B = [[int(x) for x in b[1, i]] for i in range(3)]
+
+    def run(fn, *args, acc=None):
+        pa = rh.DevicePoly.from_numpy(ring, a)
+        po = rh.DevicePoly.from_numpy(ring, b if acc is None else acc)
+        fn(pa, *args, po)
+        return [[int(x) for x in po.numpy()[1, i]] for i in range(3)]
+    for i, q in enumerate(mods):
+        q = int(q)
+        assert run(ring.AddScalar, 77)[i] == [(x + 77) % q for x in A[i]]
+        assert run(ring.SubScalar, 77)[i] == [(x - 77) % q for x in A[i]]
+        assert run(ring.AddScalarBigint, big)[i] == [(x + big) % q for x in A[i]]
+        assert run(ring.SubScalarBigint, big)[i] == [(x - big) % q for x in A[i]]
+        assert run(ring.MulScalar, sm)[i] == [(x * sm) % q for x in A[i]]
+        assert run(ring.MulScalarBigint, big)[i] == [(x * big) % q for x in A[i]]
+        assert run(ring.MulScalarThenAdd, sm)[i] == [(y + x * sm) % q for x, y in zip(A[i], B[i])]
+        assert run(ring.MulScalarThenSub, sm)[i] == [(y - x * sm) % q for x, y in zip(A[i], B[i])]
+        assert run(ring.MulScalarBigintThenAdd, big)[i] == [(y + x * big) % q for x, y in zip(A[i], B[i])]
+    pa, pb, po = rh.DevicePoly.from_numpy(ring, a), rh.DevicePoly.from_numpy(ring, b), ring.NewPoly(2)
+    ring.EvalPolyScalar([pa, pb, pa], 5, po)                    # a + 5 b + 25 a
+    for i, q in enumerate(mods):
+        assert [int(x) for x in po.numpy()[1, i]] == [(26 * x + 5 * y) % int(q) for x, y in zip(A[i], B[i])]
+    ring.close()
