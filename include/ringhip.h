@@ -170,6 +170,19 @@ int rh_ring_vec_op(rh_ring* r, int opcode, const uint64_t* p1_dev, const uint64_
 int rh_ring_vec_op_rows(rh_ring* r, int opcode, const uint64_t* p1_dev, int rows1, const uint64_t* p2_dev, int rows2, uint64_t* p3_dev,
                         int rows3, int npoly, int level, const uint64_t* s0_host, const uint64_t* s1_host);
 
+/* p2 = ONE row of N words on the device used for every (poly, limb): Ring.MulByVectorMontgomery / ...ThenAddLazy (ring/operations.go:366-377)
+ * with RH_OP_MUL_MONT / RH_OP_MUL_MONT_THEN_ADD_LAZY (any opcode with a second operand) */
+int rh_ring_vec_op_bcast(rh_ring* r, int opcode, const uint64_t* p1_dev, int rows1, const uint64_t* vector_dev, uint64_t* p3_dev, int rows3,
+                         int npoly, int level);
+/* a one-operand scalar opcode with one RNS scalar for coefficients [0, N/2) and another for [N/2, N): Ring.AddDoubleRNSScalar,
+ * SubDoubleRNSScalar, MulDoubleRNSScalar(ThenAdd) (ring/operations.go:167-184, 250-266); scalars as the opcode takes them */
+int rh_ring_vec_op_halves(rh_ring* r, int opcode, const uint64_t* p1_dev, uint64_t* p3_dev, int npoly, int level,
+                          const uint64_t* s_lo_host, const uint64_t* s_hi_host);
+/* Ring.Shift (:278-282): p2[j] = p1[(j + k) mod N]; Ring.MultByMonomial (:306-363): p2 = p1 * X^k with the reference's representatives
+ * (q - 0 is written as q).  Every limb 0..level of dense blocks; out of place. */
+int rh_ring_shift(rh_ring* r, int level, const uint64_t* in_dev, uint64_t* out_dev, int k, int npoly);
+int rh_ring_mult_by_monomial(rh_ring* r, int level, const uint64_t* in_dev, uint64_t* out_dev, int k, int npoly);
+
 /* ---- RNS rescale (ring/scaling.go): divide by the last modulus, `nb` times.  round = 0: floored, 1: rounded.
  * p0: npoly polys of level+1 limbs; p1: npoly polys of p1_rows >= level+1-nb limbs (limbs 0..level-nb are written).
  *   rh_ring_div_by_last_modulus_many      coefficient domain: DivFloorByLastModulus(:21-28) / DivRoundByLastModulus

@@ -97,3 +97,61 @@ extern "C" int rh_ring_automorphism(rh_ring* r, int level, const uint64_t* in, u
   else automorphism_coeff_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(in, out, r->logN, gen, r->d_consts, level + 1);
   return done("automorphism_coeff_kernel");
 }
+
+// ---- ring.Shift and ring.MultByMonomial (ring/operations.go:278-282, 306-363): index maps over every limb of a block, out of place ----
+__global__ void __launch_bounds__(256)
+shift_kernel(const u64* in, u64* out, unsigned N, unsigned k) {              // p2[j] = p1[(j + k) mod N] (utils.RotateSliceAllocFree: left rotation)
+  const size_t base = (size_t)blockIdx.y * N;
+  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+    unsigned src = j + k; if (src >= N) src -= N;
+    out[base + j] = in[base + src];
+  }
+}
+__global__ void __launch_bounds__(256)
+monomial_kernel(const u64* in, u64* out, unsigned N, unsigned shift2n, const LimbConsts* __restrict__ consts, int L) {
+  // shift2n = (k + 2N) mod 2N, not 0.  tmp = shift2n < N ? p1 : q - p1 (q - 0 = q, as the reference writes it); s = shift2n mod N;
+  // p2[j] = q - tmp[N - s + j] for j < s, tmp[j - s] otherwise (:324-361)
+  const u64 q = consts[blockIdx.y % (unsigned)L].q;
+  const size_t base = (size_t)blockIdx.y * N;
+  const bool neg = shift2n >= N;
+  const unsigned s = shift2n >= N ? shift2n - N : shift2n;
+  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+    const unsigned src = j < s ? N - s + j : j - s;
+    u64 v = in[base + src];
+    if (neg) v = q - v;
+    out[base + j] = j < s ? q - v : v;
+  }
+}
+static int index_map_common(rh_ring* r, int level, const void* in, const void* out, int npoly, const char* who) {
+  if (!r || !in || !out) return rh_fail(RH_ERR_ARG, "%s: null argument", who);
+  if (in == out) return rh_fail(RH_ERR_ARG, "%s: the device form is out of place", who);
+  if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "%s: level %d out of range [0,%d)", who, level, r->L);
+  if (npoly < 0) return rh_fail(RH_ERR_ARG, "%s: npoly < 0", who);
+  (void)hipSetDevice(r->device);
+  (void)hipGetLastError();
+  return 0;
+}
+extern "C" int rh_ring_shift(rh_ring* r, int level, const uint64_t* in, uint64_t* out, int k, int npoly) {
+  if (int rc = index_map_common(r, level, in, out, npoly, "shift")) return rc;
+  const unsigned rows = (unsigned)npoly * (unsigned)(level + 1);
+  if (!rows) return RH_OK;
+  const int N = r->N;
+  int kk = k % N; if (kk < 0) kk += N;
+  unsigned chunks = ((unsigned)N + 1023) / 1024; if (chunks > 64) chunks = 64;
+  shift_kernel<<<dim3(chunks, rows), 256, 0, rh_stream(r)>>>(in, out, (unsigned)N, (unsigned)kk);
+  return done("shift_kernel");
+}
+extern "C" int rh_ring_mult_by_monomial(rh_ring* r, int level, const uint64_t* in, uint64_t* out, int k, int npoly) {
+  if (int rc = index_map_common(r, level, in, out, npoly, "mult_by_monomial")) return rc;
+  const unsigned rows = (unsigned)npoly * (unsigned)(level + 1);
+  if (!rows) return RH_OK;
+  const long N = r->N;
+  long sh = ((long)k % (2 * N) + 2 * N) % (2 * N);                         // (k + 2N) % 2N for any int k
+  if (sh == 0) {
+    if (hipMemcpyAsync(out, in, (size_t)rows * N * 8, hipMemcpyDeviceToDevice, rh_stream(r)) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "mult_by_monomial: copy failed");
+    return RH_OK;
+  }
+  unsigned chunks = ((unsigned)N + 1023) / 1024; if (chunks > 64) chunks = 64;
+  monomial_kernel<<<dim3(chunks, rows), 256, 0, rh_stream(r)>>>(in, out, (unsigned)N, (unsigned)sh, r->d_consts, level + 1);
+  return done("monomial_kernel");
+}

@@ -936,7 +936,8 @@ extern "C" int rh_ntt_backward_lazy(rh_ring* r, int limb, const uint64_t* p1, ui
 // ------------------------------------------------------------------------------------------------ element-wise
 struct ScalarPack { u64 s[RH_MAX_LIMBS]; };
 
-struct RowStrides { int r1, r2, r3; };                // limbs per poly of the three operand blocks (>= L: ring.AtLevel views)
+struct RowStrides { int r1, r2, r3; unsigned pair0, pair1; };   // limbs per poly of the three operand blocks (>= L: ring.AtLevel views; r2 < 0: p2 is ONE
+                                                                 // row used for every (poly, limb)); the range of coefficient pairs processed
 template <int OP>
 __global__ void __launch_bounds__(256)
 vec_op_packed(const u64* p1, const u64* p2, u64* p3, unsigned n, ScalarPack s0, ScalarPack s1,
@@ -945,9 +946,8 @@ vec_op_packed(const u64* p1, const u64* p2, u64* p3, unsigned n, ScalarPack s0, 
   const u32 limb = row % (u32)L, poly = row / (u32)L;
   const LimbConsts c = consts[limb];
   const u64 a0 = s0.s[limb], a1 = s1.s[limb];
-  const size_t o1 = ((size_t)poly * rs.r1 + limb) * n, o2 = ((size_t)poly * rs.r2 + limb) * n, o3 = ((size_t)poly * rs.r3 + limb) * n;
-  const unsigned npairs = n >> 1;
-  for (unsigned i = blockIdx.y * blockDim.x + threadIdx.x; i < npairs; i += gridDim.y * blockDim.x) {
+  const size_t o1 = ((size_t)poly * rs.r1 + limb) * n, o2 = rs.r2 < 0 ? 0 : ((size_t)poly * rs.r2 + limb) * n, o3 = ((size_t)poly * rs.r3 + limb) * n;
+  for (unsigned i = rs.pair0 + blockIdx.y * blockDim.x + threadIdx.x; i < rs.pair1; i += gridDim.y * blockDim.x) {
     const size_t e = 2 * (size_t)i;
     ulonglong2 x = make_ulonglong2(0, 0), y = x, z = x;
     if (op_reads_x(OP)) x = *reinterpret_cast<const ulonglong2*>(p1 + o1 + e);
@@ -968,7 +968,7 @@ static const vec_fn* vec_table(std::integer_sequence<int, I...>) {
 }
 
 int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3, int npoly, int Lrows, int limb0,
-                  const u64* s0, const u64* s1, int rows1, int rows2, int rows3) {   // rows_k: limbs per poly of operand k (0: Lrows)
+                  const u64* s0, const u64* s1, int rows1, int rows2, int rows3, int half) {   // rows_k: limbs per poly of operand k (0: Lrows; rows2 < 0: one broadcast row); half: 0 all coefficients, 1 / 2 the first / second N/2
   static const vec_fn* table = vec_table(std::make_integer_sequence<int, RH_OP_COUNT>());
   (void)hipGetLastError();
   ScalarPack a, b;
@@ -981,9 +981,33 @@ int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3,
   unsigned chunks = (n / 2 + 256 * 4 - 1) / (256 * 4);
   if (chunks < 1) chunks = 1;
   if (chunks > 64) chunks = 64;
-  const RowStrides rs{rows1 ? rows1 : Lrows, rows2 ? rows2 : Lrows, rows3 ? rows3 : Lrows};
+  const unsigned npairs = n >> 1;
+  const RowStrides rs{rows1 ? rows1 : Lrows, rows2 ? rows2 : Lrows, rows3 ? rows3 : Lrows, half == 2 ? npairs / 2 : 0u, half == 1 ? npairs / 2 : npairs};
   hipLaunchKernelGGL(table[opcode], dim3(rows, chunks), dim3(256), 0, rh_stream(r), p1, p2, p3, n, a, b, r->d_consts + limb0, Lrows, rs);
   return check_launch("vec_op");
+}
+
+// p2 = ONE row of N words used for every (poly, limb): MulByVectorMontgomery(ThenAddLazy) (ring/operations.go:366-377) with the
+// MUL_MONT / MUL_MONT_THEN_ADD_LAZY opcodes (any two-operand opcode works)
+extern "C" int rh_ring_vec_op_bcast(rh_ring* r, int opcode, const uint64_t* p1, int rows1, const uint64_t* vector, uint64_t* p3, int rows3,
+                                    int npoly, int level) {
+  if (!r || !p1 || !vector || !p3) return rh_fail(RH_ERR_ARG, "vec_op_bcast: null argument");
+  if (opcode < 0 || opcode >= RH_OP_COUNT || !op_reads_y(opcode)) return rh_fail(RH_ERR_ARG, "vec_op_bcast: opcode %d has no second operand", opcode);
+  if (level < 0 || level >= r->L || rows1 < level + 1 || rows3 < level + 1 || npoly < 0) return rh_fail(RH_ERR_ARG, "vec_op_bcast: bad level / rows / npoly");
+  (void)hipSetDevice(r->device);
+  return rh_vec_launch(r, opcode, p1, vector, p3, npoly, level + 1, 0, nullptr, nullptr, rows1, -1, rows3);
+}
+// one-operand scalar opcodes with one RNS scalar for coefficients [0, N/2) and another for [N/2, N): Add / Sub / MulDoubleRNSScalar(ThenAdd)
+// (ring/operations.go:167-184, 250-266); s_lo / s_hi: level+1 words each on the host, in the form the opcode takes them
+extern "C" int rh_ring_vec_op_halves(rh_ring* r, int opcode, const uint64_t* p1, uint64_t* p3, int npoly, int level, const uint64_t* s_lo,
+                                     const uint64_t* s_hi) {
+  if (!r || !p1 || !p3 || !s_lo || !s_hi) return rh_fail(RH_ERR_ARG, "vec_op_halves: null argument");
+  if (opcode < 0 || opcode >= RH_OP_COUNT || op_reads_y(opcode)) return rh_fail(RH_ERR_ARG, "vec_op_halves: opcode %d is not a one-operand scalar opcode", opcode);
+  if (level < 0 || level >= r->L || npoly < 0) return rh_fail(RH_ERR_ARG, "vec_op_halves: bad level / npoly");
+  if (r->N % 4) return rh_fail(RH_ERR_ARG, "vec_op_halves: N must be a multiple of 4");
+  (void)hipSetDevice(r->device);
+  if (int rc = rh_vec_launch(r, opcode, p1, nullptr, p3, npoly, level + 1, 0, s_lo, nullptr, 0, 0, 0, 1)) return rc;
+  return rh_vec_launch(r, opcode, p1, nullptr, p3, npoly, level + 1, 0, s_hi, nullptr, 0, 0, 0, 2);
 }
 
 // Degree-1 x degree-1 tensoring of ckks mulRelin (schemes/ckks/evaluator.go:821-834) in one pass: the six ring calls

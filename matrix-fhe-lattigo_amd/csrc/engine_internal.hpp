@@ -87,7 +87,7 @@ int rh_std_ntt_submul_launch(rh_ring* r, u64* buf, int npoly, int Lrows, int lim
                              const u64* scalars_host, bool cols_done = false, const u64* z = nullptr, int z_rows = 0);
 int rh_std_ntt_expand_cols_launch(rh_ring* r, const u64* tmp, u64* buf, int npoly, int Lrows, const void* table_dev, int mode, u64 qL);
 int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3, int npoly, int Lrows, int limb0,
-                  const u64* s0, const u64* s1, int rows1 = 0, int rows2 = 0, int rows3 = 0);
+                  const u64* s0, const u64* s1, int rows1 = 0, int rows2 = 0, int rows3 = 0, int half = 0);
 int rh_std_intt_rows(rh_ring* r, const u64* in, int in_rows, u64* out, int out_rows, int npoly, int Lrows);
 int rh_std_upload_tables(rh_ring* r, const std::vector<tw2>& fs, const std::vector<tw2>& is, const std::vector<u64>* mont,
                          const std::vector<tw2>& lastw);

@@ -84,6 +84,8 @@ def lib():
         "rh_dev_alloc": (i, [vp, sz, C.POINTER(vp)]), "rh_dev_free": (i, [vp, vp]),
         "rh_dev_upload": (i, [vp, vp, U64P, sz]), "rh_dev_download": (i, [vp, U64P, vp, sz]),
         "rh_ring_copy_rows": (i, [vp, vp, i, vp, i, i, i]),
+        "rh_ring_vec_op_bcast": (i, [vp, i, vp, i, vp, vp, i, i, i]), "rh_ring_vec_op_halves": (i, [vp, i, vp, vp, i, i, U64P, U64P]),
+        "rh_ring_shift": (i, [vp, i, vp, vp, i, i]), "rh_ring_mult_by_monomial": (i, [vp, i, vp, vp, i, i]),
         "rh_ntt_forward": (i, [vp, i, U64P, U64P]), "rh_ntt_forward_lazy": (i, [vp, i, U64P, U64P]),
         "rh_ntt_backward": (i, [vp, i, U64P, U64P]), "rh_ntt_backward_lazy": (i, [vp, i, U64P, U64P]),
         "rh_ring_ntt": (i, [vp, vp, vp, i, i, i]), "rh_ring_intt": (i, [vp, vp, vp, i, i, i]),
@@ -475,6 +477,53 @@ class Ring:
     def MulScalarBigintThenAdd(self, p1, scalar, p2):
         """:240-247"""
         self.vec_op("MUL_SCALAR_MONT_THEN_ADD", p1, None, p2, s0=self._mform_scalars([int(scalar) % q for q in self._qs()]))
+
+    def _halves(self, op, p1, s_lo, s_hi, p2):
+        self._chk(p1, p2)
+        a, b = _u64(s_lo), _u64(s_hi)
+        _check(lib().rh_ring_vec_op_halves(self._h, OPS[op], p1.ptr, p2.ptr, p1.npoly, self.level, _p(a), _p(b)))
+
+    def AddDoubleRNSScalar(self, p1, scalar0, scalar1, p2):
+        """:167-173: scalar0 on coefficients [0, N/2), scalar1 on [N/2, N)"""
+        self._halves("ADD_SCALAR", p1, scalar0, scalar1, p2)
+
+    def SubDoubleRNSScalar(self, p1, scalar0, scalar1, p2):
+        """:177-183"""
+        self._halves("SUB_SCALAR", p1, scalar0, scalar1, p2)
+
+    def MulDoubleRNSScalar(self, p1, scalar0, scalar1, p2):
+        """:250-256: MulScalarMontgomery by MForm(scalar_k[i])"""
+        self._halves("MUL_SCALAR_MONT", p1, self._mform_scalars(scalar0), self._mform_scalars(scalar1), p2)
+
+    def MulDoubleRNSScalarThenAdd(self, p1, scalar0, scalar1, p2):
+        """:260-266"""
+        self._halves("MUL_SCALAR_MONT_THEN_ADD", p1, self._mform_scalars(scalar0), self._mform_scalars(scalar1), p2)
+
+    def MulByVectorMontgomery(self, p1, vector, p2):
+        """:366-370: every limb of every poly times the same N-word vector (a 1-poly, 1-limb DevicePoly)"""
+        self._chk(p1, p2, rows_ok=True)
+        _check(lib().rh_ring_vec_op_bcast(self._h, OPS["MUL_MONT"], p1.ptr, p1.limbs, vector.ptr, p2.ptr, p2.limbs, p1.npoly, self.level))
+
+    def MulByVectorMontgomeryThenAddLazy(self, p1, vector, p2):
+        """:373-377"""
+        self._chk(p1, p2, rows_ok=True)
+        _check(lib().rh_ring_vec_op_bcast(self._h, OPS["MUL_MONT_THEN_ADD_LAZY"], p1.ptr, p1.limbs, vector.ptr, p2.ptr, p2.limbs, p1.npoly, self.level))
+
+    def Shift(self, p1, k, p2):
+        """:278-282: p2[j] = p1[(j + k) mod N] on every limb; in place through a temporary"""
+        self._chk(p1, p2)
+        src = p1
+        if p1.ptr == p2.ptr:
+            src = self.NewPoly(p1.npoly); self.CopyLvl(p1, src)
+        _check(lib().rh_ring_shift(self._h, self.level, src.ptr, p2.ptr, int(k), p1.npoly))
+
+    def MultByMonomial(self, p1, k, p2):
+        """:306-363: p2 = p1 * X^k (X^N = -1), the reference's representatives (q - 0 is written as q); in place through a temporary"""
+        self._chk(p1, p2)
+        src = p1
+        if p1.ptr == p2.ptr:
+            src = self.NewPoly(p1.npoly); self.CopyLvl(p1, src)
+        _check(lib().rh_ring_mult_by_monomial(self._h, self.level, src.ptr, p2.ptr, int(k), p1.npoly))
 
     def EvalPolyScalar(self, p1, scalar, p2):
         """:269-275: p2 = p1[0] + p1[1] * scalar + ... by Horner (p1: list of blocks)"""

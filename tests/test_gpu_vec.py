@@ -101,3 +101,65 @@ def test_scalar_forms_of_ring_operations(rh):
     for i, q in enumerate(mods):
         assert [int(x) for x in po.numpy()[1, i]] == [(26 * x + 5 * y) % int(q) for x, y in zip(A[i], B[i])]
     ring.close()
+
+
+def test_double_rns_scalars_vector_shift_and_monomial(rh):
+    # ring/operations.go:167-184, 250-266 (one RNS scalar per half of the coefficients), :366-377 (one vector for every limb), :278-282
+    # (Shift, with the reference's known answer ring/ring_test.go:904-916), :306-363 (MultByMonomial)
+    N, mods = 64, QI60[:2]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(21)
+    a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(2)])
+    b = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(2)])
+    s0, s1 = [11, 1 << 40], [(1 << 61) - 5, 3]
+    A = lambda k, i: [int(x) for x in a[k, i]]
+    pa, pb, po = rh.DevicePoly.from_numpy(ring, a), rh.DevicePoly.from_numpy(ring, b), ring.NewPoly(2)
+    for name, f in (("Add", lambda x, s, q: (x + s) % q), ("Sub", lambda x, s, q: (x - s) % q), ("Mul", lambda x, s, q: (x * s) % q)):
+        getattr(ring, name + "DoubleRNSScalar")(pa, s0, s1, po)
+        g = po.numpy()
+        for i, q in enumerate(mods):
+            q = int(q)
+            exp = [f(x, s0[i] % q, q) for x in A(1, i)[:N // 2]] + [f(x, s1[i] % q, q) for x in A(1, i)[N // 2:]]
+            assert [int(x) for x in g[1, i]] == exp, name
+    acc = rh.DevicePoly.from_numpy(ring, b)
+    ring.MulDoubleRNSScalarThenAdd(pa, s0, s1, acc)
+    for i, q in enumerate(mods):
+        q = int(q)
+        exp = [(y + x * (s0[i] if j < N // 2 else s1[i])) % q for j, (x, y) in enumerate(zip(A(0, i), [int(v) for v in b[0, i]]))]
+        assert [int(x) for x in acc.numpy()[0, i]] == exp
+    # one vector for every limb: MulCoeffsMontgomery(p1[i], vector) = x * v * 2^-64
+    vec = np.array([[rng.integers(0, 1 << 60, size=N, dtype=np.uint64)]])
+    pv = rh.DevicePoly.from_numpy(ring.AtLevel(0), vec)
+    ring.MulByVectorMontgomery(pa, pv, po)
+    for i, q in enumerate(mods):
+        q = int(q); rinv = pow(1 << 64, -1, q)
+        assert [int(x) for x in po.numpy()[1, i]] == [(x * int(v) * rinv) % q for x, v in zip(A(1, i), vec[0, 0])]
+    acc = rh.DevicePoly.from_numpy(ring, b)
+    ring.MulByVectorMontgomeryThenAddLazy(pa, pv, acc)
+    for i, q in enumerate(mods):
+        q = int(q); rinv = pow(1 << 64, -1, q)
+        assert [int(x) % q for x in acc.numpy()[1, i]] == [(int(y) + x * int(v) * rinv) % q for x, v, y in zip(A(1, i), vec[0, 0], b[1, i])]
+    # Shift: the reference's known answer (N = 16, q = 97, k = 3)
+    r16 = rh.Ring(16, [97])
+    p1 = rh.DevicePoly.from_numpy(r16, np.arange(16, dtype=np.uint64).reshape(1, 1, 16)); p2 = r16.NewPoly(1)
+    r16.Shift(p1, 3, p2)
+    assert [int(x) for x in p2.numpy()[0, 0]] == [3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2]
+    r16.Shift(p2, -3, p2)                                         # in place, back
+    assert [int(x) for x in p2.numpy()[0, 0]] == list(range(16))
+    r16.close()
+    # MultByMonomial: the reference's loops restated, and X^1 then X^8 == X^9 (ring/ring_test.go:880-899)
+    def monomial(x, k, q):
+        sh = (k + 2 * N) % (2 * N)
+        if sh == 0:
+            return list(x)
+        t = list(x) if sh < N else [q - v for v in x]
+        sh %= N
+        return [q - t[N - sh + j] for j in range(sh)] + [t[j - sh] for j in range(sh, N)]
+    for k in (1, 9, N, N + 5, -7, 2 * N):
+        ring.MultByMonomial(pa, k, po)
+        for i, q in enumerate(mods):
+            assert [int(x) for x in po.numpy()[1, i]] == monomial(A(1, i), k, int(q)), k
+    t1 = ring.NewPoly(2)
+    ring.MultByMonomial(pa, 1, t1); ring.MultByMonomial(t1, 8, t1); ring.MultByMonomial(pa, 9, po)
+    assert np.array_equal(t1.numpy(), po.numpy())
+    ring.close()
