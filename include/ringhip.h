@@ -182,6 +182,10 @@ int rh_ring_vec_op_halves(rh_ring* r, int opcode, const uint64_t* p1_dev, uint64
  * (q - 0 is written as q).  Every limb 0..level of dense blocks; out of place. */
 int rh_ring_shift(rh_ring* r, int level, const uint64_t* in_dev, uint64_t* out_dev, int k, int npoly);
 int rh_ring_mult_by_monomial(rh_ring* r, int level, const uint64_t* in_dev, uint64_t* out_dev, int k, int npoly);
+/* Ring.AutomorphismNTTWithIndex / AutomorphismNTTWithIndexThenAddLazy (ring/automorphism.go:50-117): out[j] (=|+=) in[index[j]] on every limb
+ * 0..level; index_dev: the caller's lookup table of N words ON THE DEVICE (e.g. AutomorphismNTTIndex, :12-34); out of place */
+int rh_ring_automorphism_ntt_index(rh_ring* r, int level, const uint64_t* in_dev, const uint64_t* index_dev, uint64_t* out_dev, int npoly,
+                                   int add_lazy);
 
 /* ---- RNS rescale (ring/scaling.go): divide by the last modulus, `nb` times.  round = 0: floored, 1: rounded.
  * p0: npoly polys of level+1 limbs; p1: npoly polys of p1_rows >= level+1-nb limbs (limbs 0..level-nb are written).

@@ -155,3 +155,23 @@ extern "C" int rh_ring_mult_by_monomial(rh_ring* r, int level, const uint64_t* i
   monomial_kernel<<<dim3(chunks, rows), 256, 0, rh_stream(r)>>>(in, out, (unsigned)N, (unsigned)sh, r->d_consts, level + 1);
   return done("monomial_kernel");
 }
+
+// ---- AutomorphismNTTWithIndex / ...ThenAddLazy (:50-117): the caller's lookup table (N words on the device), any permutation
+__global__ void __launch_bounds__(256)
+automorphism_index_kernel(const u64* in, u64* out, const u64* __restrict__ index, unsigned N, int add_lazy) {
+  const size_t base = (size_t)blockIdx.y * N;
+  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+    const u64 v = in[base + index[j]];
+    out[base + j] = add_lazy ? out[base + j] + v : v;
+  }
+}
+extern "C" int rh_ring_automorphism_ntt_index(rh_ring* r, int level, const uint64_t* in, const uint64_t* index, uint64_t* out, int npoly,
+                                              int add_lazy) {
+  if (!index) return rh_fail(RH_ERR_ARG, "automorphism (with index): null index table");
+  if (int rc = index_map_common(r, level, in, out, npoly, "automorphism (with index)")) return rc;
+  const unsigned rows = (unsigned)npoly * (unsigned)(level + 1);
+  if (!rows) return RH_OK;
+  unsigned chunks = ((unsigned)r->N + 1023) / 1024; if (chunks > 64) chunks = 64;
+  automorphism_index_kernel<<<dim3(chunks, rows), 256, 0, rh_stream(r)>>>(in, out, index, (unsigned)r->N, add_lazy);
+  return done("automorphism_index_kernel");
+}

@@ -85,7 +85,7 @@ def lib():
         "rh_dev_upload": (i, [vp, vp, U64P, sz]), "rh_dev_download": (i, [vp, U64P, vp, sz]),
         "rh_ring_copy_rows": (i, [vp, vp, i, vp, i, i, i]),
         "rh_ring_vec_op_bcast": (i, [vp, i, vp, i, vp, vp, i, i, i]), "rh_ring_vec_op_halves": (i, [vp, i, vp, vp, i, i, U64P, U64P]),
-        "rh_ring_shift": (i, [vp, i, vp, vp, i, i]), "rh_ring_mult_by_monomial": (i, [vp, i, vp, vp, i, i]),
+        "rh_ring_shift": (i, [vp, i, vp, vp, i, i]), "rh_ring_automorphism_ntt_index": (i, [vp, i, vp, vp, vp, i, i]), "rh_ring_mult_by_monomial": (i, [vp, i, vp, vp, i, i]),
         "rh_ntt_forward": (i, [vp, i, U64P, U64P]), "rh_ntt_forward_lazy": (i, [vp, i, U64P, U64P]),
         "rh_ntt_backward": (i, [vp, i, U64P, U64P]), "rh_ntt_backward_lazy": (i, [vp, i, U64P, U64P]),
         "rh_ring_ntt": (i, [vp, vp, vp, i, i, i]), "rh_ring_intt": (i, [vp, vp, vp, i, i, i]),
@@ -371,6 +371,25 @@ class Ring:
         self._chk(polIn, polOut)
         _check(lib().rh_ring_automorphism_ntt(self._h, self.level, polIn.ptr, int(gen), polOut.ptr, polIn.npoly, 1))
 
+    def _index_table(self, index):
+        """the lookup table as a device block: a DevicePoly of N words, or a host array uploaded for the call"""
+        if isinstance(index, DevicePoly):
+            return index
+        arr = _u64(index).reshape(1, 1, self.N)
+        return DevicePoly.from_numpy(self.AtLevel(0), arr)
+
+    def AutomorphismNTTWithIndex(self, polIn, index, polOut):
+        """ring/automorphism.go:50-78: polOut[j] = polIn[index[j]] on every limb (index: AutomorphismNTTIndex or any permutation)"""
+        self._chk(polIn, polOut)
+        t = self._index_table(index)
+        _check(lib().rh_ring_automorphism_ntt_index(self._h, self.level, polIn.ptr, t.ptr, polOut.ptr, polIn.npoly, 0))
+
+    def AutomorphismNTTWithIndexThenAddLazy(self, polIn, index, polOut):
+        """:82-117: polOut[j] += polIn[index[j]] (no reduction)"""
+        self._chk(polIn, polOut)
+        t = self._index_table(index)
+        _check(lib().rh_ring_automorphism_ntt_index(self._h, self.level, polIn.ptr, t.ptr, polOut.ptr, polIn.npoly, 1))
+
     def Automorphism(self, polIn, gen, polOut):
         self._chk(polIn, polOut)
         _check(lib().rh_ring_automorphism(self._h, self.level, polIn.ptr, int(gen), polOut.ptr, polIn.npoly))
@@ -533,6 +552,21 @@ class Ring:
             self.Add(p2, p1[i - 1], p2)
 
 
+def AutomorphismNTTIndex(N, NthRoot, GalEl):
+    """ring/automorphism.go:12-34: the lookup table of the NTT-domain automorphism X -> X^GalEl"""
+    if N & (N - 1) or NthRoot & (NthRoot - 1):
+        raise RingHipError("N and NthRoot must be powers of two")
+    lg = (int(NthRoot) - 1).bit_length() - 1
+    mask = int(NthRoot) - 1
+    rev = lambda x: int(format(x, "0%db" % lg)[::-1], 2) if lg else 0
+    out = np.empty(N, dtype=np.uint64)
+    for i in range(N):
+        t1 = 2 * rev(i) + 1
+        t2 = (((int(GalEl) * t1) & mask) - 1) >> 1
+        out[i] = rev(t2)
+    return out
+
+
 class BasisExtender:
     """ring.BasisExtender (ring/basis_extension.go:13-79) over a (ringQ, ringP) pair on the same device."""
 
@@ -566,6 +600,10 @@ class BasisExtender:
     def GadgetProduct(self, levelQ, levelP, cx, evkQ_ptr, evkP_ptr, beta_key, ct0, ct1):
         """rlwe.Evaluator.GadgetProduct for NTT-domain cx; evk*_ptr: device pointers of the key blocks (see ringhip.h)"""
         _check(lib().rh_bext_gadget_product(self._h, levelQ, levelP, cx.ptr, evkQ_ptr, evkP_ptr, beta_key, ct0.ptr, ct1.ptr, cx.npoly))
+
+    def ShallowCopy(self):
+        """basis_extension.go:166-183: an extender over the same rings with its own scratch (the handle itself is safe to share)"""
+        return BasisExtender(self.ringQ, self.ringP)
 
     def GadgetProductThenAdd(self, levelQ, levelP, cx, evkQ_ptr, evkP_ptr, beta_key, add0, add1, ct0, ct1):
         """ct_c = add_c + GadgetProduct(cx)_c (rh_bext_gadget_product_then_add); add_c may be None and may alias ct_c"""

@@ -105,3 +105,27 @@ def test_gpu_ci_automorphisms_vs_oracle(rh, oracle, logN, gen):
     with pytest.raises(rh.RingHipError):
         ring.AutomorphismNTT(p, 4 * N - 1, o)                    # gen = 3 mod 4: the reference's table look-up runs out of range
     ring.close()
+
+
+@pytest.mark.gpu
+def test_automorphism_with_index_table(rh, oracle):
+    # AutomorphismNTTIndex (ring/automorphism.go:12-34) + AutomorphismNTTWithIndex / ...ThenAddLazy (:50-117) == AutomorphismNTT by generator
+    N, mods = 256, QI60[:2]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(5)
+    a = np.stack([np.stack([rng.integers(0, 1 << 62, size=N, dtype=np.uint64) % np.uint64(q) for q in mods]) for _ in range(2)])
+    pa, o1, o2 = rh.DevicePoly.from_numpy(ring, a), ring.NewPoly(2), ring.NewPoly(2)
+    for gal in (5, 25, 2 * N - 1):
+        idx = rh.AutomorphismNTTIndex(N, 2 * N, gal)
+        ring.AutomorphismNTT(pa, gal, o1)
+        ring.AutomorphismNTTWithIndex(pa, idx, o2)
+        assert np.array_equal(o1.numpy(), o2.numpy())
+        assert np.array_equal(o2.numpy()[1, 1], a[1, 1][idx.astype(np.int64)])
+        assert np.array_equal(o2.numpy()[1, 0], oracle.automorphism_ntt(a[1, 0], gal))
+        acc = rh.DevicePoly.from_numpy(ring, a)
+        ring.AutomorphismNTTWithIndexThenAddLazy(pa, idx, acc)
+        assert np.array_equal(acc.numpy(), a + o1.numpy())
+    be = rh.BasisExtender(ring, rh.Ring(N, QI60[2:4]))
+    be2 = be.ShallowCopy()
+    assert be2._h != be._h
+    be2.close(); be.close(); ring.close()
