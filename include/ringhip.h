@@ -275,6 +275,16 @@ int rh_bext_gadget_product_hoisted(rh_bext* be, int levelQ, int levelP, const ui
                                    const uint64_t* evkQ_dev, const uint64_t* evkP_dev, int beta_key, uint64_t* ct0_dev,
                                    uint64_t* ct1_dev, int npoly);
 
+/* Evaluator.GadgetProductHoistedLazy (core/rlwe/evaluator_gadget_product.go:351-429): the product WITHOUT the ModDown -- accumulators
+ * modulo Q (ctQ0 / ctQ1, levelQ+1 limbs) and modulo P (ctP0 / ctP1, levelP+1 limbs), canonical, NTT domain, still scaled by P: what
+ * AutomorphismHoistedLazy and the linear transformations accumulate before ONE ModDown.
+ * rh_bext_moddown_qp_to_q_ntt_pair: Evaluator.ModDown (:33-46) NTT -> NTT on both components (ct_c may alias ctQ_c). */
+int rh_bext_gadget_product_hoisted_lazy(rh_bext* be, int levelQ, int levelP, const uint64_t* decompQ_dev, const uint64_t* decompP_dev,
+                                        const uint64_t* evkQ_dev, const uint64_t* evkP_dev, int beta_key, uint64_t* ctQ0_dev,
+                                        uint64_t* ctQ1_dev, uint64_t* ctP0_dev, uint64_t* ctP1_dev, int npoly);
+int rh_bext_moddown_qp_to_q_ntt_pair(rh_bext* be, int levelQ, int levelP, const uint64_t* ctQ0_dev, const uint64_t* ctQ1_dev,
+                                     const uint64_t* ctP0_dev, const uint64_t* ctP1_dev, uint64_t* ct0_dev, uint64_t* ct1_dev, int npoly);
+
 /* the same with the ring.Add of AutomorphismHoisted (core/rlwe/evaluator_automorphism.go:88-89): ct_c = add_c + product_c */
 int rh_bext_gadget_product_hoisted_then_add(rh_bext* be, int levelQ, int levelP, const uint64_t* decompQ_dev, const uint64_t* decompP_dev,
                                             const uint64_t* evkQ_dev, const uint64_t* evkP_dev, int beta_key, const uint64_t* add0_dev,

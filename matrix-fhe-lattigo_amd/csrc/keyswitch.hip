@@ -265,6 +265,35 @@ static int hoisted_tail(rh_bext* be, int levelQ, int levelP, const uint64_t* dec
   if (int rc = rh_bext_moddown_qp_to_q(be, levelQ, levelP, ct0, aP0, out0, npoly)) return rc;
   return rh_bext_moddown_qp_to_q(be, levelQ, levelP, ct1, aP1, out1, npoly);
 }
+// GadgetProductHoistedLazy (:351-371) = gadgetProductMultiplePLazyHoisted (:373-429) without the ModDown: the accumulators modulo Q and
+// modulo P, canonical after the closing Reduce, P parts as separate blocks ([npoly][levelP+1][N]).  "Lazy" = still scaled by P.
+extern "C" int rh_bext_gadget_product_hoisted_lazy(rh_bext* be, int levelQ, int levelP, const uint64_t* decompQ, const uint64_t* decompP,
+                                                   const uint64_t* evkQ, const uint64_t* evkP, int beta_key, uint64_t* ctQ0, uint64_t* ctQ1,
+                                                   uint64_t* ctP0, uint64_t* ctP1, int npoly) {
+  if (!be || !decompQ || !decompP || !evkQ || !evkP || !ctQ0 || !ctQ1 || !ctP0 || !ctP1) return rh_fail(RH_ERR_ARG, "gadget_product_hoisted_lazy: null argument");
+  RhBextGuard guard(be);
+  int beta; if (int rc = ks_check(be, levelQ, levelP, beta_key, "gadget_product_hoisted_lazy", &beta)) return rc;
+  if (npoly <= 0) return RH_OK;
+  rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
+  const int LQ = levelQ + 1, LP = levelP + 1, N = RQ->N;
+  const size_t wq = (size_t)npoly * LQ * N, wp = (size_t)npoly * LP * N;
+  ReduceSchedule rs(RQ, levelQ, RP, levelP);
+  if (int rc = mac_all(RQ, decompQ, wq, evkQ, beta, rs.QiOverF, ctQ0, ctQ1, npoly, LQ)) return rc;
+  return mac_all(RP, decompP, wp, evkP, beta, rs.PiOverF, ctP0, ctP1, npoly, LP);
+}
+// Evaluator.ModDown (:33-98) for both components of a QP element, NTT -> NTT: ct_c = ModDownQPtoQNTT(ctQ_c, ctP_c); outputs may alias ctQ_c
+extern "C" int rh_bext_moddown_qp_to_q_ntt_pair(rh_bext* be, int levelQ, int levelP, const uint64_t* ctQ0, const uint64_t* ctQ1,
+                                                const uint64_t* ctP0, const uint64_t* ctP1, uint64_t* ct0, uint64_t* ct1, int npoly) {
+  if (!be || !ctQ0 || !ctQ1 || !ctP0 || !ctP1 || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "moddown pair: null argument");
+  if (npoly <= 0) return RH_OK;
+  rh_ring* RP = rh_bext_ringP(be);
+  if (!RP) return rh_fail(RH_ERR_ARG, "moddown pair: basis extender has no P ring");
+  if (levelP < 0 || levelP >= RP->L) return rh_fail(RH_ERR_ARG, "moddown pair: levelP out of range");
+  const size_t wp = (size_t)npoly * (levelP + 1) * RP->N;
+  if (ctP1 == ctP0 + wp) return rh_bext_moddown_ntt_pair(be, levelQ, levelP, ctQ0, ctQ1, ctP0, ct0, ct1, npoly, nullptr, nullptr);   // back to back: one batch
+  if (int rc = rh_bext_moddown_ntt_add(be, levelQ, levelP, ctQ0, ctP0, ct0, npoly, nullptr)) return rc;
+  return rh_bext_moddown_ntt_add(be, levelQ, levelP, ctQ1, ctP1, ct1, npoly, nullptr);
+}
 extern "C" int rh_bext_gadget_product_hoisted(rh_bext* be, int levelQ, int levelP, const uint64_t* decompQ, const uint64_t* decompP,
                                               const uint64_t* evkQ, const uint64_t* evkP, int beta_key, uint64_t* ct0, uint64_t* ct1, int npoly) {
   return hoisted_tail(be, levelQ, levelP, decompQ, decompP, evkQ, evkP, beta_key, ct0, ct1, npoly, nullptr);

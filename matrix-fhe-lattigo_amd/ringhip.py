@@ -114,6 +114,8 @@ def lib():
         "rh_bext_gadget_product_single_p": (i, [vp, i, i, vp, i, i, C.POINTER(i), vp, vp, i, vp, vp, i]),
         "rh_bext_decompose_ntt": (i, [vp, i, i, vp, i, vp, vp, i]),
         "rh_bext_gadget_product_hoisted": (i, [vp, i, i, vp, vp, vp, vp, i, vp, vp, i]),
+        "rh_bext_gadget_product_hoisted_lazy": (i, [vp, i, i, vp, vp, vp, vp, i, vp, vp, vp, vp, i]),
+        "rh_bext_moddown_qp_to_q_ntt_pair": (i, [vp, i, i, vp, vp, vp, vp, vp, vp, i]),
         "rh_bext_gadget_product_hoisted_then_add": (i, [vp, i, i, vp, vp, vp, vp, i, vp, vp, vp, vp, i]),
         "rh_kshard_create": (i, [C.POINTER(vp), vp, vp, U64P, i, U64P, i, C.POINTER(i), i, C.POINTER(i), i]),
         "rh_kshard_destroy": (None, [vp]), "rh_kshard_num_digits": (i, [vp]),

@@ -49,6 +49,32 @@ class GadgetCiphertext:
         return self.levelP
 
 
+class PolyQP:
+    """ringqp.Poly: the Q part and the P part of one polynomial of the extended ring (ring/ringqp/poly.go)"""
+
+    def __init__(self, Q, P):
+        self.Q, self.P = Q, P
+
+
+class ElementQP:
+    """Element[ringqp.Poly] as the lazy key-switch routines use it: Value[0..1] of PolyQP batches and the NTT flag"""
+
+    def __init__(self, value, is_ntt=True):
+        self.Value = list(value)
+        self.IsNTT = bool(is_ntt)
+
+    @classmethod
+    def alloc(cls, ringQ, ringP, npoly, levelQ, levelP):
+        mk = lambda: PolyQP(DevicePoly(ringQ.AtLevel(levelQ), npoly, levelQ + 1), DevicePoly(ringP.AtLevel(levelP), npoly, levelP + 1))
+        return cls([mk(), mk()], True)
+
+    def LevelP(self):
+        return self.Value[0].P.limbs - 1
+
+    def LevelQ(self):
+        return self.Value[0].Q.limbs - 1
+
+
 class Evaluator:
     """rlwe.Evaluator restricted to the key-switch path; `galois_keys` maps a Galois element to its GadgetCiphertext."""
 
@@ -135,6 +161,37 @@ class Evaluator:
         _check(lib().rh_bext_gadget_product_hoisted(self.be._h, levelQ, gadgetCt.LevelP(), dq.ptr, dp.ptr, gadgetCt.Q.ptr,
                                                     gadgetCt.P.ptr, gadgetCt.digits, ct.Value[0].ptr, ct.Value[1].ptr, npoly))
 
+    def GadgetProductHoistedLazy(self, levelQ, decompQP, gadgetCt, ctQP):
+        """(:351-371): the hoisted product WITHOUT the ModDown -- ctQP receives the accumulators modulo Q and modulo P (canonical, NTT
+        domain, still scaled by P).  For sums of rotations that share one ModDown (AutomorphismHoistedLazy, linear transformations)."""
+        dq, dp = decompQP
+        q0, q1, p0, p1 = ctQP.Value[0].Q, ctQP.Value[1].Q, ctQP.Value[0].P, ctQP.Value[1].P
+        levelP = gadgetCt.LevelP()
+        if ctQP.LevelP() < levelP:
+            raise RingHipError("ctQP.LevelP()=%d < gadgetCt.LevelP()=%d" % (ctQP.LevelP(), levelP))
+        self._rows(levelQ, dq, q0, q1)
+        _check(lib().rh_bext_gadget_product_hoisted_lazy(self.be._h, levelQ, levelP, dq.ptr, dp.ptr, gadgetCt.Q.ptr, gadgetCt.P.ptr,
+                                                         gadgetCt.digits, q0.ptr, q1.ptr, p0.ptr, p1.ptr, q0.npoly))
+        ctQP.IsNTT = True
+
+    def ModDown(self, levelQ, levelP, ctQP, ct):
+        """(:33-98), NTT -> NTT and coefficient -> coefficient: ct_c = ModDownQPtoQ(NTT)(ctQP_c.Q, ctQP_c.P)"""
+        if ctQP.IsNTT != ct.IsNTT:
+            raise RingHipError("ModDown: the mixed-domain forms are not built on the device path")
+        if ctQP.IsNTT:
+            self._rows(levelQ, ct.Value[0], ct.Value[1], ctQP.Value[0].Q, ctQP.Value[1].Q)
+            _check(lib().rh_bext_moddown_qp_to_q_ntt_pair(self.be._h, levelQ, levelP, ctQP.Value[0].Q.ptr, ctQP.Value[1].Q.ptr,
+                                                          ctQP.Value[0].P.ptr, ctQP.Value[1].P.ptr, ct.Value[0].ptr, ct.Value[1].ptr,
+                                                          ct.Value[0].npoly))
+        else:
+            for c in (0, 1):
+                self.be.ModDownQPtoQ(levelQ, levelP, ctQP.Value[c].Q, ctQP.Value[c].P, ct.Value[c])
+
+    def ALlocateDecompositionBuffer(self, levelQ, levelP, npoly):
+        """(:480-494), spelled as in the reference: the (decompQ, decompP) pair DecomposeNTT fills"""
+        beta = self.BaseRNSDecompositionVectorSize(levelQ, levelP)
+        return (DevicePoly(self.ringQ.AtLevel(levelQ), beta * npoly, levelQ + 1), DevicePoly(self.ringP.AtLevel(levelP), beta * npoly, levelP + 1))
+
     # ---- core/rlwe/evaluator_evaluationkey.go ---------------------------------------------------------------
     def ApplyEvaluationKey(self, ctIn, evk, opOut):
         """(:37-123), same ring degree on both sides (:97-99 -> applyEvaluationKey :105-112):
@@ -211,3 +268,28 @@ class Evaluator:
         ringQ.AutomorphismNTT(tmp.Value[0], galEl, opOut.Value[0])
         ringQ.AutomorphismNTT(tmp.Value[1], galEl, opOut.Value[1])
         opOut.IsNTT = ctIn.IsNTT
+
+    def AutomorphismHoistedLazy(self, levelQ, ctIn, c1DecompQP, galEl, ctQP):
+        """(:103-160), NTT-domain ctQP: the rotated ciphertext modulo QP and scaled by P --
+        ctQP[1] = phi(KS_1), ctQP[0] = phi(KS_0 + P * ctIn[0]) on the Q part, phi(KS_0) on the P part (P * ctIn[0] vanishes modulo P)"""
+        evk = self._galois_key(galEl)
+        levelP = evk.LevelP()
+        if ctQP.LevelP() < levelP:
+            raise RingHipError("ctQP.LevelP()=%d < GaloisKey[%d].LevelP()=%d" % (ctQP.LevelP(), galEl, levelP))
+        if not ctIn.IsNTT:
+            raise RingHipError("AutomorphismHoistedLazy: coefficient-domain ciphertexts are not supported by the device path")
+        ringQ, ringP = self.ringQ.AtLevel(levelQ), self.ringP.AtLevel(levelP)
+        npoly = ctIn.Value[0].npoly
+        tmp = ElementQP([PolyQP(self.buffer("lazyQ0", ringQ, npoly, levelQ + 1), self.buffer("lazyP0", ringP, npoly, levelP + 1)),
+                         PolyQP(self.buffer("lazyQ1", ringQ, npoly, levelQ + 1), self.buffer("lazyP1", ringP, npoly, levelP + 1))])
+        self.GadgetProductHoistedLazy(levelQ, c1DecompQP, evk, tmp)
+        ringQ.AutomorphismNTT(tmp.Value[1].Q, galEl, ctQP.Value[1].Q)                     # ringQP.AutomorphismNTTWithIndex (:135)
+        ringP.AutomorphismNTT(tmp.Value[1].P, galEl, ctQP.Value[1].P)
+        P = 1
+        for p in self.ringP.moduli[:levelP + 1]:
+            P *= int(p)
+        ringQ.MulScalarBigint(ctIn.Value[0], P, tmp.Value[1].Q)                           # ctIn[0] * P (:138)
+        ringQ.Add(tmp.Value[0].Q, tmp.Value[1].Q, tmp.Value[0].Q)                         # (:141)
+        ringQ.AutomorphismNTT(tmp.Value[0].Q, galEl, ctQP.Value[0].Q)                     # (:143)
+        ringP.AutomorphismNTT(tmp.Value[0].P, galEl, ctQP.Value[0].P)
+        ctQP.IsNTT = True

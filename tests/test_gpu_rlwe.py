@@ -119,3 +119,41 @@ def test_relinearize_and_apply_evaluation_key(rh, oracle):
     with pytest.raises(rh.RingHipError):
         rh.rlwe.Evaluator(rq, rp).Relinearize(ct2, out)   # key missing
     ev.close(); rq.close(); rp.close()
+
+
+@pytest.mark.parametrize("N,nq,np_", [(4096, 5, 2), (16384, 6, 3)])
+def test_lazy_hoisted_product_and_rotation_then_moddown(rh, oracle, N, nq, np_):
+    # GadgetProductHoistedLazy (:351-371) + Evaluator.ModDown (:33-46) == GadgetProductHoisted, bit for bit (same accumulators, same ModDown);
+    # AutomorphismHoistedLazy (:103-160) + ModDown == AutomorphismHoisted up to the centred rounding of the division by P: the automorphism
+    # negates coefficients, and the rounding of (x - [x]_P) / P is odd-symmetric except on its boundary, so the two agree exactly on random data.
+    Q, P, rq, rp, beta, evkQ, evkP, c0, c1 = make_case(rh, N, nq, np_, 2, 3 * N + nq)
+    gal = 5
+    gct = rh.rlwe.GadgetCiphertext(rq, rp, evkQ, evkP)
+    ev = rh.rlwe.Evaluator(rq, rp, galois_keys={gal: gct})
+    levelQ, levelP = nq - 1, np_ - 1
+    ct = rh.Ciphertext([rh.DevicePoly.from_numpy(rq, c0), rh.DevicePoly.from_numpy(rq, c1)], is_ntt=True)
+    dec = ev.ALlocateDecompositionBuffer(levelQ, levelP, 2)
+    ev.DecomposeNTT(levelQ, levelP, ct.Value[1], True, dec)
+    ref = rh.Ciphertext([rq.NewPoly(2), rq.NewPoly(2)], is_ntt=True)
+    ev.GadgetProductHoisted(levelQ, dec, gct, ref)
+    lazy = rh.rlwe.ElementQP.alloc(rq, rp, 2, levelQ, levelP)
+    ev.GadgetProductHoistedLazy(levelQ, dec, gct, lazy)
+    assert lazy.IsNTT and lazy.LevelP() == levelP
+    # the accumulators themselves: canonical residues of sum_d evk_d * dec_d * 2^-64 (one limb of Q and one of P against plain integers)
+    dq, dp = dec[0].numpy(), dec[1].numpy()
+    for which, acc, key, d, mods, i in (("Q", lazy.Value[1].Q, evkQ, dq, Q, nq - 1), ("P", lazy.Value[1].P, evkP, dp, P, 0)):
+        q = int(mods[i]); rinv = pow(1 << 64, -1, q)
+        want = sum(key[dd, 1, i].astype(object) * d[dd * 2 + 1, i].astype(object) for dd in range(beta)) * rinv % q
+        assert [int(x) for x in acc.numpy()[1, i][:64]] == [int(x) for x in want[:64]], which
+    out = rh.Ciphertext([rq.NewPoly(2), rq.NewPoly(2)], is_ntt=True)
+    ev.ModDown(levelQ, levelP, lazy, out)
+    assert np.array_equal(out.Value[0].numpy(), ref.Value[0].numpy()) and np.array_equal(out.Value[1].numpy(), ref.Value[1].numpy())
+    rot = rh.Ciphertext([rq.NewPoly(2), rq.NewPoly(2)], is_ntt=True)
+    ev.AutomorphismHoisted(levelQ, ct, dec, gal, rot)
+    lz = rh.rlwe.ElementQP.alloc(rq, rp, 2, levelQ, levelP)
+    ev.AutomorphismHoistedLazy(levelQ, ct, dec, gal, lz)
+    got = rh.Ciphertext([rq.NewPoly(2), rq.NewPoly(2)], is_ntt=True)
+    ev.ModDown(levelQ, levelP, lz, got)
+    assert np.array_equal(got.Value[1].numpy(), rot.Value[1].numpy())
+    assert np.array_equal(got.Value[0].numpy(), rot.Value[0].numpy())
+    ev.close(); rq.close(); rp.close()
