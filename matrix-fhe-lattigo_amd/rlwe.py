@@ -174,6 +174,32 @@ class Evaluator:
                                                          gadgetCt.digits, q0.ptr, q1.ptr, p0.ptr, p1.ptr, q0.npoly))
         ctQP.IsNTT = True
 
+    def GadgetProductLazy(self, levelQ, cx, gadgetCt, ctQP, cxIsNTT=True):
+        """(:100-120) for gadget ciphertexts with more than one P modulus: the product without the ModDown.  The accumulators are the
+        canonical residues the hoisted form leaves (gadgetProductMultiplePLazy and ...Hoisted differ in WHEN the digits are formed, not
+        in what is summed), so this is DecomposeNTT into the evaluator's buffer + GadgetProductHoistedLazy."""
+        levelP = gadgetCt.LevelP()
+        dec = (self.buffer("lazydecQ", self.ringQ.AtLevel(levelQ), self.BaseRNSDecompositionVectorSize(levelQ, levelP) * cx.npoly, levelQ + 1),
+               self.buffer("lazydecP", self.ringP.AtLevel(levelP), self.BaseRNSDecompositionVectorSize(levelQ, levelP) * cx.npoly, levelP + 1))
+        self.DecomposeNTT(levelQ, levelP, cx, cxIsNTT, dec)
+        self.GadgetProductHoistedLazy(levelQ, dec, gadgetCt, ctQP)
+
+    def DecomposeSingleNTT(self, levelQ, levelP, nbPi, decompRNS, c2NTT, c2InvNTT, c2QiQ, c2QiP):
+        """(:455-478): digit `decompRNS` of the decomposition -- DecomposeAndSplit of the coefficient-domain c2InvNTT, the digit's own limbs
+        copied from the NTT-domain c2NTT, the others transformed (the reference's NTTLazy there; canonical here, same residues)"""
+        rq, rp = self.ringQ.AtLevel(levelQ), self.ringP.AtLevel(levelP)
+        self.be.DecomposeAndSplit(levelQ, levelP, nbPi, decompRNS, c2InvNTT, c2QiQ, c2QiP)
+        rq.NTT(c2QiQ, c2QiQ)
+        rp.NTT(c2QiP, c2QiP)
+        st = decompRNS * nbPi
+        ed = min(st + nbPi, levelQ + 1)
+        N = rq.N
+        for k in range(c2NTT.npoly):                   # limbs [st, ed) of every poly from the NTT-domain input (:467-468)
+            off = (k * (levelQ + 1) + st) * N * 8
+            src = DevicePoly(rq.AtLevel(ed - st - 1), 1, ed - st, ptr=c2NTT.ptr + off, owner=c2NTT)
+            dst = DevicePoly(rq.AtLevel(ed - st - 1), 1, ed - st, ptr=c2QiQ.ptr + off, owner=c2QiQ)
+            rq.AtLevel(ed - st - 1).CopyLvl(src, dst)
+
     def ModDown(self, levelQ, levelP, ctQP, ct):
         """(:33-98), NTT -> NTT and coefficient -> coefficient: ct_c = ModDownQPtoQ(NTT)(ctQP_c.Q, ctQP_c.P)"""
         if ctQP.IsNTT != ct.IsNTT:

@@ -157,3 +157,26 @@ def test_lazy_hoisted_product_and_rotation_then_moddown(rh, oracle, N, nq, np_):
     assert np.array_equal(got.Value[1].numpy(), rot.Value[1].numpy())
     assert np.array_equal(got.Value[0].numpy(), rot.Value[0].numpy())
     ev.close(); rq.close(); rp.close()
+
+
+def test_gadget_product_lazy_and_decompose_single(rh, oracle):
+    # GadgetProductLazy (:100-120) == GadgetProductHoistedLazy on DecomposeNTT's output; DecomposeSingleNTT (:455-478) == that digit of DecomposeNTT
+    N, nq, np_ = 4096, 6, 2
+    Q, P, rq, rp, beta, evkQ, evkP, c0, c1 = make_case(rh, N, nq, np_, 2, 77)
+    gct = rh.rlwe.GadgetCiphertext(rq, rp, evkQ, evkP)
+    ev = rh.rlwe.Evaluator(rq, rp)
+    levelQ, levelP = nq - 1, np_ - 1
+    pcx = rh.DevicePoly.from_numpy(rq, c1)
+    dec = ev.DecomposeNTT(levelQ, levelP, pcx, True)
+    a, b = rh.rlwe.ElementQP.alloc(rq, rp, 2, levelQ, levelP), rh.rlwe.ElementQP.alloc(rq, rp, 2, levelQ, levelP)
+    ev.GadgetProductHoistedLazy(levelQ, dec, gct, a)
+    ev.GadgetProductLazy(levelQ, pcx, gct, b)
+    for c in (0, 1):
+        assert np.array_equal(a.Value[c].Q.numpy(), b.Value[c].Q.numpy()) and np.array_equal(a.Value[c].P.numpy(), b.Value[c].P.numpy())
+    inv = rq.NewPoly(2); rq.INTT(pcx, inv)
+    dq, dp = dec[0].numpy(), dec[1].numpy()
+    for d in range(beta):
+        oq, op = rq.NewPoly(2), rp.NewPoly(2)
+        ev.DecomposeSingleNTT(levelQ, levelP, np_, d, pcx, inv, oq, op)
+        assert np.array_equal(oq.numpy(), dq[d * 2:(d + 1) * 2]) and np.array_equal(op.numpy(), dp[d * 2:(d + 1) * 2])
+    ev.close(); rq.close(); rp.close()
