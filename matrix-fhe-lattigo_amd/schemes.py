@@ -111,6 +111,51 @@ class MatrixCKKSEvaluator:
         ctOut.IsNTT = ct0.IsNTT
 
 
+    def ModDown(self, op0, opOut, levels):
+        """evaluator.go:259-290: drops `levels` limbs WITHOUT dividing (the leading limbs are copied); opOut's components hold
+        op0.Level() + 1 - levels limbs"""
+        if op0.Level() <= levels - 1:
+            raise RingHipError("cannot ModDown: input Ciphertext level is too low")
+        if opOut.Degree() != op0.Degree() or opOut.Level() != op0.Level() - levels:
+            raise RingHipError("ModDown: opOut must have op0's degree and level %d" % (op0.Level() - levels))
+        rq = self.ringQ.AtLevel(opOut.Level())
+        for vin, vout in zip(op0.Value, opOut.Value):
+            rq.CopyLvl(vin, vout)
+        opOut.IsNTT = op0.IsNTT
+
+    def _new(self, degree, level, npoly, is_ntt=False):
+        from .ringhip import DevicePoly
+        return Ciphertext([DevicePoly(self.ringQ.AtLevel(level), npoly, level + 1) for _ in range(degree + 1)], is_ntt)
+
+    def AddNew(self, ct0, ct1):
+        """:104-111"""
+        out = self._new(max(ct0.Degree(), ct1.Degree()), ct0.Level(), ct0.Value[0].npoly)
+        self.Add(ct0, ct1, out)
+        return out
+
+    def MulNew(self, ct0, ct1):
+        """:195-200"""
+        out = self._new(ct0.Degree() + ct1.Degree(), ct0.Level(), ct0.Value[0].npoly)
+        self.Mul(ct0, ct1, out)
+        return out
+
+    def RescaleNew(self, ct):
+        """:246-251"""
+        out = self._new(ct.Degree(), ct.Level() - self.levelsConsumedPerRescaling(), ct.Value[0].npoly)
+        self.Rescale(ct, out)
+        return out
+
+    def ModDownNew(self, ct, levels):
+        """:293-297"""
+        out = self._new(ct.Degree(), ct.Level() - levels, ct.Value[0].npoly)
+        self.ModDown(ct, out, levels)
+        return out
+
+    def DropLevelNew(self, op0, levels):
+        """:307-311 (DropLevel :301-303 resizes in place: on device blocks that is a copy of the leading limbs)"""
+        return self.ModDownNew(op0, levels)
+
+
 def ckks_tensor_degree1(ringQ, ct0, ct1, c0, c1, c2, c00, c01):
     """schemes/ckks/evaluator.go:821-834 (degree-1 x degree-1 tensoring of mulRelin; all operands in the NTT domain):
     c00 = MForm(ct0[0]); c01 = MForm(ct0[1]); c0 = c00*ct1[0]; c1 = c00*ct1[1] + c01*ct1[0]; c2 = c01*ct1[1]."""

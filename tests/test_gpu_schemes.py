@@ -266,3 +266,33 @@ def test_intt_mul_and_polymul_on_other_ring_types(rh, oracle, kind):
     rh.schemes.ckks_polymul(ring, qa, qb, c)
     assert np.array_equal(c.numpy(), ref.numpy())
     ring.close()
+
+
+def test_matrix_ckks_new_forms_and_level_drop(rh, oracle):
+    # MulNew / AddNew / RescaleNew / ModDownNew (evaluator.go:104-111, 195-200, 246-251, 259-297)
+    N, L, B = 3 << 10, 3, 2
+    mods = primes_3n(oracle, N, L)
+    ring = rh.Ring(N, mods, kind=rh.Matrix3N)
+    ev = rh.MatrixCKKSEvaluator(ring)
+    rng = np.random.default_rng(9)
+    mk = lambda: np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    a0, a1, b0, b1 = mk(), mk(), mk(), mk()
+    dp = lambda x: rh.DevicePoly.from_numpy(ring, x)
+    x, y = rh.Ciphertext([dp(a0), dp(a1)]), rh.Ciphertext([dp(b0), dp(b1)])
+    s = ev.AddNew(x, y)
+    for i, q in enumerate(mods):
+        assert np.array_equal(s.Value[1].numpy()[:, i], (a1[:, i] + b1[:, i]) % np.uint64(q))
+    prod = ev.MulNew(rh.Ciphertext([dp(a0), dp(a1)]), rh.Ciphertext([dp(b0), dp(b1)]))
+    ref = rh.Ciphertext([ring.NewPoly(B) for _ in range(3)])
+    ev.Mul(rh.Ciphertext([dp(a0), dp(a1)]), rh.Ciphertext([dp(b0), dp(b1)]), ref)
+    assert prod.Degree() == 2 and all(np.array_equal(u.numpy(), v.numpy()) for u, v in zip(prod.Value, ref.Value))
+    low = ev.ModDownNew(x, 1)
+    assert low.Level() == L - 2 and np.array_equal(low.Value[0].numpy(), a0[:, :L - 1]) and np.array_equal(low.Value[1].numpy(), a1[:, :L - 1])
+    xn = rh.Ciphertext([dp(a0), dp(a1)], is_ntt=True)
+    for v in xn.Value:
+        ring.NTT(v, v)
+    r = ev.RescaleNew(xn)
+    sub = ring.AtLevel(L - 2)
+    sub.INTT(r.Value[0], r.Value[0])
+    assert np.array_equal(r.Value[0].numpy(), np.stack([oracle.div_by_last_modulus_many(a0[k], mods, 1, 1) for k in range(B)]))
+    ring.close()
