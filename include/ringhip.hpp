@@ -163,6 +163,20 @@ class Ring {
   }
   void AutomorphismNTT(const Poly& in, uint64_t gen, Poly& out) const { check(rh_ring_automorphism_ntt(h_.get(), level_, in.data(), gen, out.data(), in.npoly(), 0)); }
   void Automorphism(const Poly& in, uint64_t gen, Poly& out) const { check(rh_ring_automorphism(h_.get(), level_, in.data(), gen, out.data(), in.npoly())); }
+  // AutomorphismNTTWithIndex / ...ThenAddLazy (ring/automorphism.go:50-117): `index` = a 1-poly, 1-limb device block holding the lookup table
+  void AutomorphismNTTWithIndex(const Poly& in, const Poly& index, Poly& out, bool thenAddLazy = false) const {
+    check(rh_ring_automorphism_ntt_index(h_.get(), level_, in.data(), index.data(), out.data(), in.npoly(), thenAddLazy ? 1 : 0));
+  }
+  // ring/operations.go: Poly.CopyLvl, Shift (:278-282), MultByMonomial (:306-363), MulByVectorMontgomery(ThenAddLazy) (:366-377); out of place
+  void CopyLvl(const Poly& p1, Poly& p2) const { check(rh_ring_copy_rows(h_.get(), p2.data(), p2.limbs(), p1.data(), p1.limbs(), p1.npoly(), level_)); }
+  void Shift(const Poly& p1, int k, Poly& p2) const { check(rh_ring_shift(h_.get(), level_, p1.data(), p2.data(), k, p1.npoly())); }
+  void MultByMonomial(const Poly& p1, int k, Poly& p2) const { check(rh_ring_mult_by_monomial(h_.get(), level_, p1.data(), p2.data(), k, p1.npoly())); }
+  void MulByVectorMontgomery(const Poly& p1, const Poly& vector, Poly& p2, bool thenAddLazy = false) const {
+    check(rh_ring_vec_op_bcast(h_.get(), thenAddLazy ? RH_OP_MUL_MONT_THEN_ADD_LAZY : RH_OP_MUL_MONT, p1.data(), p1.limbs(), vector.data(), p2.data(),
+                               p2.limbs(), p1.npoly(), level_));
+  }
+  // MForm + MulCoeffsMontgomery + INTT as one call (schemes/ckks/evaluator.go:821-834 + INTT)
+  void INTTMul(const Poly& a, const Poly& b, Poly& out) const { check(rh_ring_intt_mul(h_.get(), a.data(), b.data(), out.data(), a.npoly(), level_)); }
 
   std::vector<SubRing> SubRings;
  private:
@@ -222,6 +236,15 @@ class BasisExtender {
     check(rh_bext_gadget_product_hoisted(h_.get(), lq, lp, decompQ.data(), decompP.data(), evkQ.data(), evkP.data(), beta, ct0.data(),
                                          ct1.data(), ct0.npoly()));
   }
+  // GadgetProductHoistedLazy (:351-371): the accumulators modulo Q and modulo P, no ModDown; ModDownPair: Evaluator.ModDown (:33-46) NTT -> NTT
+  void GadgetProductHoistedLazy(int lq, int lp, const Poly& decompQ, const Poly& decompP, const Poly& evkQ, const Poly& evkP, int beta,
+                                Poly& ctQ0, Poly& ctQ1, Poly& ctP0, Poly& ctP1) const {
+    check(rh_bext_gadget_product_hoisted_lazy(h_.get(), lq, lp, decompQ.data(), decompP.data(), evkQ.data(), evkP.data(), beta, ctQ0.data(),
+                                              ctQ1.data(), ctP0.data(), ctP1.data(), ctQ0.npoly()));
+  }
+  void ModDownPair(int lq, int lp, const Poly& ctQ0, const Poly& ctQ1, const Poly& ctP0, const Poly& ctP1, Poly& ct0, Poly& ct1) const {
+    check(rh_bext_moddown_qp_to_q_ntt_pair(h_.get(), lq, lp, ctQ0.data(), ctQ1.data(), ctP0.data(), ctP1.data(), ct0.data(), ct1.data(), ct0.npoly()));
+  }
  private:
   std::shared_ptr<rh_bext> h_;
 };
@@ -242,6 +265,11 @@ class KeySwitchShard {
   void Digit(int digit, const uint64_t* srcGathered, const Poly& cxLoc, const uint64_t* evkQLoc, const uint64_t* evkPLoc, Poly& ct0, Poly& ct1,
              uint64_t* accP0, uint64_t* accP1) const {
     check(rh_kshard_digit(h_.get(), digit, srcGathered, cxLoc.data(), evkQLoc, evkPLoc, ct0.data(), ct1.data(), accP0, accP1, cxLoc.npoly()));
+  }
+  // all digits in one call: srcAll = every limb of INTT(cx) in chain order (one all-gather per product)
+  void Product(const uint64_t* srcAll, const Poly& cxLoc, const uint64_t* evkQLoc, const uint64_t* evkPLoc, Poly& ct0, Poly& ct1,
+               uint64_t* accP0, uint64_t* accP1) const {
+    check(rh_kshard_product(h_.get(), srcAll, cxLoc.data(), evkQLoc, evkPLoc, ct0.data(), ct1.data(), accP0, accP1, cxLoc.npoly()));
   }
   void ModDown(const uint64_t* srcPGathered, const Poly& ctIn, Poly& ctOut) const {
     check(rh_kshard_moddown(h_.get(), srcPGathered, ctIn.data(), ctOut.data(), ctIn.npoly()));

@@ -43,6 +43,21 @@ int main() {
     r2.SubRings[1].NTT(KAT16_POLY_1, y2);
     EXPECT(y2 == KAT16_NTT_1);
   }
+  // testShift (ring/ring_test.go:904-916): N = 16, q = 97, p1 = 0..15, Shift by 3; then MultByMonomial X^1 * X^8 == X^9 (:880-899) and CopyLvl
+  {
+    Ring s(16, {97});
+    std::vector<uint64_t> iota(16); for (int i = 0; i < 16; ++i) iota[i] = (uint64_t)i;
+    Poly p1 = s.NewPoly(), p2 = s.NewPoly(), p3 = s.NewPoly(), p4 = s.NewPoly();
+    p1.upload(iota);
+    s.Shift(p1, 3, p2);
+    EXPECT((p2.download() == std::vector<uint64_t>{3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2}));
+    std::vector<uint64_t> ones(16); for (int i = 0; i < 16; ++i) ones[i] = (uint64_t)(i + 1);
+    p1.upload(ones);
+    s.MultByMonomial(p1, 1, p2); s.MultByMonomial(p2, 8, p3); s.MultByMonomial(p1, 9, p4);
+    EXPECT(p3.download() == p4.download());
+    s.CopyLvl(p4, p2);
+    EXPECT(p2.download() == p4.download());
+  }
   // 3N-cyclotomic ring, Type::Matrix (ring/ntt_3n.go:21-156, ring/ring.go:299-304): omega handed over like the Go factory
   // does; vectors from references/integer_dft.py in the Go transformer's ascending-totative order
   {
