@@ -346,6 +346,32 @@ func (d *DeviceRing) AutomorphismNTT(in *DevPoly, galEl uint64, out *DevPoly) {
 	d.must(C.rh_ring_automorphism_ntt(d.h, C.int(in.limbs-1), in.ptr, C.uint64_t(galEl), out.ptr, C.int(in.npoly), 0))
 }
 
+// CopyLvl, Shift, MultByMonomial (ring/poly.go, ring/operations.go:278-282, 306-363) on dense device blocks; out of place.
+func (d *DeviceRing) CopyLvl(p1, p2 *DevPoly) {
+	d.must(C.rh_ring_copy_rows(d.h, p2.ptr, C.int(p2.limbs), p1.ptr, C.int(p1.limbs), C.int(p1.npoly), C.int(min(p1.limbs, p2.limbs)-1)))
+}
+func (d *DeviceRing) Shift(p1 *DevPoly, k int, p2 *DevPoly) {
+	d.must(C.rh_ring_shift(d.h, C.int(p1.limbs-1), p1.ptr, p2.ptr, C.int(k), C.int(p1.npoly)))
+}
+func (d *DeviceRing) MultByMonomial(p1 *DevPoly, k int, p2 *DevPoly) {
+	d.must(C.rh_ring_mult_by_monomial(d.h, C.int(p1.limbs-1), p1.ptr, p2.ptr, C.int(k), C.int(p1.npoly)))
+}
+
+// AutomorphismNTTWithIndex (ring/automorphism.go:50-117): index = a 1-poly, 1-limb device block holding the lookup table
+// (ring.AutomorphismNTTIndex, uploaded once per Galois element).
+func (d *DeviceRing) AutomorphismNTTWithIndex(in, index, out *DevPoly, thenAddLazy bool) {
+	add := C.int(0)
+	if thenAddLazy {
+		add = 1
+	}
+	d.must(C.rh_ring_automorphism_ntt_index(d.h, C.int(in.limbs-1), in.ptr, index.ptr, out.ptr, C.int(in.npoly), add))
+}
+
+// INTTMul = MForm + MulCoeffsMontgomery + INTT as one call (schemes/ckks/evaluator.go:821-834 + INTT).
+func (d *DeviceRing) INTTMul(a, b, out *DevPoly) {
+	d.must(C.rh_ring_intt_mul(d.h, a.ptr, b.ptr, out.ptr, C.int(a.npoly), C.int(a.limbs-1)))
+}
+
 // KeySwitcher pairs the Q and P device rings (ring.BasisExtender + the gadget product of rlwe.Evaluator).
 type KeySwitcher struct {
 	be   *C.rh_bext
@@ -392,6 +418,16 @@ func (k *KeySwitcher) DecomposeNTT(levelQ, levelP int, c2 *DevPoly, c2IsNTT bool
 func (k *KeySwitcher) GadgetProductHoisted(levelQ, levelP int, decompQ, decompP, evkQ, evkP *DevPoly, beta int, ct0, ct1 *DevPoly) {
 	k.q.must(C.rh_bext_gadget_product_hoisted(k.be, C.int(levelQ), C.int(levelP), decompQ.ptr, decompP.ptr, evkQ.ptr, evkP.ptr, C.int(beta),
 		ct0.ptr, ct1.ptr, C.int(ct0.npoly)))
+}
+
+// GadgetProductHoistedLazy (core/rlwe/evaluator_gadget_product.go:351-371): the accumulators modulo Q and modulo P, no ModDown;
+// ModDownPair is Evaluator.ModDown (:33-46), NTT -> NTT, on both components.
+func (k *KeySwitcher) GadgetProductHoistedLazy(levelQ, levelP int, decompQ, decompP, evkQ, evkP *DevPoly, beta int, ctQ0, ctQ1, ctP0, ctP1 *DevPoly) {
+	k.q.must(C.rh_bext_gadget_product_hoisted_lazy(k.be, C.int(levelQ), C.int(levelP), decompQ.ptr, decompP.ptr, evkQ.ptr, evkP.ptr, C.int(beta),
+		ctQ0.ptr, ctQ1.ptr, ctP0.ptr, ctP1.ptr, C.int(ctQ0.npoly)))
+}
+func (k *KeySwitcher) ModDownPair(levelQ, levelP int, ctQ0, ctQ1, ctP0, ctP1, ct0, ct1 *DevPoly) {
+	k.q.must(C.rh_bext_moddown_qp_to_q_ntt_pair(k.be, C.int(levelQ), C.int(levelP), ctQ0.ptr, ctQ1.ptr, ctP0.ptr, ctP1.ptr, ct0.ptr, ct1.ptr, C.int(ct0.npoly)))
 }
 
 // ModDownQPtoQNTT mirrors ring.BasisExtender.ModDownQPtoQNTT (ring/basis_extension.go:241-258).
