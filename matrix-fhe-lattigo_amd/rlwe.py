@@ -314,8 +314,7 @@ class Evaluator:
         P = 1
         for p in self.ringP.moduli[:levelP + 1]:
             P *= int(p)
-        ringQ.MulScalarBigint(ctIn.Value[0], P, tmp.Value[1].Q)                           # ctIn[0] * P (:138)
-        ringQ.Add(tmp.Value[0].Q, tmp.Value[1].Q, tmp.Value[0].Q)                         # (:141)
+        ringQ.MulScalarBigintThenAdd(ctIn.Value[0], P, tmp.Value[0].Q)                    # + ctIn[0] * P (:138, :141 as one pass: same canonical values)
         ringQ.AutomorphismNTT(tmp.Value[0].Q, galEl, ctQP.Value[0].Q)                     # (:143)
         ringP.AutomorphismNTT(tmp.Value[0].P, galEl, ctQP.Value[0].P)
         ctQP.IsNTT = True

@@ -133,7 +133,14 @@ ms_rot = timed(lambda: kev.AutomorphismHoisted(23, ctA, dec, gal, ctO), reps=3, 
 e = entry("hoisted rotation N=2^16 Q=24 P=6: DecomposeNTT once (%.3f ms per batch of %d), then per rotation" % (ms_dec, B), ms_rot, 0.0, B, "rotation")
 e.pop("algorithmic_GBps"); e.pop("frac_of_8TBps")
 res.append(e)
-del dec
+# rotations accumulated modulo QP under ONE ModDown (AutomorphismHoistedLazy, core/rlwe/evaluator_automorphism.go:103-160): the pattern of linear transformations
+lz = rh.rlwe.ElementQP.alloc(rq, rp, B, 23, 5)
+ms_lazy = timed(lambda: kev.AutomorphismHoistedLazy(23, ctA, dec, gal, lz), reps=3, warm=1)
+ms_md = timed(lambda: kev.ModDown(23, 5, lz, ctO), reps=3, warm=1)
+e = entry("lazy hoisted rotation N=2^16 Q=24 P=6 (result modulo QP; one ModDown per sum of rotations: %.3f ms per batch of %d)" % (ms_md, B), ms_lazy, 0.0, B, "rotation")
+e.pop("algorithmic_GBps"); e.pop("frac_of_8TBps")
+res.append(e)
+del dec, lz
 kev.close()
 del ctA, ctB, ctO, ctR, gct
 cev.close()
