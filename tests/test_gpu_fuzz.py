@@ -1,0 +1,200 @@
+"""GPU: seeded random differential test of the ring entry points against the oracle.
+
+The hand-picked cases of the other files cover the shapes the reference's tests and the BASELINE configs use; this file draws
+the shapes the callers of ring.Ring produce in between -- any degree 2^3 .. 2^17, any limb count, batches on either side of the
+launch-shape thresholds of the engine (one launch pair / pipelined spans of ~2048 rows), AtLevel views over polys that carry more
+limbs than the view (ring/ring.go:192-213: different row strides on the two sides), in place and out of place, every ring type
+-- and checks drawn (poly, limb) rows bit for bit, and that rows above the view's level are not touched.  Every case is derived
+from the case number, so a failure names a reproducible shape."""
+import numpy as np
+import pytest
+
+from conftest import QI60, PI60, uniform_mod
+from test_oracle_ntt3n import find_prime_3n, omega_for
+
+pytestmark = pytest.mark.gpu
+
+SENTINEL = np.uint64(0xDEADBEEFCAFEF00D)
+
+
+def _draw_shape(rng, max_rows):
+    """(logN, L, level, B): rows = B * (level + 1) <= max_rows words-rows of N"""
+    logN = int(rng.choice([3, 4, 5, 7, 10, 11, 12, 13, 14, 15, 16, 17], p=[.04, .04, .04, .06, .08, .06, .1, .12, .12, .12, .16, .06]))
+    L = int(rng.choice([1, 2, 3, 5, 8, 16, 17]))
+    level = int(rng.integers(0, L))
+    cap = max(1, min(max_rows // (level + 1), (1 << 27) // ((level + 1) << logN)))   # <= 1 GiB per block
+    B = int(rng.choice([1, 2, 3, 7, 33, 130, 300]))
+    return logN, L, level, max(1, min(B, cap))
+
+
+def _block(rng, mods, B, limbs, N, level):
+    """B polys of `limbs` limbs: limbs 0..level uniform residues of their modulus, the others a sentinel that must survive"""
+    a = np.full((B, limbs, N), SENTINEL, dtype=np.uint64)
+    for i in range(level + 1):
+        a[:, i] = uniform_mod(rng, mods[i], (B, N))
+    return a
+
+
+def _spots(rng, B, level, n=4):
+    s = {(0, 0), (B - 1, level)}
+    for _ in range(n):
+        s.add((int(rng.integers(0, B)), int(rng.integers(0, level + 1))))
+    return sorted(s)
+
+
+@pytest.mark.parametrize("case", range(96))
+def test_fuzz_standard_ntt_family(rh, oracle, case):
+    """Ring.NTT / NTTLazy / INTT / INTTLazy (ring/ntt.go:127-152) through AtLevel views"""
+    rng = np.random.default_rng(7000 + case)
+    logN, L, level, B = _draw_shape(rng, 600)
+    if case % 8 in (5, 6):                                     # just past the pipelined-span threshold of the engine (~2048 rows)
+        logN = int(rng.choice([12, 13, 14, 15, 16]))
+        B = 2048 // (level + 1) + int(rng.choice([1, 5, 40]))
+    N = 1 << logN
+    mods = (QI60 + PI60)[:L]
+    which = ["NTT", "INTT", "NTTLazy", "INTTLazy"][(case + case // 8) % 4]
+    inplace = bool(rng.integers(0, 2))
+    limbs_in = level + 1 + int(rng.choice([0, 0, 1, 3]))
+    limbs_out = limbs_in if inplace else level + 1 + int(rng.choice([0, 0, 2]))
+    ring = rh.Ring(N, mods)
+    view = ring.AtLevel(level)
+    a = _block(rng, mods, B, limbs_in, N, level)
+    pin = rh.DevicePoly.from_numpy(ring, a)
+    if inplace:
+        pout = pin
+    else:
+        pout = rh.DevicePoly.from_numpy(ring, np.full((B, limbs_out, N), SENTINEL, dtype=np.uint64))
+    getattr(view, which)(pin, pout)
+    got = pout.numpy()
+    ctx = "case %d: %s N=2^%d L=%d level=%d B=%d limbs %d->%d inplace=%s" % (case, which, logN, L, level, B, limbs_in, limbs_out, inplace)
+    for (k, i) in _spots(rng, B, level):
+        sr = oracle.SubRingConsts(N, mods[i])
+        f = oracle.ntt if which.startswith("NTT") else oracle.intt
+        exp = f(a[k, i], sr, lazy=which.endswith("Lazy"))
+        assert np.array_equal(got[k, i], exp), ctx + " row (%d, %d)" % (k, i)
+    if limbs_out > level + 1:
+        assert (got[:, level + 1:] == SENTINEL).all(), ctx + ": rows above the level were written"
+    if not inplace:
+        assert np.array_equal(pin.numpy(), a), ctx + ": input modified"
+    ring.close()
+
+
+@pytest.mark.parametrize("case", range(30))
+def test_fuzz_vec_ops_at_level(rh, oracle, case):
+    """one drawn element-wise kernel of ring/vec_ops.go through an AtLevel view with per-operand row strides (ring/operations.go)"""
+    rng = np.random.default_rng(8000 + case)
+    logN, L, level, B = _draw_shape(rng, 400)
+    logN = max(logN, 4)
+    N = 1 << logN
+    mods = (QI60 + PI60)[:L]
+    names = sorted(k for k in rh.OPS if k not in ("COUNT", "MASK", "ZERO"))
+    name = names[int(rng.integers(0, len(names)))]
+    code = rh.OPS[name]
+    ring = rh.Ring(N, mods)
+    view = ring.AtLevel(level)
+    lx, ly, lz = (level + 1 + int(rng.choice([0, 1, 2])) for _ in range(3))
+    lazy_in = name in ("ADD_LAZY", "SUB_LAZY", "MUL_LAZY", "MUL_LAZY_THEN_ADD_LAZY", "REDUCE", "REDUCE_LAZY", "MUL_BARRETT", "MUL_BARRETT_LAZY",
+                       "MUL_MONT_LAZY", "MUL_MONT_LAZY_THEN_ADD_LAZY", "MFORM_LAZY", "MUL_MONT_LAZY_THEN_NEG")
+    x, y, z = _block(rng, mods, B, lx, N, level), _block(rng, mods, B, ly, N, level), _block(rng, mods, B, lz, N, level)
+    if lazy_in and case % 2:                                   # the lazy forms take any 64-bit operand
+        x[:, :level + 1] = rng.integers(0, 1 << 64, size=(B, level + 1, N), dtype=np.uint64)
+    s0 = np.array([int(rng.integers(1, int(q))) for q in mods[:level + 1]], dtype=np.uint64)
+    s1 = np.array([int(rng.integers(1, int(q))) for q in mods[:level + 1]], dtype=np.uint64)
+    px, py, pz = (rh.DevicePoly.from_numpy(ring, t) for t in (x, y, z))
+    view.vec_op(name, px, py, pz, s0=s0, s1=s1)
+    got = pz.numpy()
+    ctx = "case %d: %s N=2^%d level=%d B=%d limbs (%d, %d, %d)" % (case, name, logN, level, B, lx, ly, lz)
+    for (k, i) in _spots(rng, B, level):
+        exp = oracle.vec_op(code, x[k, i], y[k, i], z[k, i], s0[i], s1[i], mods[i])
+        assert np.array_equal(got[k, i], exp), ctx + " row (%d, %d)" % (k, i)
+    if lz > level + 1:
+        assert (got[:, level + 1:] == SENTINEL).all(), ctx + ": rows above the level were written"
+    assert np.array_equal(px.numpy(), x) and np.array_equal(py.numpy(), y), ctx + ": operand modified"
+    ring.close()
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_fuzz_conjugate_invariant_and_3n(rh, oracle, case):
+    """the other two ring types through the same batched entry points (ring/ntt.go:80-124, ring/ntt_3n.go:82-156)"""
+    rng = np.random.default_rng(9000 + case)
+    L = int(rng.choice([1, 2, 3]))
+    level = int(rng.integers(0, L))
+    B = int(rng.choice([1, 2, 5, 19]))
+    inplace = bool(rng.integers(0, 2))
+    if case % 2 == 0:
+        logN = int(rng.choice([4, 8, 11, 12, 13, 14, 15, 16]))
+        N = 1 << logN
+        mods = [q for q in QI60 + PI60 if (q - 1) % (4 * N) == 0][:L]
+        ring = rh.Ring(N, mods, kind=rh.ConjugateInvariant)
+        srs = [oracle.SubRingConsts(N, q, nthroot=4 * N) for q in mods]
+        fwd = lambda v, i: oracle.ntt_ci(v, srs[i])
+        bwd = lambda v, i: oracle.intt_ci(v, srs[i])
+        name = "CI N=2^%d" % logN
+    else:
+        N = int(rng.choice([6, 18, 48, 96, 3 * 256, 3 * 1024, 3 * 2048, 3 * 8192, 9 * 1024, 3 << 14]))
+        q = find_prime_3n(N, 60)
+        mods = [q]
+        while len(mods) < L:
+            q += 3 * N
+            while not oracle.lib().orc_is_prime(q):
+                q += 3 * N
+            mods.append(q)
+        oms = [omega_for(m, N) for m in mods]
+        ring = rh.Ring(N, mods, kind=rh.Matrix3N)
+        fwd = lambda v, i: oracle.ntt3n_forward(v, mods[i], oms[i])
+        bwd = lambda v, i: oracle.ntt3n_backward(v, mods[i], oms[i])
+        name = "3N N=%d" % N
+    view = ring.AtLevel(level)
+    a = _block(rng, mods, B, level + 1, N, level)
+    pin = rh.DevicePoly.from_numpy(ring, a)
+    pout = pin if inplace else view.NewPoly(B)
+    inverse = bool((case // 2) % 2)
+    (view.INTT if inverse else view.NTT)(pin, pout)
+    got = pout.numpy()
+    ctx = "case %d: %s %s L=%d level=%d B=%d inplace=%s" % (case, name, "INTT" if inverse else "NTT", L, level, B, inplace)
+    for (k, i) in _spots(rng, B, level, n=2):
+        assert np.array_equal(got[k, i], (bwd if inverse else fwd)(a[k, i], i)), ctx + " row (%d, %d)" % (k, i)
+    ring.close()
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_fuzz_basis_extension_levels(rh, oracle, case):
+    """ModUpQtoP / ModUpPtoQ / ModDownQPtoQ at drawn (levelQ, levelP) of a larger extender (ring/basis_extension.go:188-234): the
+    constants of EVERY source level are the extender's own tables; unreduced outputs compared word for word"""
+    rng = np.random.default_rng(9500 + case)
+    logN = int(rng.choice([4, 9, 12, 13, 14]))
+    N = 1 << logN
+    nq, npm = int(rng.integers(2, 9)), int(rng.integers(1, 5))
+    Q, P = QI60[:nq], PI60[:npm]
+    levelQ, levelP = int(rng.integers(0, nq)), int(rng.integers(0, npm))
+    B = int(rng.choice([1, 2, 6]))
+    rq, rp = rh.Ring(N, Q), rh.Ring(N, P)
+    be = rh.BasisExtender(rq, rp)
+    vq, vp = rq.AtLevel(levelQ), rp.AtLevel(levelP)
+    xq = _block(rng, Q, B, levelQ + 1, N, levelQ)
+    xp = _block(rng, P, B, levelP + 1, N, levelP)
+    pq, pp = rh.DevicePoly.from_numpy(rq, xq), rh.DevicePoly.from_numpy(rp, xp)
+    ctx = "case %d: N=2^%d Q=%d P=%d levelQ=%d levelP=%d B=%d" % (case, logN, nq, npm, levelQ, levelP, B)
+    kind = case % 3
+    if kind == 0:
+        out = vp.NewPoly(B)
+        be.ModUpQtoP(levelQ, levelP, pq, out)
+        got = out.numpy()
+        for k in {0, B - 1}:
+            exp = oracle.modup_centered(xq[k], Q[:levelQ + 1], P[:levelP + 1])
+            assert np.array_equal(got[k], exp), ctx + " ModUpQtoP poly %d" % k
+    elif kind == 1:
+        out = vq.NewPoly(B)
+        be.ModUpPtoQ(levelP, levelQ, pp, out)
+        got = out.numpy()
+        for k in {0, B - 1}:
+            exp = oracle.modup_centered(xp[k], P[:levelP + 1], Q[:levelQ + 1])
+            assert np.array_equal(got[k], exp), ctx + " ModUpPtoQ poly %d" % k
+    else:
+        out = vq.NewPoly(B)
+        be.ModDownQPtoQ(levelQ, levelP, pq, pp, out)
+        got = out.numpy()
+        for k in {0, B - 1}:
+            exp = oracle.moddown_qp_to_q(xq[k], xp[k], Q[:levelQ + 1], P[:levelP + 1])
+            assert np.array_equal(got[k], exp), ctx + " ModDownQPtoQ poly %d" % k
+    be.close(); rq.close(); rp.close()
