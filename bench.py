@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=-1, help="polys per (column,tile) kernel pair; -1 = engine default")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="skip the clock / package-power sample under load (rocm-smi)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed region's output")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -211,6 +212,47 @@ def cpu_baseline(args, N, mods):
     return out
 
 
+def power_sample(step, dev_index, seconds=1.8):
+    """Shader clock and package power WHILE the step runs: the step is re-launched for `seconds` on this thread, `rocm-smi` is run
+    from a sampler thread (a child process that makes no HIP call).  None when rocm-smi is not available."""
+    import re
+    import shutil
+    import threading
+    import torch
+    exe = shutil.which("rocm-smi")
+    if exe is None:
+        return None
+
+    def smi(*flags):
+        try:
+            return subprocess.run([exe, "-d", str(dev_index)] + list(flags), capture_output=True, text=True, timeout=20).stdout
+        except (OSError, subprocess.SubprocessError):
+            return ""
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        time.sleep(0.6 * seconds / 1.8)
+        while not stop.is_set() and len(samples) < 3:
+            t = smi("--showclocks", "--showpower")
+            c, w = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", t), re.search(r"Power \(W\): ([\d.]+)", t)
+            if c and w:
+                samples.append((int(c.group(1)), float(w.group(1))))
+    th = threading.Thread(target=sampler)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds or (th.is_alive() and time.perf_counter() - t0 < 4 * seconds):
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+    stop.set(); th.join()
+    cap = re.search(r"Max Graphics Package Power \(W\): ([\d.]+)", smi("--showmaxpower"))
+    if not samples:
+        return None
+    return {"sclk_mhz_under_load": sum(c for c, _ in samples) / len(samples), "package_w_under_load": sum(w for _, w in samples) / len(samples),
+            "package_cap_w": float(cap.group(1)) if cap else None, "sclk_peak_mhz": 2400, "samples": len(samples),
+            "source": "rocm-smi --showclocks --showpower sampled while the timed step is re-launched for %.1f s after the timed region" % seconds}
+
+
 def load_json(name):
     p = os.path.join(ROOT, "profiles", name)
     try:
@@ -286,6 +328,7 @@ def run_ntt(args):
             b.record(stream)
             torch.cuda.synchronize()
             kern[name] = a.elapsed_time(b) / reps
+    power = power_sample(step, local_rank) if (rank == 0 and world == 1 and not args.no_power) else None
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -324,6 +367,14 @@ def run_ntt(args):
                         "butterfly_ceiling_NTT_per_s": vj["butterfly_ceiling_limb_ntt_per_s"] / L,
                         "frac_of_butterfly_ceiling": (B / (launch_ms * 1e-3)) / (vj["butterfly_ceiling_limb_ntt_per_s"] / L),
                         "source": vj.get("source")}
+    if power is not None:
+        # the package power cap, not a pipeline, sets the clock this kernel runs at: both ceilings above are
+        # quoted at the 2.4 GHz the chip holds for pure VALU streams; at the clock measured under THIS kernel they scale by sclk / 2400
+        roof["power"] = power
+        if "valu" in roof:
+            k = power["sclk_mhz_under_load"] / power["sclk_peak_mhz"]
+            roof["valu"]["issue_peak_at_measured_clock_Gwinstr_per_s"] = roof["valu"]["issue_peak_Gwinstr_per_s"] * k
+            roof["valu"]["frac_of_issue_peak_at_measured_clock"] = roof["valu"]["frac_of_issue_peak"] / k
     out = {
         "metric": "forward-NTT/s at N=2^%d, %d RNS limbs; achieved HBM GB/s vs peak" % (args.logn, L),
         "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
