@@ -47,6 +47,23 @@ def main():
         "vec ADD (3 streams)": lambda: ring.Add(poly, other, other),
         "Ring.INTT": lambda: ring.INTT(poly, poly),
     }
+    # config 5 gadget product (Q = 24, P = 6, batch 64) and the rescale of the metric ring (512 polys, 16 -> 15 limbs)
+    from bench import PI60
+    rq, rp = rh.Ring(N, QI60[:24]), rh.Ring(N, PI60[:6])
+    for r in (rq, rp):
+        r.set_stream(stream.cuda_stream)
+    be = rh.BasisExtender(rq, rp)
+
+    def rb(n, mods):
+        m = torch.tensor(mods, dtype=torch.int64, device=dev).view(1, len(mods), 1)
+        return torch.randint(0, 1 << 62, (n, len(mods), N), dtype=torch.int64, device=dev, generator=g) % m
+    xq, evq, evp = rb(64, QI60[:24]), rb(8, QI60[:24]), rb(8, PI60[:6])
+    c0, c1 = torch.zeros_like(xq), torch.zeros_like(xq)
+    pq, p0, p1 = (rh.DevicePoly.from_torch(rq, t) for t in (xq, c0, c1))
+    work["GadgetProduct, batch 64 (config 5)"] = lambda: be.GadgetProduct(23, 5, pq, evq.data_ptr(), evp.data_ptr(), 4, p0, p1)
+    half = rh.DevicePoly.from_torch(ring, data[:512])
+    resc = rh.DevicePoly.from_torch(ring.AtLevel(L - 2), torch.empty((512, L - 1, N), dtype=torch.int64, device=dev))
+    work["DivRoundByLastModulusNTT, 512 polys"] = lambda: ring.DivRoundByLastModulusNTT(half, resc)
     print("%-44s | sclk MHz (samples) | package W (samples) | ms per call" % "workload")
     for name, fn in work.items():
         if fn is None:
