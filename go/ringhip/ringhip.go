@@ -357,6 +357,22 @@ func (d *DeviceRing) MultByMonomial(p1 *DevPoly, k int, p2 *DevPoly) {
 	d.must(C.rh_ring_mult_by_monomial(d.h, C.int(p1.limbs-1), p1.ptr, p2.ptr, C.int(k), C.int(p1.npoly)))
 }
 
+// Standard <-> conjugate-invariant bridges (ring/conjugate_invariant.go:8-80; callers schemes/ckks/bridge.go:82-83, 116-117).  The receiver
+// is the ring the reference calls the method on: the standard ring of degree 2n for Unfold, the conjugate-invariant ring of degree n for Fold.
+func (d *DeviceRing) UnfoldConjugateInvariantToStandard(ci, std *DevPoly) {
+	d.must(C.rh_ring_unfold_ci_to_standard(d.h, C.int(std.limbs-1), ci.ptr, std.ptr, C.int(std.npoly)))
+}
+func (d *DeviceRing) FoldStandardToConjugateInvariant(std, index, ci *DevPoly) {
+	d.must(C.rh_ring_fold_standard_to_ci(d.h, C.int(ci.limbs-1), std.ptr, index.ptr, ci.ptr, C.int(std.npoly)))
+}
+func (d *DeviceRing) PadDefaultRingToConjugateInvariant(std *DevPoly, isNTT bool, ci *DevPoly) {
+	f := C.int(0)
+	if isNTT {
+		f = 1
+	}
+	d.must(C.rh_ring_pad_default_to_ci(d.h, C.int(std.limbs-1), std.ptr, f, ci.ptr, C.int(std.npoly)))
+}
+
 // AutomorphismNTTWithIndex (ring/automorphism.go:50-117): index = a 1-poly, 1-limb device block holding the lookup table
 // (ring.AutomorphismNTTIndex, uploaded once per Galois element).
 func (d *DeviceRing) AutomorphismNTTWithIndex(in, index, out *DevPoly, thenAddLazy bool) {

@@ -186,6 +186,20 @@ int rh_ring_mult_by_monomial(rh_ring* r, int level, const uint64_t* in_dev, uint
  * 0..level; index_dev: the caller's lookup table of N words ON THE DEVICE (e.g. AutomorphismNTTIndex, :12-34); out of place */
 int rh_ring_automorphism_ntt_index(rh_ring* r, int level, const uint64_t* in_dev, const uint64_t* index_dev, uint64_t* out_dev, int npoly,
                                    int add_lazy);
+/* Standard <-> conjugate-invariant bridges (ring/conjugate_invariant.go; callers: schemes/ckks/bridge.go:82-83, 116-117,
+ * core/rlwe/keygenerator.go:213).  Dense blocks, every limb 0..level, out of place; n = the SMALLER of the two degrees.
+ *   rh_ring_unfold_ci_to_standard (:8-26)   r: the standard ring of degree 2n.  ci: rows of n words, std: rows of 2n words;
+ *                                           std[j] = ci[j], std[n + k] = ci[n - 1 - k]
+ *   rh_ring_fold_standard_to_ci (:31-49)    r: the conjugate-invariant ring of degree n.  std: rows of 2n words, ci: rows of n words,
+ *                                           index_dev: n words on the device with values < 2n (AutomorphismNTTIndex of the standard ring);
+ *                                           ci[j] = CRed(std[index[j]] + std[j])
+ *   rh_ring_pad_default_to_ci (:52-80)      r: a ring of degree n (level and moduli).  std: rows of n words, ci: rows of 2n words of which only
+ *                                           the first n are written, with the reference's in-place loop reproduced: is_ntt: ci[k] = std[k],
+ *                                           ci[n-1-k] = std[k] for k < n/2;  else ci[0] = 0, ci[k] = std[k] (1 <= k < n/2),
+ *                                           ci[n/2] = q - std[n/2], ci[n-k] = q - std[k] (1 <= k < n/2; q - 0 is written as q) */
+int rh_ring_unfold_ci_to_standard(rh_ring* r, int level, const uint64_t* ci_dev, uint64_t* std_dev, int npoly);
+int rh_ring_fold_standard_to_ci(rh_ring* r, int level, const uint64_t* std_dev, const uint64_t* index_dev, uint64_t* ci_dev, int npoly);
+int rh_ring_pad_default_to_ci(rh_ring* r, int level, const uint64_t* std_dev, int is_ntt, uint64_t* ci_dev, int npoly);
 
 /* ---- RNS rescale (ring/scaling.go): divide by the last modulus, `nb` times.  round = 0: floored, 1: rounded.
  * p0: npoly polys of level+1 limbs; p1: npoly polys of p1_rows >= level+1-nb limbs (limbs 0..level-nb are written).

@@ -169,6 +169,15 @@ class Ring {
   }
   // ring/operations.go: Poly.CopyLvl, Shift (:278-282), MultByMonomial (:306-363), MulByVectorMontgomery(ThenAddLazy) (:366-377); out of place
   void CopyLvl(const Poly& p1, Poly& p2) const { check(rh_ring_copy_rows(h_.get(), p2.data(), p2.limbs(), p1.data(), p1.limbs(), p1.npoly(), level_)); }
+  // ring/conjugate_invariant.go: UnfoldConjugateInvariantToStandard (:8-26, receiver: standard ring of degree 2n), FoldStandardToConjugateInvariant
+  // (:31-49, receiver: conjugate-invariant ring of degree n; index: device table of n words < 2n), PadDefaultRingToConjugateInvariant (:52-80)
+  void UnfoldConjugateInvariantToStandard(const Poly& ci, Poly& std_) const { check(rh_ring_unfold_ci_to_standard(h_.get(), level_, ci.data(), std_.data(), std_.npoly())); }
+  void FoldStandardToConjugateInvariant(const Poly& std_, const Poly& index, Poly& ci) const {
+    check(rh_ring_fold_standard_to_ci(h_.get(), level_, std_.data(), index.data(), ci.data(), std_.npoly()));
+  }
+  void PadDefaultRingToConjugateInvariant(const Poly& std_, bool isNTT, Poly& ci) const {
+    check(rh_ring_pad_default_to_ci(h_.get(), level_, std_.data(), isNTT ? 1 : 0, ci.data(), std_.npoly()));
+  }
   void Shift(const Poly& p1, int k, Poly& p2) const { check(rh_ring_shift(h_.get(), level_, p1.data(), p2.data(), k, p1.npoly())); }
   void MultByMonomial(const Poly& p1, int k, Poly& p2) const { check(rh_ring_mult_by_monomial(h_.get(), level_, p1.data(), p2.data(), k, p1.npoly())); }
   void MulByVectorMontgomery(const Poly& p1, const Poly& vector, Poly& p2, bool thenAddLazy = false) const {

@@ -175,3 +175,64 @@ extern "C" int rh_ring_automorphism_ntt_index(rh_ring* r, int level, const uint6
   automorphism_index_kernel<<<dim3(chunks, rows), 256, 0, rh_stream(r)>>>(in, out, index, (unsigned)r->N, add_lazy);
   return done("automorphism_index_kernel");
 }
+
+// ---- standard <-> conjugate-invariant bridges (ring/conjugate_invariant.go) ----------------------------------------------------------
+// unfold (:8-26): std[j] = ci[j], std[n + k] = ci[n - 1 - k]; one thread per word of the 2n-word output row
+__global__ void __launch_bounds__(256)
+ci_unfold_kernel(const u64* ci, u64* std_, unsigned n) {
+  const size_t bi = (size_t)blockIdx.y * n, bo = (size_t)blockIdx.y * 2 * n;
+  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < 2 * n; j += gridDim.x * blockDim.x)
+    std_[bo + j] = ci[bi + (j < n ? j : 2 * n - 1 - j)];
+}
+// fold (:31-49): AutomorphismNTTWithIndex over the first n outputs, then SubRing.Add with the first n words of the standard poly
+__global__ void __launch_bounds__(256)
+ci_fold_std_kernel(const u64* std_, const u64* __restrict__ index, u64* ci, unsigned n, const LimbConsts* __restrict__ consts, int L) {
+  const u64 q = consts[blockIdx.y % (unsigned)L].q;
+  const size_t bi = (size_t)blockIdx.y * 2 * n, bo = (size_t)blockIdx.y * n;
+  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const u64 v = std_[bi + index[j]] + std_[bi + j];
+    ci[bo + j] = v >= q ? v - q : v;                            // CRed (addvec, ring/vec_ops.go:7-29)
+  }
+}
+// pad (:52-80): the reference copies the n words and then runs its loop IN PLACE over them, so the second half of the loop reads what the
+// first half wrote; the closed form of that is what each thread writes (ringhip.h).  Words n..2n-1 of the output row are not touched.
+__global__ void __launch_bounds__(256)
+ci_pad_kernel(const u64* std_, u64* ci, unsigned n, int is_ntt, const LimbConsts* __restrict__ consts, int L) {
+  const u64 q = consts[blockIdx.y % (unsigned)L].q;
+  const size_t bi = (size_t)blockIdx.y * n, bo = (size_t)blockIdx.y * 2 * n;
+  const unsigned h = n / 2;
+  for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    u64 v;
+    if (is_ntt) v = std_[bi + (k < h ? k : n - 1 - k)];
+    else if (k == 0) v = 0;
+    else if (k < h) v = std_[bi + k];
+    else if (k == h) v = q - std_[bi + h];
+    else v = q - std_[bi + (n - k)];
+    ci[bo + k] = v;
+  }
+}
+static unsigned bridge_chunks(unsigned words) { unsigned c = (words + 1023) / 1024; return c > 64 ? 64 : (c ? c : 1); }
+extern "C" int rh_ring_unfold_ci_to_standard(rh_ring* r, int level, const uint64_t* ci, uint64_t* std_, int npoly) {
+  if (int rc = index_map_common(r, level, ci, std_, npoly, "unfold_ci_to_standard")) return rc;
+  if (r->kind != RH_RING_STANDARD || r->N < 2) return rh_fail(RH_ERR_ARG, "unfold_ci_to_standard: the receiver is the standard ring of degree 2n");
+  const unsigned rows = (unsigned)npoly * (unsigned)(level + 1), n = (unsigned)r->N / 2;
+  if (!rows) return RH_OK;
+  ci_unfold_kernel<<<dim3(bridge_chunks(2 * n), rows), 256, 0, rh_stream(r)>>>(ci, std_, n);
+  return done("ci_unfold_kernel");
+}
+extern "C" int rh_ring_fold_standard_to_ci(rh_ring* r, int level, const uint64_t* std_, const uint64_t* index, uint64_t* ci, int npoly) {
+  if (!index) return rh_fail(RH_ERR_ARG, "fold_standard_to_ci: null index table");
+  if (int rc = index_map_common(r, level, std_, ci, npoly, "fold_standard_to_ci")) return rc;
+  const unsigned rows = (unsigned)npoly * (unsigned)(level + 1), n = (unsigned)r->N;
+  if (!rows) return RH_OK;
+  ci_fold_std_kernel<<<dim3(bridge_chunks(n), rows), 256, 0, rh_stream(r)>>>(std_, index, ci, n, r->d_consts, level + 1);
+  return done("ci_fold_std_kernel");
+}
+extern "C" int rh_ring_pad_default_to_ci(rh_ring* r, int level, const uint64_t* std_, int is_ntt, uint64_t* ci, int npoly) {
+  if (int rc = index_map_common(r, level, std_, ci, npoly, "pad_default_to_ci")) return rc;
+  if (r->N < 2) return rh_fail(RH_ERR_ARG, "pad_default_to_ci: degree < 2");
+  const unsigned rows = (unsigned)npoly * (unsigned)(level + 1), n = (unsigned)r->N;
+  if (!rows) return RH_OK;
+  ci_pad_kernel<<<dim3(bridge_chunks(n), rows), 256, 0, rh_stream(r)>>>(std_, ci, n, is_ntt ? 1 : 0, r->d_consts, level + 1);
+  return done("ci_pad_kernel");
+}

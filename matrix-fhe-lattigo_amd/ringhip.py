@@ -86,6 +86,8 @@ def lib():
         "rh_ring_copy_rows": (i, [vp, vp, i, vp, i, i, i]),
         "rh_ring_vec_op_bcast": (i, [vp, i, vp, i, vp, vp, i, i, i]), "rh_ring_vec_op_halves": (i, [vp, i, vp, vp, i, i, U64P, U64P]),
         "rh_ring_shift": (i, [vp, i, vp, vp, i, i]), "rh_ring_automorphism_ntt_index": (i, [vp, i, vp, vp, vp, i, i]), "rh_ring_mult_by_monomial": (i, [vp, i, vp, vp, i, i]),
+        "rh_ring_unfold_ci_to_standard": (i, [vp, i, vp, vp, i]), "rh_ring_fold_standard_to_ci": (i, [vp, i, vp, vp, vp, i]),
+        "rh_ring_pad_default_to_ci": (i, [vp, i, vp, i, vp, i]),
         "rh_ntt_forward": (i, [vp, i, U64P, U64P]), "rh_ntt_forward_lazy": (i, [vp, i, U64P, U64P]),
         "rh_ntt_backward": (i, [vp, i, U64P, U64P]), "rh_ntt_backward_lazy": (i, [vp, i, U64P, U64P]),
         "rh_ring_ntt": (i, [vp, vp, vp, i, i, i]), "rh_ring_intt": (i, [vp, vp, vp, i, i, i]),
@@ -545,6 +547,44 @@ class Ring:
         if p1.ptr == p2.ptr:
             src = self.NewPoly(p1.npoly); self.CopyLvl(p1, src)
         _check(lib().rh_ring_mult_by_monomial(self._h, self.level, src.ptr, p2.ptr, int(k), p1.npoly))
+
+    # ---- standard <-> conjugate-invariant bridges (ring/conjugate_invariant.go) ------------------------------------
+    def _bridge_chk(self, small, big, who):
+        if big.ring.N != 2 * small.ring.N:
+            raise RingHipError("cannot %s: the ring degree of one operand must be twice the other's (%d, %d)" % (who, small.ring.N, big.ring.N))
+        for p in (small, big):
+            if p.limbs != self.level + 1 or p.npoly != small.npoly:
+                raise RingHipError("%s: dense blocks of level+1 = %d limbs and the same number of polys" % (who, self.level + 1))
+
+    def UnfoldConjugateInvariantToStandard(self, polyConjugateInvariant, polyStandard):
+        """:8-26, receiver = the standard ring of degree 2n: std[j] = ci[j], std[n + k] = ci[n - 1 - k] on every limb"""
+        self._bridge_chk(polyConjugateInvariant, polyStandard, "UnfoldConjugateInvariantToStandard")
+        if polyStandard.ring.N != self.N:
+            raise RingHipError("UnfoldConjugateInvariantToStandard: the receiver is the standard ring of polyStandard")
+        _check(lib().rh_ring_unfold_ci_to_standard(self._h, self.level, polyConjugateInvariant.ptr, polyStandard.ptr, polyStandard.npoly))
+
+    def FoldStandardToConjugateInvariant(self, polyStandard, permuteNTTIndexInv, polyConjugateInvariant):
+        """:31-49, receiver = the conjugate-invariant ring of degree n: ci[j] = CRed(std[index[j]] + std[j]); index: n entries < 2n
+        (the standard ring's AutomorphismNTTIndex of the inverse Galois element, schemes/ckks/bridge.go:48-50)"""
+        self._bridge_chk(polyConjugateInvariant, polyStandard, "FoldStandardToConjugateInvariant")
+        if polyConjugateInvariant.ring.N != self.N:
+            raise RingHipError("FoldStandardToConjugateInvariant: the receiver is the ring of polyConjugateInvariant")
+        if isinstance(permuteNTTIndexInv, DevicePoly):
+            t = permuteNTTIndexInv
+        else:
+            idx = _u64(permuteNTTIndexInv).reshape(-1)[:self.N]
+            if idx.size != self.N or int(idx.max()) >= 2 * self.N:
+                raise RingHipError("FoldStandardToConjugateInvariant: the index table needs N entries below 2N")
+            t = self._index_table(idx)
+        _check(lib().rh_ring_fold_standard_to_ci(self._h, self.level, polyStandard.ptr, t.ptr, polyConjugateInvariant.ptr, polyStandard.npoly))
+
+    def PadDefaultRingToConjugateInvariant(self, polyStandard, IsNTT, polyConjugateInvariant):
+        """:52-80, receiver = a ring of polyStandard's degree n: the first n words of every limb of polyConjugateInvariant (rows of 2n
+        words) as the reference's in-place loop leaves them; words n..2n-1 are not written"""
+        self._bridge_chk(polyStandard, polyConjugateInvariant, "PadDefaultRingToConjugateInvariant")
+        if polyStandard.ring.N != self.N:
+            raise RingHipError("PadDefaultRingToConjugateInvariant: the receiver has polyStandard's degree")
+        _check(lib().rh_ring_pad_default_to_ci(self._h, self.level, polyStandard.ptr, 1 if IsNTT else 0, polyConjugateInvariant.ptr, polyStandard.npoly))
 
     def EvalPolyScalar(self, p1, scalar, p2):
         """:269-275: p2 = p1[0] + p1[1] * scalar + ... by Horner (p1: list of blocks)"""

@@ -151,3 +151,43 @@ def gadget_product_single_p(N, Q, P, levelQ, levelP, cx, is_ntt, pw2, digits_per
                 q = orc.moddown_qp_to_q(q, p, Ql, Pl)
             out.append(q)
     return out
+
+
+# ---- standard <-> conjugate-invariant bridges (ring/conjugate_invariant.go), literal restatements of the reference's loops -------------
+def unfold_ci_to_standard(ci):
+    """UnfoldConjugateInvariantToStandard (:8-26) on one limb: copy, then tmp2[jdx] = tmp1[idx] for idx = N-1 .. 0, jdx = N .. 2N-1"""
+    ci = np.asarray(ci, dtype=np.uint64)
+    N = ci.size
+    out = np.empty(2 * N, dtype=np.uint64)
+    out[:N] = ci
+    idx, jdx = N - 1, N
+    while jdx < 2 * N:
+        out[jdx] = ci[idx]
+        idx, jdx = idx - 1, jdx + 1
+    return out
+
+
+def fold_standard_to_ci(std, index, q):
+    """FoldStandardToConjugateInvariant (:31-49) on one limb: AutomorphismNTTWithIndex over the N outputs (ring/automorphism.go:50-78),
+    then SubRing.Add (addvec: CRed(x + y), ring/vec_ops.go:7-29) with the first N words of the standard poly"""
+    std = np.asarray(std, dtype=np.uint64)
+    N = std.size // 2
+    out = std[np.asarray(index[:N], dtype=np.int64)].copy()
+    return orc.vec_op(OPS["ADD"], out, std[:N].copy(), out, 0, 0, q)
+
+
+def pad_default_to_ci(std, is_ntt, q, ci_before):
+    """PadDefaultRingToConjugateInvariant (:52-80) on one limb, the in-place loop run literally (its second half reads what its first
+    half wrote); ci_before: the 2N words the output limb held (words N..2N-1 are not written)"""
+    std = np.asarray(std, dtype=np.uint64)
+    N = std.size
+    tmp = [int(x) for x in ci_before]
+    tmp[:N] = [int(x) for x in std]
+    if is_ntt:
+        for j in range(N):
+            tmp[N - j - 1] = tmp[j]
+    else:
+        tmp[0] = 0
+        for j in range(1, N):
+            tmp[N - j] = int(q) - tmp[j]
+    return np.array(tmp, dtype=np.uint64)

@@ -58,6 +58,26 @@ int main() {
     s.CopyLvl(p4, p2);
     EXPECT(p2.download() == p4.download());
   }
+  // ring/conjugate_invariant.go: Unfold (:8-26), Fold (:31-49), Pad (:52-80) on n = 8 / 2n = 16, q = 97, by hand
+  {
+    Ring small(8, {97}), big(16, {97});
+    std::vector<uint64_t> c8 = {1, 2, 3, 4, 5, 6, 7, 8}, s16(16);
+    for (int i = 0; i < 16; ++i) s16[i] = (uint64_t)(90 + i) % 97;          // 90..96, 0..8
+    Poly pc = small.NewPoly(), ps = big.NewPoly(), idx = small.NewPoly(), po = small.NewPoly();
+    pc.upload(c8);
+    big.UnfoldConjugateInvariantToStandard(pc, ps);
+    EXPECT((ps.download() == std::vector<uint64_t>{1, 2, 3, 4, 5, 6, 7, 8, 8, 7, 6, 5, 4, 3, 2, 1}));
+    ps.upload(s16);
+    idx.upload(std::vector<uint64_t>{15, 14, 13, 12, 11, 10, 9, 8});
+    small.FoldStandardToConjugateInvariant(ps, idx, po);                     // (s16[15 - j] + s16[j]) mod 97
+    EXPECT((po.download() == std::vector<uint64_t>{(8 + 90) % 97, (7 + 91) % 97, (6 + 92) % 97, (5 + 93) % 97, (4 + 94) % 97, (3 + 95) % 97, (2 + 96) % 97, 1}));
+    small.PadDefaultRingToConjugateInvariant(pc, true, ps);                 // first n words: c[0..3], reversed c[0..3]; the rest untouched
+    std::vector<uint64_t> w = s16; const uint64_t a[8] = {1, 2, 3, 4, 4, 3, 2, 1}; for (int i = 0; i < 8; ++i) w[i] = a[i];
+    EXPECT(ps.download() == w);
+    small.PadDefaultRingToConjugateInvariant(pc, false, ps);                // 0, c1, c2, c3, q - c4, q - c3, q - c2, q - c1
+    const uint64_t b[8] = {0, 2, 3, 4, 97 - 5, 97 - 4, 97 - 3, 97 - 2}; for (int i = 0; i < 8; ++i) w[i] = b[i];
+    EXPECT(ps.download() == w);
+  }
   // 3N-cyclotomic ring, Type::Matrix (ring/ntt_3n.go:21-156, ring/ring.go:299-304): omega handed over like the Go factory
   // does; vectors from references/integer_dft.py in the Go transformer's ascending-totative order
   {
