@@ -40,6 +40,20 @@ __global__ void __launch_bounds__(256) sum16(const ulonglong2* __restrict__ a, c
   for (int k = 0; k < 8; ++k) { ulonglong2 x = a[base + k * 256], y = b[base + k * 256]; s += (x.x ^ y.x) + (x.y ^ y.y); }
   if (s == 0x1234567) c[threadIdx.x] = s;
 }
+// L2-resident reads: every block re-reads its own 32 KiB (x2 buffers) `reps` times; the grid's footprint is 2 x 16 MiB = 4 MiB per XCD
+__global__ void __launch_bounds__(256) sum16_rep(const ulonglong2* a, const ulonglong2* b, u64* c, int reps) {
+  const size_t base = (size_t)blockIdx.x * 2048 + threadIdx.x;
+  u64 s = 0;
+  for (int r = 0; r < reps; ++r) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      ulonglong2 x = a[base + k * 256], y = b[base + k * 256];
+      s += (x.x ^ y.x) + (x.y ^ y.y) + r;
+    }
+    asm volatile("" ::: "memory");                                        // re-read every trip (the 128 KiB a CU's two blocks cycle through do not fit its L1)
+  }
+  if (s == 0x1234567) c[threadIdx.x] = s;
+}
 __global__ void fill(u64* p, size_t n, u64 seed) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = (i + seed) * 0x9E3779B97F4A7C15ull;
 }
@@ -62,14 +76,20 @@ int main(int argc, char** argv) {
       if (mode == 0) add8<<<grid, 256>>>(a, b, c);
       else if (mode == 1) add16<<<grid, 256>>>((const ulonglong2*)a, (const ulonglong2*)b, (ulonglong2*)c);
       else if (mode == 2) sum8<<<grid, 256>>>(a, b, c);
-      else sum16<<<grid, 256>>>((const ulonglong2*)a, (const ulonglong2*)b, c);
+      else if (mode == 3) sum16<<<grid, 256>>>((const ulonglong2*)a, (const ulonglong2*)b, c);
+      else if (mode == 4) sum16_rep<<<512, 256>>>((const ulonglong2*)a, (const ulonglong2*)b, c, 256);       // 512 blocks x 32 KiB x 2 = 32 MiB: L2-resident (4 MiB per XCD)
+      else sum16<<<4096, 256>>>((const ulonglong2*)a, (const ulonglong2*)b, c);                              // 4096 blocks x 32 KiB x 2 = 256 MiB... see below
     }
     CK(hipDeviceSynchronize());
   }
   CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-  const double bytes = (double)words * 8 * (mode < 2 ? 3 : 2) * n;
-  const char* names[] = {"add, 8 B per lane", "add, 16 B per lane", "read-only, 8 B per lane", "read-only, 16 B per lane"};
-  printf("%s: %.0f GB/s over %.1f s\n", names[mode & 3], bytes / (ms * 1e-3) / 1e9, ms * 1e-3);
+  double bytes = (double)words * 8 * (mode < 2 ? 3 : 2) * n;
+  if (mode == 4) bytes = 512.0 * 32768 * 2 * 256 * n;
+  if (mode == 5) bytes = 4096.0 * 32768 * 2 * n;            // 128 MiB per buffer pair half... 2 x 128 MiB re-read every launch: Infinity-Cache-resident
+  const char* names[] = {"add, 8 B per lane", "add, 16 B per lane", "read-only, 8 B per lane", "read-only, 16 B per lane",
+                         "read-only, 16 B per lane, L2-resident (32 MiB footprint, 256 re-reads per launch)",
+                         "read-only, 16 B per lane, 256 MiB footprint re-read every launch (Infinity Cache)"};
+  printf("%s: %.0f GB/s over %.1f s\n", names[mode % 6], bytes / (ms * 1e-3) / 1e9, ms * 1e-3);
   return 0;
 }
