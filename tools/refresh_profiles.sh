@@ -6,13 +6,13 @@ tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
 echo "[1/9] bench"; python3 bench.py > $O/bench.log 2>$O/bench.err; tail -1 $O/bench.log > $O/${tag}_bench.json
-echo "[2/9] kernel trace"; rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 bench.py --no-cpu --no-verify > $O/kt.log 2>&1
+echo "[2/9] kernel trace"; rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 bench.py --no-cpu --no-verify --no-power > $O/kt.log 2>&1
 cp $O/kt/kt_kernel_stats.csv $O/${tag}_kernel_stats.csv
-echo "[3/9] pmc fetch"; rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pf -o f --output-format csv -- python3 bench.py --no-cpu --no-verify --steps 3 --warmup 1 > $O/pf.log 2>&1
-echo "[4/9] pmc write"; rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pw -o w --output-format csv -- python3 bench.py --no-cpu --no-verify --steps 3 --warmup 1 > $O/pw.log 2>&1
+echo "[3/9] pmc fetch"; rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pf -o f --output-format csv -- python3 bench.py --no-cpu --no-verify --no-power --steps 3 --warmup 1 > $O/pf.log 2>&1
+echo "[4/9] pmc write"; rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pw -o w --output-format csv -- python3 bench.py --no-cpu --no-verify --no-power --steps 3 --warmup 1 > $O/pw.log 2>&1
 python3 tools/make_traffic.py $O/pf/f_counter_collection.csv $O/pw/w_counter_collection.csv $O/latest_traffic.json 1024 9 > /dev/null
 for x in f w; do d=$([ $x = f ] && echo pf || echo pw); n=$([ $x = f ] && echo fetch_size || echo write_size); head -1 $O/$d/${x}_counter_collection.csv > $O/${tag}_pmc_${n}.csv; grep ntt_ $O/$d/${x}_counter_collection.csv >> $O/${tag}_pmc_${n}.csv || true; done
-echo "[5/9] pmc sq"; rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -d $O/ps -o s --output-format csv -- python3 bench.py --no-cpu --no-verify --steps 3 --warmup 1 > $O/ps.log 2>&1
+echo "[5/9] pmc sq"; rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -d $O/ps -o s --output-format csv -- python3 bench.py --no-cpu --no-verify --no-power --steps 3 --warmup 1 > $O/ps.log 2>&1
 python3 tools/make_valu.py $O/ps/s_counter_collection.csv $O/latest_valu.json 1024 9 > /dev/null
 python3 tools/pmc_table.py $O/ps > $O/${tag}_pmc_sq_counters.txt
 echo "[6/9] 3N kernels (config 4 ring, reference order and block order)"
