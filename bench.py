@@ -225,18 +225,23 @@ def power_sample(step, dev_index, seconds=1.8):
 
     def smi(*flags):
         try:
-            return subprocess.run([exe, "-d", str(dev_index)] + list(flags), capture_output=True, text=True, timeout=20).stdout
+            return subprocess.run([exe] + list(flags), capture_output=True, text=True, timeout=20).stdout
         except (OSError, subprocess.SubprocessError):
             return ""
     samples, stop = [], threading.Event()
 
     def sampler():
+        # every GPU rocm-smi sees is read and the one drawing the most power is kept: rocm-smi numbers physical devices, which need
+        # not be this process's HIP ordinal (HIP_VISIBLE_DEVICES), and on a shared node the other GPUs idle during an N = 1 run
         time.sleep(0.6 * seconds / 1.8)
         while not stop.is_set() and len(samples) < 3:
             t = smi("--showclocks", "--showpower")
-            c, w = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", t), re.search(r"Power \(W\): ([\d.]+)", t)
-            if c and w:
-                samples.append((int(c.group(1)), float(w.group(1))))
+            clk = {int(g): int(c) for g, c in re.findall(r"GPU\[(\d+)\]\s*: sclk clock level: \S+ \((\d+)Mhz\)", t)}
+            pw = {int(g): float(w) for g, w in re.findall(r"GPU\[(\d+)\]\s*: [^\n]*Power \(W\): ([\d.]+)", t)}
+            both = [g for g in pw if g in clk]
+            if both:
+                g = max(both, key=lambda k: pw[k])
+                samples.append((clk[g], pw[g], g))
     th = threading.Thread(target=sampler)
     th.start()
     t0 = time.perf_counter()
@@ -245,11 +250,12 @@ def power_sample(step, dev_index, seconds=1.8):
             step()
         torch.cuda.synchronize()
     stop.set(); th.join()
-    cap = re.search(r"Max Graphics Package Power \(W\): ([\d.]+)", smi("--showmaxpower"))
     if not samples:
         return None
-    return {"sclk_mhz_under_load": sum(c for c, _ in samples) / len(samples), "package_w_under_load": sum(w for _, w in samples) / len(samples),
-            "package_cap_w": float(cap.group(1)) if cap else None, "sclk_peak_mhz": 2400, "samples": len(samples),
+    gpu = samples[-1][2]
+    cap = re.search(r"GPU\[%d\]\s*: [^\n]*Max Graphics Package Power \(W\): ([\d.]+)" % gpu, smi("--showmaxpower"))
+    return {"sclk_mhz_under_load": sum(c for c, _, _ in samples) / len(samples), "package_w_under_load": sum(w for _, w, _ in samples) / len(samples),
+            "package_cap_w": float(cap.group(1)) if cap else None, "sclk_peak_mhz": 2400, "samples": len(samples), "rocm_smi_gpu": gpu,
             "source": "rocm-smi --showclocks --showpower sampled while the timed step is re-launched for %.1f s after the timed region" % seconds}
 
 
