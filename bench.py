@@ -377,6 +377,14 @@ def run_ntt(args):
         # the package power cap, not a pipeline, sets the clock this kernel runs at: both ceilings above are
         # quoted at the 2.4 GHz the chip holds for pure VALU streams; at the clock measured under THIS kernel they scale by sclk / 2400
         roof["power"] = power
+        if traffic is not None and "valu" in roof and power.get("package_cap_w"):
+            # energy floor of this design at the cap (constants measured on this chip, profiles/r02_mem_power_l2_mall.txt,
+            # profiles/r02_power_clock_samples.txt): HBM-path traffic 0.137 nJ per byte, a VALU wave-instruction of this mix ~1.1 nJ,
+            # 291 W drawn idle; (traffic + arithmetic energy) / (cap - idle) = the time the cap allows for one step
+            e_mem, e_valu, idle_w = traffic * 0.137e-9, roof["valu"]["wave_instructions_per_step"] * 1.1e-9, 291.0
+            floor_ms = (e_mem + e_valu) / (power["package_cap_w"] - idle_w) * 1e3
+            roof["power"]["energy_model"] = {"traffic_J_per_step": e_mem, "valu_J_per_step": e_valu, "idle_w": idle_w,
+                                             "floor_ms_per_step_at_cap": floor_ms, "frac_of_floor": floor_ms / launch_ms}
         if "valu" in roof:
             k = power["sclk_mhz_under_load"] / power["sclk_peak_mhz"]
             roof["valu"]["issue_peak_at_measured_clock_Gwinstr_per_s"] = roof["valu"]["issue_peak_Gwinstr_per_s"] * k
