@@ -6,6 +6,8 @@ launch-shape thresholds of the engine (one launch pair / pipelined spans of ~204
 limbs than the view (ring/ring.go:192-213: different row strides on the two sides), in place and out of place, every ring type
 -- and checks drawn (poly, limb) rows bit for bit, and that rows above the view's level are not touched.  Every case is derived
 from the case number, so a failure names a reproducible shape."""
+import os
+
 import numpy as np
 import pytest
 
@@ -15,6 +17,7 @@ from test_oracle_ntt3n import find_prime_3n, omega_for
 pytestmark = pytest.mark.gpu
 
 SENTINEL = np.uint64(0xDEADBEEFCAFEF00D)
+SCALE = int(os.environ.get("RH_FUZZ_SCALE", "1"))              # RH_FUZZ_SCALE=10: ten times the cases (a longer hunt on the GPU box)
 
 
 def _draw_shape(rng, max_rows):
@@ -42,7 +45,7 @@ def _spots(rng, B, level, n=4):
     return sorted(s)
 
 
-@pytest.mark.parametrize("case", range(96))
+@pytest.mark.parametrize("case", range(96 * SCALE))
 def test_fuzz_standard_ntt_family(rh, oracle, case):
     """Ring.NTT / NTTLazy / INTT / INTTLazy (ring/ntt.go:127-152) through AtLevel views"""
     rng = np.random.default_rng(7000 + case)
@@ -79,7 +82,7 @@ def test_fuzz_standard_ntt_family(rh, oracle, case):
     ring.close()
 
 
-@pytest.mark.parametrize("case", range(30))
+@pytest.mark.parametrize("case", range(30 * SCALE))
 def test_fuzz_vec_ops_at_level(rh, oracle, case):
     """one drawn element-wise kernel of ring/vec_ops.go through an AtLevel view with per-operand row strides (ring/operations.go)"""
     rng = np.random.default_rng(8000 + case)
@@ -113,7 +116,7 @@ def test_fuzz_vec_ops_at_level(rh, oracle, case):
     ring.close()
 
 
-@pytest.mark.parametrize("case", range(12))
+@pytest.mark.parametrize("case", range(12 * SCALE))
 def test_fuzz_conjugate_invariant_and_3n(rh, oracle, case):
     """the other two ring types through the same batched entry points (ring/ntt.go:80-124, ring/ntt_3n.go:82-156)"""
     rng = np.random.default_rng(9000 + case)
@@ -157,7 +160,7 @@ def test_fuzz_conjugate_invariant_and_3n(rh, oracle, case):
     ring.close()
 
 
-@pytest.mark.parametrize("case", range(10))
+@pytest.mark.parametrize("case", range(10 * SCALE))
 def test_fuzz_basis_extension_levels(rh, oracle, case):
     """ModUpQtoP / ModUpPtoQ / ModDownQPtoQ at drawn (levelQ, levelP) of a larger extender (ring/basis_extension.go:188-234): the
     constants of EVERY source level are the extender's own tables; unreduced outputs compared word for word"""
@@ -198,3 +201,84 @@ def test_fuzz_basis_extension_levels(rh, oracle, case):
             exp = oracle.moddown_qp_to_q(xq[k], xp[k], Q[:levelQ + 1], P[:levelP + 1])
             assert np.array_equal(got[k], exp), ctx + " ModDownQPtoQ poly %d" % k
     be.close(); rq.close(); rp.close()
+
+
+@pytest.mark.parametrize("case", range(16 * SCALE))
+def test_fuzz_gadget_product_shapes(rh, oracle, case):
+    """rlwe.Evaluator.GadgetProduct, hybrid branch (core/rlwe/evaluator_gadget_product.go:16-188): drawn chain lengths, levels (incl.
+    last digits of a single prime and levelP below the extender's), degrees either side of the kernel-shape thresholds, small batches"""
+    from oracle import compose
+    rng = np.random.default_rng(9700 + case)
+    logN = int(rng.choice([6, 11, 12, 13, 14, 15]))
+    N = 1 << logN
+    nq, npm = int(rng.integers(2, 11)), int(rng.integers(2, 5))
+    levelQ, levelP = int(rng.integers(0, nq)), int(rng.integers(1, npm))
+    if case % 4 == 0:
+        levelQ, levelP = nq - 1, npm - 1
+    Q, P = QI60[:nq], PI60[:npm]
+    beta = -(-(levelQ + 1) // (levelP + 1))                                  # ceil((levelQ + 1) / (levelP + 1)) digits in play
+    beta_key = max(beta, (nq - 1 + npm) // npm)
+    B = int(rng.choice([1, 2, 3]))
+    LQ = levelQ + 1
+    cx = np.stack([np.stack([uniform_mod(rng, q, N) for q in Q[:LQ]]) for _ in range(B)])
+    key = lambda mods: np.stack([np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(2)]) for _ in range(beta_key)])
+    evkQ, evkP = key(Q), key(P)
+    rq, rp = rh.Ring(N, Q), rh.Ring(N, P)
+    be = rh.BasisExtender(rq, rp)
+    pcx = rh.DevicePoly.from_numpy(rq.AtLevel(levelQ), cx)
+    dq = rh.DevicePoly.from_numpy(rq, evkQ.reshape(beta_key * 2, nq, N))
+    dp = rh.DevicePoly.from_numpy(rp, evkP.reshape(beta_key * 2, npm, N))
+    ct0, ct1 = rh.DevicePoly(rq, B, LQ), rh.DevicePoly(rq, B, LQ)
+    be.GadgetProduct(levelQ, levelP, pcx, dq.ptr, dp.ptr, beta_key, ct0, ct1)
+    g0, g1 = ct0.numpy(), ct1.numpy()
+    ctx = "case %d: N=2^%d Q=%d P=%d levelQ=%d levelP=%d beta_key=%d B=%d" % (case, logN, nq, npm, levelQ, levelP, beta_key, B)
+    for k in {0, B - 1}:
+        e0, e1 = compose.gadget_product(N, Q, P, levelQ, levelP, cx[k], evkQ, evkP)
+        assert np.array_equal(g0[k], e0) and np.array_equal(g1[k], e1), ctx + " poly %d" % k
+    assert np.array_equal(pcx.numpy(), cx), ctx + ": input modified"
+    be.close(); rq.close(); rp.close()
+
+
+@pytest.mark.parametrize("case", range(16 * SCALE))
+def test_fuzz_rescale_and_automorphism(rh, oracle, case):
+    """DivFloor / DivRoundByLastModulusMany(NTT) (ring/scaling.go) with a drawn number of rescales, and AutomorphismNTT / Automorphism
+    (ring/automorphism.go) with a drawn Galois element, on drawn degrees / limb counts / batches"""
+    rng = np.random.default_rng(9800 + case)
+    logN = int(rng.choice([4, 8, 12, 13, 14, 15, 16]))
+    N = 1 << logN
+    L = int(rng.integers(2, 9))
+    B = int(rng.choice([1, 2, 5, 40])) if logN <= 14 else int(rng.choice([1, 3]))
+    Q = QI60[:L]
+    ring = rh.Ring(N, Q)
+    a = _block(rng, Q, B, L, N, L - 1)
+    ctx = "case %d: N=2^%d L=%d B=%d" % (case, logN, L, B)
+    if case % 2 == 0:
+        nb, round_ = int(rng.integers(1, min(L, 4))), int(rng.integers(0, 2))
+        p0, p1 = rh.DevicePoly.from_numpy(ring, a), rh.DevicePoly(ring, B, L - nb)
+        (ring.DivRoundByLastModulusMany if round_ else ring.DivFloorByLastModulusMany)(nb, p0, p1)
+        got = p1.numpy()
+        for k in {0, B - 1}:
+            assert np.array_equal(got[k], oracle.div_by_last_modulus_many(a[k], Q, nb, round_)), ctx + " nb=%d round=%d poly %d" % (nb, round_, k)
+        # NTT domain: the same division seen through the transform
+        pn = rh.DevicePoly.from_numpy(ring, a)
+        ring.NTT(pn, pn)
+        po = rh.DevicePoly.from_numpy(ring, np.full((B, L, N), SENTINEL, dtype=np.uint64))
+        (ring.DivRoundByLastModulusManyNTT if round_ else ring.DivFloorByLastModulusManyNTT)(nb, pn, po)
+        out = po.numpy()
+        assert (out[:, L - nb:] == SENTINEL).all(), ctx + ": limbs above the new level were written"
+        sub = ring.AtLevel(L - nb - 1)
+        chk = rh.DevicePoly.from_numpy(sub, out[:, :L - nb].copy())
+        sub.INTT(chk, chk)
+        assert np.array_equal(chk.numpy(), got), ctx + " nb=%d round=%d NTT domain" % (nb, round_)
+    else:
+        gen = int(rng.integers(0, N)) * 2 + 1
+        pin, pout = rh.DevicePoly.from_numpy(ring, a), ring.NewPoly(B)
+        ring.AutomorphismNTT(pin, gen, pout)
+        got = pout.numpy()
+        for (k, i) in _spots(rng, B, L - 1, n=2):
+            assert np.array_equal(got[k, i], oracle.automorphism_ntt(a[k, i], gen)), ctx + " AutomorphismNTT gen=%d row (%d, %d)" % (gen, k, i)
+        ring.Automorphism(pin, gen, pout)
+        got = pout.numpy()
+        for (k, i) in _spots(rng, B, L - 1, n=2):
+            assert np.array_equal(got[k, i], oracle.automorphism(a[k, i], gen, Q[i])), ctx + " Automorphism gen=%d row (%d, %d)" % (gen, k, i)
+    ring.close()
