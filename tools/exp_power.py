@@ -61,6 +61,10 @@ def main():
     c0, c1 = torch.zeros_like(xq), torch.zeros_like(xq)
     pq, p0, p1 = (rh.DevicePoly.from_torch(rq, t) for t in (xq, c0, c1))
     work["GadgetProduct, batch 64 (config 5)"] = lambda: be.GadgetProduct(23, 5, pq, evq.data_ptr(), evp.data_ptr(), 4, p0, p1)
+    xp = rb(64, PI60[:6]); oq, op_ = torch.zeros_like(xq), torch.zeros_like(xp)
+    pp, poq, pop = rh.DevicePoly.from_torch(rp, xp), rh.DevicePoly.from_torch(rq, oq), rh.DevicePoly.from_torch(rp, op_)
+    work["DecomposeAndSplit, one digit, batch 64 (bext_kernel<6>)"] = lambda: be.DecomposeAndSplit(23, 5, 6, 1, pq, poq, pop)
+    work["ModUpPtoQ 6 -> 24 limbs, batch 64"] = lambda: be.ModUpPtoQ(5, 23, pp, poq)
     half = rh.DevicePoly.from_torch(ring, data[:512])
     resc = rh.DevicePoly.from_torch(ring.AtLevel(L - 2), torch.empty((512, L - 1, N), dtype=torch.int64, device=dev))
     work["DivRoundByLastModulusNTT, 512 polys"] = lambda: ring.DivRoundByLastModulusNTT(half, resc)
