@@ -10,3 +10,4 @@ from .ringhip import (  # noqa: F401
 from .schemes import Ciphertext, MatrixCKKSEvaluator, ckks_tensor_degree1, ckks_polymul  # noqa: F401,E402
 from . import rlwe  # noqa: F401,E402
 from . import ckks  # noqa: F401,E402
+from . import rgsw  # noqa: F401,E402

@@ -191,3 +191,49 @@ def pad_default_to_ci(std, is_ntt, q, ci_before):
         for j in range(1, N):
             tmp[N - j] = int(q) - tmp[j]
     return np.array(tmp, dtype=np.uint64)
+
+
+def external_product(N, Q, P, levelQ, levelP, ct, is_ntt, rgswQ, rgswP):
+    """rgsw.Evaluator.ExternalProduct, LevelP >= 1 (core/rgsw/evaluator.go:42-80 -> externalProductInPlaceMultipleP :188-257 -> ModDownQPtoQNTT):
+    ONE pair of lazy accumulators over both components k of the RLWE ciphertext and every digit i, the Reduce counter running through
+    (:229-241), the closing Reduce (:245-253).  ct: (2, levelQ+1, N) in the NTT domain (is_ntt) or the coefficient domain (:208-216);
+    rgswQ / rgswP: (2, digits, 2, len(Q) / len(P), N) = rgsw.Value[k].Value[i][0][c].{Q, P}.  Returns (out0, out1), NTT domain."""
+    LQ, LP = levelQ + 1, levelP + 1
+    Ql, Pl = Q[:LQ], P[:LP]
+    srQ = [orc.SubRingConsts(N, q) for q in Ql]
+    srP = [orc.SubRingConsts(N, p) for p in Pl]
+    beta = (levelQ + levelP + 1) // (levelP + 1)
+    qiof = int(2.0 ** 64 / float(max(Ql))) >> 1
+    piof = int(2.0 ** 64 / float(max(Pl))) >> 1
+    acc = {}
+    reduce = 0
+    for k in (0, 1):
+        if is_ntt:
+            c2ntt = ct[k]
+            c2inv = np.stack([orc.intt(ct[k][i], srQ[i]) for i in range(LQ)])
+        else:
+            c2inv = ct[k]
+            c2ntt = np.stack([orc.ntt(ct[k][i], srQ[i]) for i in range(LQ)])
+        for d in range(beta):
+            c2q, c2p = orc.decompose_and_split(levelQ, levelP, LP, d, c2inv, Q, P)
+            st, ed = d * LP, min(d * LP + LP, LQ)
+            c2q = np.stack([c2ntt[i] if st <= i < ed else orc.ntt(c2q[i], srQ[i]) for i in range(LQ)])
+            c2p = np.stack([orc.ntt(c2p[j], srP[j]) for j in range(LP)])
+            first = k == 0 and d == 0
+            for c in (0, 1):
+                acc[("Q", c)] = _mac(acc.get(("Q", c)), rgswQ[k][d][c], c2q, Ql, first)
+                acc[("P", c)] = _mac(acc.get(("P", c)), rgswP[k][d][c], c2p, Pl, first)
+            if reduce % qiof == qiof - 1:
+                for c in (0, 1):
+                    acc[("Q", c)] = _reduce(acc[("Q", c)], Ql)
+            if reduce % piof == piof - 1:
+                for c in (0, 1):
+                    acc[("P", c)] = _reduce(acc[("P", c)], Pl)
+            reduce += 1
+    if reduce % qiof:
+        for c in (0, 1):
+            acc[("Q", c)] = _reduce(acc[("Q", c)], Ql)
+    if reduce % piof:
+        for c in (0, 1):
+            acc[("P", c)] = _reduce(acc[("P", c)], Pl)
+    return [orc.moddown_qp_to_q_ntt(acc[("Q", c)], acc[("P", c)], Ql, Pl, srQ, srP) for c in (0, 1)]
