@@ -548,6 +548,48 @@ class Ring:
             src = self.NewPoly(p1.npoly); self.CopyLvl(p1, src)
         _check(lib().rh_ring_mult_by_monomial(self._h, self.level, src.ptr, p2.ptr, int(k), p1.npoly))
 
+    # ---- big-integer converters and Equal (ring/ring.go:433-558): host-side in the reference too (math/big) -----------
+    def SetCoefficientsBigint(self, coeffs, p1, poly=0):
+        """:433-447: limb i of poly `poly` of the block gets coeff mod q_i (Go's big.Int.Mod: the non-negative residue) for the
+        first len(coeffs) coefficients; the others and the other polys of the block keep what they hold"""
+        coeffs = [int(c) for c in coeffs]
+        if len(coeffs) > self.N:
+            raise RingHipError("SetCoefficientsBigint: %d coefficients for a ring of degree %d" % (len(coeffs), self.N))
+        host = p1.numpy()
+        for i in range(self.level + 1):
+            q = int(self.moduli[i])
+            host[poly, i, :len(coeffs)] = np.array([c % q for c in coeffs], dtype=np.uint64)
+        _check(lib().rh_dev_upload(self._h, p1.ptr, _p(host), host.size))
+
+    def _crt(self):
+        mods = [int(q) for q in self.moduli[:self.level + 1]]
+        Q = 1
+        for q in mods:
+            Q *= q
+        return mods, Q, [(Q // q) * pow(Q // q, -1, q) for q in mods]
+
+    def PolyToBigint(self, p1, gap=1, poly=0):
+        """:467-496: CRT reconstruction of coefficients 0, gap, 2 gap, ... of poly `poly` modulo Q_level, as Python integers"""
+        mods, Q, crt = self._crt()
+        host = p1.numpy()[poly]
+        return [sum(int(host[k, j]) * crt[k] for k in range(len(mods))) % Q for j in range(0, self.N, gap)]
+
+    def PolyToBigintCentered(self, p1, gap=1, poly=0):
+        """:503-543: the same, centred: values >= floor(Q/2) have Q subtracted"""
+        mods, Q, crt = self._crt()
+        half = Q >> 1
+        return [v - Q if v >= half else v for v in self.PolyToBigint(p1, gap, poly)]
+
+    def Equal(self, p1, p2):
+        """:546-558: Reduce both operands IN PLACE (as the reference does), then compare limbs 0..level"""
+        self._chk(p1, p2, rows_ok=True)
+        if p1.npoly != p2.npoly:
+            return False
+        self.Reduce(p1, p1)
+        self.Reduce(p2, p2)
+        a, b = p1.numpy(), p2.numpy()
+        return bool(np.array_equal(a[:, :self.level + 1], b[:, :self.level + 1]))
+
     # ---- standard <-> conjugate-invariant bridges (ring/conjugate_invariant.go) ------------------------------------
     def _bridge_chk(self, small, big, who):
         if big.ring.N != 2 * small.ring.N:

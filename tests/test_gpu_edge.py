@@ -120,3 +120,39 @@ def test_thirty_two_limbs_and_widest_basis_extension(rh, oracle):
     for k in range(B):
         assert np.array_equal(outp.numpy()[k], oracle.modup_centered(a[k, :12], Q[:12], P))
     be.close(); rq.close(); rp.close()
+
+
+def test_bigint_converters_and_equal(rh):
+    """ring/ring.go:433-558 (SetCoefficientsBigint, PolyToBigint, PolyToBigintCentered, Equal): host-side big-integer converters around
+    device blocks; the method of ring/ring_test.go:186-240 -- set, transform there and back, reconstruct, compare with the integers"""
+    N, mods = 64, QI60[:3]
+    ring = rh.Ring(N, mods)
+    Q = 1
+    for q in mods:
+        Q *= int(q)
+    rng = np.random.default_rng(3)
+    vals = [int.from_bytes(rng.bytes(24), "little") % Q - Q // 2 for _ in range(N)]             # signed, up to |Q|/2
+    p = ring.NewPoly(2)
+    ring.SetCoefficientsBigint(vals, p, poly=1)
+    host = p.numpy()
+    for i, q in enumerate(mods):
+        assert [int(x) for x in host[1, i]] == [v % int(q) for v in vals]
+    ring.NTT(p, p); ring.INTT(p, p)
+    assert ring.PolyToBigint(p, poly=1) == [v % Q for v in vals]
+    assert ring.PolyToBigint(p, gap=4, poly=1) == [v % Q for v in vals[::4]]
+    cen = ring.PolyToBigintCentered(p, poly=1)
+    assert cen == [(v % Q) - Q if (v % Q) >= Q >> 1 else v % Q for v in vals]
+    # at a lower level the reconstruction is modulo the shorter chain
+    v1 = ring.AtLevel(1)
+    q01 = int(mods[0]) * int(mods[1])
+    p1 = rh.DevicePoly.from_numpy(v1, host[1:2, :2].copy())
+    assert v1.PolyToBigint(p1) == [v % q01 for v in vals]
+    # Equal reduces in place first: a lazy representative equals its canonical one
+    host[0] = host[1][:, ::-1]                                       # poly 0 was never written: give it canonical content
+    a = rh.DevicePoly.from_numpy(ring, host)
+    lazy = host.copy(); lazy[:, 0] += np.uint64(mods[0])
+    b = rh.DevicePoly.from_numpy(ring, lazy)
+    assert ring.Equal(a, b) and np.array_equal(b.numpy(), host)
+    lazy[0, 2, 5] ^= np.uint64(1)
+    assert not ring.Equal(a, rh.DevicePoly.from_numpy(ring, lazy))
+    ring.close()
