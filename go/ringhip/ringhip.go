@@ -446,6 +446,28 @@ func (k *KeySwitcher) ModDownPair(levelQ, levelP int, ctQ0, ctQ1, ctP0, ctP1, ct
 	k.q.must(C.rh_bext_moddown_qp_to_q_ntt_pair(k.be, C.int(levelQ), C.int(levelP), ctQ0.ptr, ctQ1.ptr, ctP0.ptr, ctP1.ptr, ct0.ptr, ct1.ptr, C.int(ct0.npoly)))
 }
 
+// ExternalProduct mirrors rgsw.Evaluator.ExternalProduct for RGSW ciphertexts with LevelP >= 1 and an NTT-domain RLWE ciphertext
+// (core/rgsw/evaluator.go:42-80, 188-257): the two lazy gadget products of (c0, c1) against rgsw.Value[0] and rgsw.Value[1] are added
+// modulo Q and modulo P (every Reduce of the reference's single accumulator pair is canonical, so the sum of the two canonical lazy products
+// is the same residue) and brought down by one ModDown.  decQ / decP: scratch for the decomposition (beta * npoly polys); acc: four Q blocks
+// and four P blocks of npoly polys (component 0 / 1 of the two products).
+func (k *KeySwitcher) ExternalProduct(levelQ, levelP int, c0, c1 *DevPoly, rgsw0Q, rgsw0P, rgsw1Q, rgsw1P *DevPoly, beta int,
+	decQ, decP *DevPoly, accQ, accP [4]*DevPoly, out0, out1 *DevPoly) {
+	for i, c := range [2]*DevPoly{c0, c1} {
+		evQ, evP := rgsw0Q, rgsw0P
+		if i == 1 {
+			evQ, evP = rgsw1Q, rgsw1P
+		}
+		k.DecomposeNTT(levelQ, levelP, c, true, decQ, decP)
+		k.GadgetProductHoistedLazy(levelQ, levelP, decQ, decP, evQ, evP, beta, accQ[2*i], accQ[2*i+1], accP[2*i], accP[2*i+1])
+	}
+	for c := 0; c < 2; c++ {
+		k.q.VecOp(C.RH_OP_ADD, accQ[c], accQ[2+c], accQ[c], nil, nil)
+		k.p.VecOp(C.RH_OP_ADD, accP[c], accP[2+c], accP[c], nil, nil)
+	}
+	k.ModDownPair(levelQ, levelP, accQ[0], accQ[1], accP[0], accP[1], out0, out1)
+}
+
 // ModDownQPtoQNTT mirrors ring.BasisExtender.ModDownQPtoQNTT (ring/basis_extension.go:241-258).
 func (k *KeySwitcher) ModDownQPtoQNTT(levelQ, levelP int, p1Q, p1P, p2Q *DevPoly) {
 	k.q.must(C.rh_bext_moddown_qp_to_q_ntt(k.be, C.int(levelQ), C.int(levelP), p1Q.ptr, p1P.ptr, p2Q.ptr, C.int(p1Q.npoly)))
