@@ -278,6 +278,13 @@ int rh_bext_gadget_product_coeff(rh_bext* be, int levelQ, int levelP, const uint
 int rh_bext_gadget_product_single_p(rh_bext* be, int levelQ, int levelP, const uint64_t* cx_dev, int cx_is_ntt, int pw2,
                                     const int* digits_per_limb, const uint64_t* evkQ_dev, const uint64_t* evkP_dev, int key_rows,
                                     uint64_t* ct0_dev, uint64_t* ct1_dev, int npoly);
+/* The same WITHOUT the closing ModDown / CopyLvl (the accumulators after the closing Reduce: canonical residues modulo Q in ctQ0 / ctQ1 and,
+ * for levelP = 0, modulo P in ctP0 / ctP1; NTT domain), for callers that sum several products under one ModDown: rgsw's external product.
+ * raw_limb_digits != 0: the digit form of externalProductInPlaceSinglePAndBitDecomp (core/rgsw/evaluator.go:119-186) -- MaskVec of limb i
+ * under every modulus even when pw2 = 0 (mask = all ones), where rlwe's routine calls DecomposeAndSplit. */
+int rh_bext_gadget_product_single_p_lazy(rh_bext* be, int levelQ, int levelP, const uint64_t* cx_dev, int cx_is_ntt, int pw2,
+                                         const int* digits_per_limb, const uint64_t* evkQ_dev, const uint64_t* evkP_dev, int key_rows,
+                                         int raw_limb_digits, uint64_t* ctQ0_dev, uint64_t* ctQ1_dev, uint64_t* ctP0_dev, uint64_t* ctP1_dev, int npoly);
 
 /* Hoisted form (rotations of one ciphertext share the decomposition).  Evaluator.DecomposeNTT
  * (core/rlwe/evaluator_gadget_product.go:431-453): c2 (levelQ+1 limbs, NTT or coefficient domain per c2_is_ntt) ->

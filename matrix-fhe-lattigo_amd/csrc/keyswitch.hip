@@ -382,9 +382,27 @@ static int reduce_pair(rh_ring* R, int L, u64* a0, u64* a1, int npoly) {
   if (int rc = rh_vec_launch(R, RH_OP_REDUCE, a0, nullptr, a0, npoly, L, 0, nullptr, nullptr)) return rc;
   return rh_vec_launch(R, RH_OP_REDUCE, a1, nullptr, a1, npoly, L, 0, nullptr, nullptr);
 }
+// lazy = false: the whole product (ModDown / CopyLvl at the end, ctP0 / ctP1 unused);  lazy = true: stop after the closing Reduce, the
+// accumulators modulo Q in ct0 / ct1 and modulo P in ctP0 / ctP1 (canonical residues, NTT domain).  raw_limb_digits: the digits of
+// rgsw's externalProductInPlaceSinglePAndBitDecomp (core/rgsw/evaluator.go:119-186): MaskVec of limb i even without a power-of-two
+// decomposition (mask = all ones: the limb's own residues under every modulus, no DecomposeAndSplit).
+static int single_p_core(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, int cx_is_ntt, int pw2,
+                         const int* digits_per_limb, const uint64_t* evkQ, const uint64_t* evkP, int key_rows,
+                         uint64_t* ct0, uint64_t* ct1, int npoly, bool lazy, bool raw_limb_digits, uint64_t* ctP0, uint64_t* ctP1);
 extern "C" int rh_bext_gadget_product_single_p(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, int cx_is_ntt, int pw2,
                                                const int* digits_per_limb, const uint64_t* evkQ, const uint64_t* evkP, int key_rows,
                                                uint64_t* ct0, uint64_t* ct1, int npoly) {
+  return single_p_core(be, levelQ, levelP, cx, cx_is_ntt, pw2, digits_per_limb, evkQ, evkP, key_rows, ct0, ct1, npoly, false, false, nullptr, nullptr);
+}
+extern "C" int rh_bext_gadget_product_single_p_lazy(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, int cx_is_ntt, int pw2,
+                                                    const int* digits_per_limb, const uint64_t* evkQ, const uint64_t* evkP, int key_rows,
+                                                    int raw_limb_digits, uint64_t* ctQ0, uint64_t* ctQ1, uint64_t* ctP0, uint64_t* ctP1, int npoly) {
+  if (levelP == 0 && (!ctP0 || !ctP1)) return rh_fail(RH_ERR_ARG, "gadget_product_single_p_lazy: levelP = 0 needs the P accumulators");
+  return single_p_core(be, levelQ, levelP, cx, cx_is_ntt, pw2, digits_per_limb, evkQ, evkP, key_rows, ctQ0, ctQ1, npoly, true, raw_limb_digits != 0, ctP0, ctP1);
+}
+static int single_p_core(rh_bext* be, int levelQ, int levelP, const uint64_t* cx, int cx_is_ntt, int pw2,
+                         const int* digits_per_limb, const uint64_t* evkQ, const uint64_t* evkP, int key_rows,
+                         uint64_t* ct0, uint64_t* ct1, int npoly, bool lazy, bool raw_limb_digits, uint64_t* ctP0, uint64_t* ctP1) {
   if (!be || !cx || !evkQ || !ct0 || !ct1) return rh_fail(RH_ERR_ARG, "gadget_product_single_p: null argument");
   RhBextGuard guard(be);
   rh_ring* RQ = rh_bext_ringQ(be); rh_ring* RP = rh_bext_ringP(be);
@@ -395,7 +413,7 @@ extern "C" int rh_bext_gadget_product_single_p(rh_bext* be, int levelQ, int leve
   if (pw2 < 0 || pw2 > 63 || (pw2 > 0 && !digits_per_limb)) return rh_fail(RH_ERR_ARG, "gadget_product_single_p: bad BaseTwoDecomposition");
   // pw2 == 0 without a P modulus: the reference calls DecomposeAndSplit with nbPi = levelP + 1 = 0, which degenerates (every digit
   // reads limb 0); such gadget ciphertexts are built with a power-of-two decomposition (core/rlwe/params.go:615-633)
-  if (pw2 == 0 && levelP < 0) return rh_fail(RH_ERR_UNSUPPORTED, "gadget_product_single_p: no P modulus needs BaseTwoDecomposition > 0");
+  if (pw2 == 0 && levelP < 0 && !raw_limb_digits) return rh_fail(RH_ERR_UNSUPPORTED, "gadget_product_single_p: no P modulus needs BaseTwoDecomposition > 0");
   if (npoly <= 0) return RH_OK;
   (void)hipSetDevice(RQ->device);
   (void)hipGetLastError();
@@ -406,7 +424,13 @@ extern "C" int rh_bext_gadget_product_single_p(rh_bext* be, int levelQ, int leve
   if (key_rows < rows_needed) return rh_fail(RH_ERR_ARG, "gadget_product_single_p: key has %d rows, level needs %d", key_rows, rows_needed);
   u64 *cxInvBuf, *c2Q, *c2P = nullptr, *aP0 = nullptr, *aP1 = nullptr;
   if (int rc = rh_bext_scratch(be, 3, wq, &c2Q)) return rc;
-  if (LP) { if (int rc = rh_bext_scratch(be, 4, wp, &c2P)) return rc; if (int rc = rh_bext_scratch(be, 5, 2 * wp, &aP0)) return rc; aP1 = aP0 + wp; }
+  if (LP) {
+    if (int rc = rh_bext_scratch(be, 4, wp, &c2P)) return rc;
+    if (lazy) { aP0 = ctP0; aP1 = ctP1; }
+    else { if (int rc = rh_bext_scratch(be, 5, 2 * wp, &aP0)) return rc; aP1 = aP0 + wp; }
+  }
+  const bool maskform = pw2 != 0 || raw_limb_digits;                  // digits by MaskVec of the limb (rlwe with pw2 > 0; rgsw always)
+  const u64 mask_all = ~(u64)0;
   const u64* cxInv = cx;
   if (cx_is_ntt) {
     if (int rc = rh_bext_scratch(be, 2, wq, &cxInvBuf)) return rc;
@@ -421,13 +445,13 @@ extern "C" int rh_bext_gadget_product_single_p(rh_bext* be, int levelQ, int leve
   int e = 0, reduce = 0;
   for (int i = 0; i < LQ; ++i) {
     const int nd = pw2 ? digits_per_limb[i] : 1;
-    if (!pw2) if (int rc = rh_bext_decompose_and_split(be, levelQ, levelP, LP, i, cxInv, c2Q, c2P, npoly)) return rc;   // (:243-245)
+    if (!maskform) if (int rc = rh_bext_decompose_and_split(be, levelQ, levelP, LP, i, cxInv, c2Q, c2P, npoly)) return rc;   // (:243-245)
     for (int j = 0; j < nd; ++j, ++e) {
-      if (pw2) {
-        mask_broadcast_kernel<<<grid, 256, 0, rh_stream(RQ)>>>(cxInv, LQ, i, j * pw2, mask, c2Q, LQ, c2P, LP, N);          // (:249-252)
+      if (maskform) {
+        mask_broadcast_kernel<<<grid, 256, 0, rh_stream(RQ)>>>(cxInv, LQ, i, j * pw2, pw2 ? mask : mask_all, c2Q, LQ, c2P, LP, N);   // (:249-252)
         if (hipGetLastError() != hipSuccess) return rh_fail(RH_ERR_DEVICE, "mask_broadcast_kernel launch failed");
       }
-      if (pw2 || j == 0) {                                             // s.NTTLazy under every modulus (:258-262, :285-289)
+      if (maskform || j == 0) {                                        // s.NTTLazy under every modulus (:258-262, :285-289)
         if (int rc = rh_ring_ntt_any(RQ, c2Q, c2Q, npoly, LQ, 0, false)) return rc;
         if (LP) if (int rc = rh_ring_ntt_any(RP, c2P, c2P, npoly, LP, 0, false)) return rc;
       }
@@ -440,6 +464,7 @@ extern "C" int rh_bext_gadget_product_single_p(rh_bext* be, int levelQ, int leve
   }
   if (reduce % QiOverF != 0) if (int rc = reduce_pair(RQ, LQ, ct0, ct1, npoly)) return rc;
   if (LP && reduce % PiOverF != 0) if (int rc = reduce_pair(RP, LP, aP0, aP1, npoly)) return rc;
+  if (lazy) return RH_OK;
   if (cx_is_ntt) {
     if (!LP) return RH_OK;                                             // levelP = -1, NTT -> NTT: CopyLvl (:72-75)
     return rh_bext_moddown_ntt_pair(be, levelQ, levelP, ct0, ct1, aP0, ct0, ct1, npoly, nullptr, nullptr);

@@ -114,6 +114,7 @@ def lib():
         "rh_bext_gadget_product_then_add": (i, [vp, i, i, vp, vp, vp, i, vp, vp, vp, vp, i]),
         "rh_bext_gadget_product_coeff": (i, [vp, i, i, vp, vp, vp, i, vp, vp, i]),
         "rh_bext_gadget_product_single_p": (i, [vp, i, i, vp, i, i, C.POINTER(i), vp, vp, i, vp, vp, i]),
+        "rh_bext_gadget_product_single_p_lazy": (i, [vp, i, i, vp, i, i, C.POINTER(i), vp, vp, i, i, vp, vp, vp, vp, i]),
         "rh_bext_decompose_ntt": (i, [vp, i, i, vp, i, vp, vp, i]),
         "rh_bext_gadget_product_hoisted": (i, [vp, i, i, vp, vp, vp, vp, i, vp, vp, i]),
         "rh_bext_gadget_product_hoisted_lazy": (i, [vp, i, i, vp, vp, vp, vp, i, vp, vp, vp, vp, i]),

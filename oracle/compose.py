@@ -237,3 +237,36 @@ def external_product(N, Q, P, levelQ, levelP, ct, is_ntt, rgswQ, rgswP):
         for c in (0, 1):
             acc[("P", c)] = _reduce(acc[("P", c)], Pl)
     return [orc.moddown_qp_to_q_ntt(acc[("Q", c)], acc[("P", c)], Ql, Pl, srQ, srP) for c in (0, 1)]
+
+
+def external_product_single_p(N, Q, P, levelQ, levelP, ct, pw2, digits_per_limb, rgswQ, rgswP):
+    """rgsw.Evaluator.ExternalProduct for LevelP in {0, -1} (core/rgsw/evaluator.go:55-70): externalProductInPlaceSinglePAndBitDecomp
+    (:119-186) then ModDownQPtoQNTT (LevelP = 0) or CopyLvl.  ct: (2, levelQ+1, N), NTT domain; rgswQ / rgswP: per component k a
+    (rows, 2, limbs, N) array, row = (digits before limb i) + j  (rgswP: None without P).  mask = all ones when pw2 = 0 (:134-137);
+    every product is the canonical MulCoeffsMontgomery(ThenAdd) (:155-178)."""
+    LQ, LP = levelQ + 1, levelP + 1
+    Ql, Pl = Q[:LQ], (P[:LP] if LP else [])
+    srQ = [orc.SubRingConsts(N, q) for q in Ql]
+    srP = [orc.SubRingConsts(N, p) for p in Pl]
+    mask = (1 << pw2) - 1 if pw2 else 0xFFFFFFFFFFFFFFFF
+    accQ, accP = [None, None], [None, None]
+    first = True
+    for k in (0, 1):
+        cinv = np.stack([orc.intt(ct[k][i], srQ[i]) for i in range(LQ)])
+        e = 0
+        for i in range(LQ):
+            for j in range(digits_per_limb[i] if pw2 else 1):
+                cw = orc.vec_op(OPS["MASK"], cinv[i], None, np.zeros(N, dtype=np.uint64), j * pw2, mask, Ql[i])
+                op = OPS["MUL_MONT"] if first else OPS["MUL_MONT_THEN_ADD"]
+                for mods, srs, key, acc in ((Ql, srQ, rgswQ[k], accQ), (Pl, srP, rgswP[k] if LP else None, accP)):
+                    if not mods:
+                        continue
+                    cwn = [orc.ntt(cw, srs[u], lazy=True) for u in range(len(mods))]              # s.NTTLazy(cw, cwNTT)
+                    for c in (0, 1):
+                        prev = acc[c] if not first else np.zeros((len(mods), N), dtype=np.uint64)
+                        acc[c] = np.stack([orc.vec_op(op, key[e, c, u], cwn[u], prev[u], 0, 0, mods[u]) for u in range(len(mods))])
+                first = False
+                e += 1
+    if LP:
+        return [orc.moddown_qp_to_q_ntt(accQ[c], accP[c], Ql, Pl, srQ, srP) for c in (0, 1)]
+    return accQ

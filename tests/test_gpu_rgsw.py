@@ -44,8 +44,41 @@ def test_external_product_vs_reference_loop(rh, oracle, N, nq, np_, is_ntt, inpl
         assert np.array_equal(g1[k], e1), "component 1, poly %d" % k
     if not inplace:
         assert np.array_equal(op0.Value[0].numpy(), c[0]) and np.array_equal(op0.Value[1].numpy(), c[1])
-    with pytest.raises(rh.RingHipError):                                   # single-P RGSW ciphertexts are refused, not mis-computed
-        rp1 = rh.Ring(N, P[:1])
-        g = rh.rlwe.GadgetCiphertext(rq, rp1, _key(rng, nq, Q, N), _key(rng, nq, P[:1], N))
-        rh.rgsw.Evaluator(rq, rp1).ExternalProduct(op0, rh.rgsw.Ciphertext(g, g), out)
     ev.close(); rq.close(); rp.close()
+
+
+@pytest.mark.parametrize("N,nq,levelQ,levelP,pw2", [(64, 3, 2, 0, 0), (4096, 4, 3, 0, 0), (8192, 3, 2, 0, 20), (64, 3, 2, -1, 16), (4096, 2, 1, -1, 31),
+                                                     (4096, 3, 1, 0, 0), (1 << 14, 2, 1, -1, 0)])
+def test_external_product_single_p_and_bit_decomposition(rh, oracle, N, nq, levelQ, levelP, pw2):
+    """LevelP <= 0 (core/rgsw/evaluator.go:55-70, 119-186): RNS digits by MaskVec of each limb (all-ones mask without a power-of-two
+    decomposition), optionally base-2^pw2 digits on top, with one P modulus (ModDownQPtoQNTT) or none (CopyLvl)"""
+    from oracle import compose
+    Q, P = QI60[:nq], PI60[:1]
+    rng = np.random.default_rng(N + nq + pw2 + levelP)
+    B = 2
+    rq = rh.Ring(N, Q)
+    rp = rh.Ring(N, P) if levelP == 0 else None
+    ev = rh.rgsw.Evaluator(rq, rp)
+    dpl = [-(-int(q).bit_length() // pw2) for q in Q] if pw2 else None      # ceil(bitlen(q_i) / pw2) digits per limb (core/rlwe/params.go:615-633)
+    rows = sum(dpl) if pw2 else nq
+    kq = [_key(rng, rows, Q, N) for _ in (0, 1)]
+    kp = [_key(rng, rows, P, N) for _ in (0, 1)] if rp is not None else [None, None]
+    mk = lambda k: rh.rlwe.GadgetCiphertext(rq, rp, kq[k], kp[k], BaseTwoDecomposition=pw2, digits_per_limb=dpl)
+    rgsw = rh.rgsw.Ciphertext(mk(0), mk(1))
+    # the product runs at the RGSW ciphertext's own levels (:44): give it levelQ by building the ring view's blocks at that level
+    rl = rq.AtLevel(levelQ)
+    c = [np.stack([np.stack([uniform_mod(rng, q, N) for q in Q[:levelQ + 1]]) for _ in range(B)]) for _ in (0, 1)]
+    op0 = rh.Ciphertext([rh.DevicePoly.from_numpy(rl, c[0]), rh.DevicePoly.from_numpy(rl, c[1])], is_ntt=True)
+    out = rh.Ciphertext([rl.NewPoly(B), rl.NewPoly(B)], is_ntt=True)
+    for g in rgsw.Value:
+        g.levelQ = levelQ                                                  # a gadget ciphertext at a lower level: its leading limbs
+    ev.ExternalProduct(op0, rgsw, out)
+    g0, g1 = out.Value[0].numpy(), out.Value[1].numpy()
+    dd = dpl[:levelQ + 1] if pw2 else None
+    for k in range(B):
+        e0, e1 = compose.external_product_single_p(N, Q, P, levelQ, levelP, np.stack([c[0][k], c[1][k]]), pw2, dd, kq, kp)
+        assert np.array_equal(g0[k], e0), "component 0, poly %d" % k
+        assert np.array_equal(g1[k], e1), "component 1, poly %d" % k
+    ev.close(); rq.close()
+    if rp is not None:
+        rp.close()
