@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 out=gpurun_out/exp_mem_power.txt
 : > $out
-for m in 3 4 5; do
+for m in 4 6; do
   tools/micro_mem_power.bin $m 4 >> $out 2>&1 &
   pid=$!
   sleep 2.4

@@ -54,6 +54,15 @@ __global__ void __launch_bounds__(256) sum16_rep(const ulonglong2* a, const ulon
   }
   if (s == 0x1234567) c[threadIdx.x] = s;
 }
+// L2-resident WRITES: every block re-writes its own 32 KiB `reps` times (footprint 16 MiB = 2 MiB per XCD): are they absorbed by L2 or written through?
+__global__ void __launch_bounds__(256) store16_rep(ulonglong2* c, int reps, u64 seed) {
+  const size_t base = (size_t)blockIdx.x * 2048 + threadIdx.x;
+  for (int r = 0; r < reps; ++r) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ulonglong2 v; v.x = seed + r + k; v.y = seed ^ (u64)(r * 8 + k); c[base + k * 256] = v; }
+    asm volatile("" ::: "memory");
+  }
+}
 __global__ void fill(u64* p, size_t n, u64 seed) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = (i + seed) * 0x9E3779B97F4A7C15ull;
 }
@@ -78,7 +87,8 @@ int main(int argc, char** argv) {
       else if (mode == 2) sum8<<<grid, 256>>>(a, b, c);
       else if (mode == 3) sum16<<<grid, 256>>>((const ulonglong2*)a, (const ulonglong2*)b, c);
       else if (mode == 4) sum16_rep<<<512, 256>>>((const ulonglong2*)a, (const ulonglong2*)b, c, 256);       // 512 blocks x 32 KiB x 2 = 32 MiB: L2-resident (4 MiB per XCD)
-      else sum16<<<4096, 256>>>((const ulonglong2*)a, (const ulonglong2*)b, c);                              // 4096 blocks x 32 KiB x 2 = 256 MiB... see below
+      else if (mode == 5) sum16<<<4096, 256>>>((const ulonglong2*)a, (const ulonglong2*)b, c);              // 4096 blocks x 32 KiB x 2 = 256 MiB re-read every launch
+      else store16_rep<<<512, 256>>>((ulonglong2*)c, 256, (u64)n);                                           // 512 blocks x 32 KiB = 16 MiB, re-written 256 times per launch
     }
     CK(hipDeviceSynchronize());
   }
@@ -86,10 +96,12 @@ int main(int argc, char** argv) {
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   double bytes = (double)words * 8 * (mode < 2 ? 3 : 2) * n;
   if (mode == 4) bytes = 512.0 * 32768 * 2 * 256 * n;
-  if (mode == 5) bytes = 4096.0 * 32768 * 2 * n;            // 128 MiB per buffer pair half... 2 x 128 MiB re-read every launch: Infinity-Cache-resident
+  if (mode == 5) bytes = 4096.0 * 32768 * 2 * n;
+  if (mode == 6) bytes = 512.0 * 32768 * 256 * n;            // 128 MiB per buffer pair half... 2 x 128 MiB re-read every launch: Infinity-Cache-resident
   const char* names[] = {"add, 8 B per lane", "add, 16 B per lane", "read-only, 8 B per lane", "read-only, 16 B per lane",
                          "read-only, 16 B per lane, L2-resident (32 MiB footprint, 256 re-reads per launch)",
-                         "read-only, 16 B per lane, 256 MiB footprint re-read every launch (Infinity Cache)"};
-  printf("%s: %.0f GB/s over %.1f s\n", names[mode % 6], bytes / (ms * 1e-3) / 1e9, ms * 1e-3);
+                         "read-only, 16 B per lane, 256 MiB footprint re-read every launch (Infinity Cache)",
+                         "write-only, 16 B per lane, 16 MiB footprint re-written 256 times per launch (L2-resident?)"};
+  printf("%s: %.0f GB/s over %.1f s\n", names[mode % 7], bytes / (ms * 1e-3) / 1e9, ms * 1e-3);
   return 0;
 }
