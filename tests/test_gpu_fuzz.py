@@ -282,3 +282,49 @@ def test_fuzz_rescale_and_automorphism(rh, oracle, case):
         for (k, i) in _spots(rng, B, L - 1, n=2):
             assert np.array_equal(got[k, i], oracle.automorphism(a[k, i], gen, Q[i])), ctx + " Automorphism gen=%d row (%d, %d)" % (gen, k, i)
     ring.close()
+
+
+@pytest.mark.parametrize("case", range(10 * SCALE))
+def test_fuzz_ckks_mul_relin_rescale_at_levels(rh, oracle, case):
+    """ckks.Evaluator.MulRelin + Rescale (schemes/ckks/evaluator.go:786-881, 500-535) on ciphertexts BELOW the key's level: the tensoring, the
+    relinearisation key switch at the ciphertext's level with a key of the full chain, the two Adds, the rescale -- against the oracle
+    composition of tests/test_gpu_ckks.py, for drawn degrees, chain lengths, levels and batches"""
+    from oracle import compose
+    from test_gpu_ckks import oracle_tensor, vop
+    rng = np.random.default_rng(9900 + case)
+    logN = int(rng.choice([6, 12, 13, 14, 15]))
+    N = 1 << logN
+    nq, npm = int(rng.integers(3, 9)), int(rng.integers(2, 4))
+    level = int(rng.integers(1, nq)) if case % 3 else nq - 1
+    B = int(rng.choice([1, 2, 3]))
+    Q, P = QI60[:nq], PI60[:npm]
+    LQ = level + 1
+    beta = (nq - 1 + npm) // npm
+    key = lambda mods: np.stack([np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(2)]) for _ in range(beta)])
+    evkQ, evkP = key(Q), key(P)
+    rq, rp = rh.Ring(N, Q), rh.Ring(N, P)
+    ev = rh.ckks.Evaluator(rq, rp, rlk=rh.rlwe.GadgetCiphertext(rq, rp, evkQ, evkP))
+    rl = rq.AtLevel(level)
+    mk = lambda: np.stack([np.stack([np.stack([uniform_mod(rng, q, N) for q in Q[:LQ]]) for _ in range(B)]) for _ in range(2)])
+    a, b = mk(), mk()
+    ct0 = rh.Ciphertext([rh.DevicePoly.from_numpy(rl, a[0]), rh.DevicePoly.from_numpy(rl, a[1])], is_ntt=True)
+    ct1 = rh.Ciphertext([rh.DevicePoly.from_numpy(rl, b[0]), rh.DevicePoly.from_numpy(rl, b[1])], is_ntt=True)
+    out = rh.Ciphertext([rl.NewPoly(B), rl.NewPoly(B)], is_ntt=True)
+    ev.MulRelin(ct0, ct1, out, relin=True)
+    got = [v.numpy() for v in out.Value]
+    res = rh.Ciphertext([rl.NewPoly(B), rl.NewPoly(B)], is_ntt=True)
+    ev.Rescale(out, res)
+    gres = [v.numpy() for v in res.Value]
+    srQ = [oracle.SubRingConsts(N, q) for q in Q[:LQ]]
+    ctx = "case %d: N=2^%d Q=%d P=%d level=%d B=%d" % (case, logN, nq, npm, level, B)
+    for k in {0, B - 1}:
+        t = oracle_tensor(oracle, rh, a[:, k], b[:, k], Q[:LQ])
+        g0, g1 = compose.gadget_product(N, Q, P, level, npm - 1, t[2], evkQ, evkP)
+        for c, g in ((0, g0), (1, g1)):
+            e = np.stack([vop(oracle, rh, "ADD", t[c][i], g[i], g[i], Q[i]) for i in range(LQ)])
+            assert np.array_equal(got[c][k], e), ctx + " MulRelin component %d poly %d" % (c, k)
+            coeff = np.stack([oracle.intt(e[i], srQ[i]) for i in range(LQ)])
+            down = oracle.div_by_last_modulus_many(coeff, Q[:LQ], 1, True)
+            want = np.stack([oracle.ntt(down[i], srQ[i]) for i in range(LQ - 1)])
+            assert np.array_equal(gres[c][k, :LQ - 1], want), ctx + " Rescale component %d poly %d" % (c, k)
+    ev.close(); rq.close(); rp.close()
