@@ -328,3 +328,47 @@ def test_fuzz_ckks_mul_relin_rescale_at_levels(rh, oracle, case):
             want = np.stack([oracle.ntt(down[i], srQ[i]) for i in range(LQ - 1)])
             assert np.array_equal(gres[c][k, :LQ - 1], want), ctx + " Rescale component %d poly %d" % (c, k)
     ev.close(); rq.close(); rp.close()
+
+
+@pytest.mark.parametrize("case", range(10 * SCALE))
+def test_fuzz_rotation_key_switch(rh, oracle, case):
+    """rlwe.Evaluator.Automorphism / AutomorphismHoisted / AutomorphismHoistedLazy + ModDown (core/rlwe/evaluator_automorphism.go:14-160) at drawn
+    degrees, chains, batches and Galois elements: the direct form against the oracle composition, the hoisted and the lazy-hoisted forms
+    against the direct one, bit for bit"""
+    from oracle import compose
+    rng = np.random.default_rng(9950 + case)
+    logN = int(rng.choice([6, 11, 12, 13, 14, 15]))
+    N = 1 << logN
+    nq, npm = int(rng.integers(2, 9)), int(rng.integers(2, 4))
+    B = int(rng.choice([1, 2, 3]))
+    gal = int(rng.integers(1, N)) * 2 + 1
+    Q, P = QI60[:nq], PI60[:npm]
+    levelQ, levelP = nq - 1, npm - 1
+    beta = (nq - 1 + npm) // npm
+    key = lambda mods: np.stack([np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(2)]) for _ in range(beta)])
+    evkQ, evkP = key(Q), key(P)
+    rq, rp = rh.Ring(N, Q), rh.Ring(N, P)
+    ev = rh.rlwe.Evaluator(rq, rp, galois_keys={gal: rh.rlwe.GadgetCiphertext(rq, rp, evkQ, evkP)})
+    c0, c1 = _block(rng, Q, B, nq, N, levelQ), _block(rng, Q, B, nq, N, levelQ)
+    ct = rh.Ciphertext([rh.DevicePoly.from_numpy(rq, c0), rh.DevicePoly.from_numpy(rq, c1)], is_ntt=True)
+    out = rh.Ciphertext([rq.NewPoly(B), rq.NewPoly(B)], is_ntt=True)
+    ev.Automorphism(ct, gal, out)
+    g0, g1 = out.Value[0].numpy(), out.Value[1].numpy()
+    ctx = "case %d: N=2^%d Q=%d P=%d B=%d gal=%d" % (case, logN, nq, npm, B, gal)
+    for k in {0, B - 1}:
+        e0, e1 = compose.gadget_product(N, Q, P, levelQ, levelP, c1[k], evkQ, evkP)
+        for i, q in enumerate(Q):
+            s = oracle.vec_op(rh.OPS["ADD"], e0[i], c0[k, i], e0[i], 0, 0, q)
+            assert np.array_equal(g0[k, i], oracle.automorphism_ntt(s, gal)), ctx + " component 0 (%d, %d)" % (k, i)
+            assert np.array_equal(g1[k, i], oracle.automorphism_ntt(e1[i], gal)), ctx + " component 1 (%d, %d)" % (k, i)
+    dec = ev.DecomposeNTT(levelQ, levelP, ct.Value[1], True)
+    out2 = rh.Ciphertext([rq.NewPoly(B), rq.NewPoly(B)], is_ntt=True)
+    ev.AutomorphismHoisted(levelQ, ct, dec, gal, out2)
+    assert np.array_equal(out2.Value[0].numpy(), g0) and np.array_equal(out2.Value[1].numpy(), g1), ctx + ": hoisted != direct"
+    qp = rh.rlwe.ElementQP.alloc(rq, rp, B, levelQ, levelP)
+    ev.AutomorphismHoistedLazy(levelQ, ct, dec, gal, qp)
+    out3 = rh.Ciphertext([rq.NewPoly(B), rq.NewPoly(B)], is_ntt=True)
+    ev.ModDown(levelQ, levelP, qp, out3)
+    assert np.array_equal(out3.Value[0].numpy(), g0) and np.array_equal(out3.Value[1].numpy(), g1), ctx + ": lazy hoisted + ModDown != direct"
+    assert np.array_equal(ct.Value[0].numpy(), c0) and np.array_equal(ct.Value[1].numpy(), c1), ctx + ": input modified"
+    ev.close(); rq.close(); rp.close()
