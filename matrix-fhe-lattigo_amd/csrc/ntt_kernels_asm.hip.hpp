@@ -14,7 +14,8 @@
 // gap_len > 0: the L transformed rows of a poly skip the limbs [gap0, gap0 + gap_len) of its Ls rows (the digit's own limbs of a
 // hybrid key-switch decomposition): row l is limb l + (l >= gap0 ? gap_len : 0)
 // LAZY: no final canonical reduction, outputs < 8q (internal consumers only)
-template <bool LAZY = false>
+// NT: the body with non-temporal data streams (tools/gen_tile_asm.py: for working sets far beyond the Infinity Cache -- the pipelined launches)
+template <bool LAZY = false, bool NT = false>
 RH_DEV void fwd_tile_asm_body(u64* lds, const u32 b, const u64* in, u64* out, const tw2* __restrict__ twk,
                               const LimbConsts* __restrict__ consts, int L, int logN, int npoly, int Ls = 0, u32 gap0 = 0, u32 gap_len = 0) {
   if (Ls == 0) Ls = L;                     // rows per poly of the block (>= L)
@@ -35,7 +36,9 @@ RH_DEV void fwd_tile_asm_body(u64* lds, const u32 b, const u64* in, u64* out, co
   asm volatile(BODY : : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw),             \
                [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)), [nq0] "s"((u32)nq),                    \
                [nq1] "s"((u32)(nq >> 32)), [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4) : NTT_TILE_ASM_CLOBBERS)
-  if constexpr (LAZY) RH_TILE_FWD_ASM(NTT_TILE_LAZY_ASM_BODY);
+  if constexpr (LAZY && NT) RH_TILE_FWD_ASM(NTT_TILE_LAZY_ASM_BODY_NT);
+  else if constexpr (LAZY) RH_TILE_FWD_ASM(NTT_TILE_LAZY_ASM_BODY);
+  else if constexpr (NT) RH_TILE_FWD_ASM(NTT_TILE_ASM_BODY_NT);
   else RH_TILE_FWD_ASM(NTT_TILE_ASM_BODY);
 #undef RH_TILE_FWD_ASM
 }
@@ -46,7 +49,7 @@ constexpr bool has_asm_cols(int S1) { return S1 >= 2 && S1 <= 4; }
 #define RH_COLS_FWD_ASM(BODY)                                                                                       \
   asm volatile(BODY : : [tid] "v"(tid), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw), [nq0] "s"((u32)nq),        \
                [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4) : NTT_TILE_ASM_CLOBBERS)
-template <int S1>
+template <int S1, bool NT = false>
 RH_DEV void fwd_cols_asm_body(const u32 b, const u64* in, u64* out, const tw2* __restrict__ twn,
                               const LimbConsts* __restrict__ consts, int L, int Ls = 0, u32 gap0 = 0, u32 gap_len = 0) {
   if (Ls == 0) Ls = L;                     // rows per poly of the block (>= L)
@@ -62,7 +65,10 @@ RH_DEV void fwd_cols_asm_body(const u32 b, const u64* in, u64* out, const tw2* _
   const u64 q = uni64(consts[limb].q);
   const u64 nq = (u64)0 - q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
   const u32 tid = threadIdx.x;
-  if constexpr (S1 == 4) RH_COLS_FWD_ASM(NTT_COLS16_ASM_BODY);
+  if constexpr (S1 == 4 && NT) RH_COLS_FWD_ASM(NTT_COLS16_ASM_BODY_NT);
+  else if constexpr (S1 == 3 && NT) RH_COLS_FWD_ASM(NTT_COLS8_ASM_BODY_NT);
+  else if constexpr (NT) RH_COLS_FWD_ASM(NTT_COLS4_ASM_BODY_NT);
+  else if constexpr (S1 == 4) RH_COLS_FWD_ASM(NTT_COLS16_ASM_BODY);
   else if constexpr (S1 == 3) RH_COLS_FWD_ASM(NTT_COLS8_ASM_BODY);
   else RH_COLS_FWD_ASM(NTT_COLS4_ASM_BODY);
 }
@@ -93,10 +99,10 @@ ntt_fwd_cols_expand_asm(const u64* tmp, u64* out, const tw2* __restrict__ twn, c
   else RH_COLS_EXP_ASM(NTT_COLS4_EXPAND_ASM_BODY);
 #undef RH_COLS_EXP_ASM
 }
-template <int S1, bool ASMCOLS>
+template <int S1, bool ASMCOLS, bool NT = false>
 RH_DEV void fwd_cols_best(const u32 b, const u64* in, u64* out, const tw2* __restrict__ twn,
                           const LimbConsts* __restrict__ consts, int L, int logN) {
-  if constexpr (has_asm_cols(S1) && ASMCOLS) fwd_cols_asm_body<S1>(b, in, out, twn, consts, L);
+  if constexpr (has_asm_cols(S1) && ASMCOLS) fwd_cols_asm_body<S1, NT>(b, in, out, twn, consts, L);
   else fwd_cols_body<ShoupPolicy, S1>(b, in, out, twn, consts, L, logN);
 }
 template <int S1>
@@ -161,8 +167,8 @@ __global__ void __launch_bounds__(256)
 ntt_fwd_fused_asm(const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n2, int npoly2,
                   const tw2* __restrict__ twn, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts, int L, int logN) {
   __shared__ u64 lds[LDS_WORDS];
-  if (blockIdx.x < n1) fwd_cols_best<S1, ASMCOLS>(blockIdx.x, in1, out1, twn, consts, L, logN);
-  if (blockIdx.x < n2) fwd_tile_asm_body(lds, blockIdx.x, data2, data2, twk, consts, L, logN, npoly2);
+  if (blockIdx.x < n1) fwd_cols_best<S1, ASMCOLS, true>(blockIdx.x, in1, out1, twn, consts, L, logN);
+  if (blockIdx.x < n2) fwd_tile_asm_body<false, true>(lds, blockIdx.x, data2, data2, twk, consts, L, logN, npoly2);
 }
 
 // The same pipeline over the digit blocks of a hybrid key-switch decomposition (rh_std_ntt_fwd_digits): launch j runs the
@@ -173,14 +179,14 @@ __global__ void __launch_bounds__(256)
 ntt_fwd_fused_gap_asm(u64* data1, unsigned n1, GapRows g1, u64* data2, unsigned n2, int npoly2, GapRows g2,
                       const tw2* __restrict__ twn, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts) {
   __shared__ u64 lds[LDS_WORDS];
-  if (blockIdx.x < n1) fwd_cols_asm_body<S1>(blockIdx.x, data1, data1, twn, consts, g1.L, g1.Ls, g1.gap0, g1.gap_len);
-  if (blockIdx.x < n2) fwd_tile_asm_body<LAZY>(lds, blockIdx.x, data2, data2, twk, consts, g2.L, LT + S1, npoly2, g2.Ls, g2.gap0, g2.gap_len);
+  if (blockIdx.x < n1) fwd_cols_asm_body<S1, true>(blockIdx.x, data1, data1, twn, consts, g1.L, g1.Ls, g1.gap0, g1.gap_len);
+  if (blockIdx.x < n2) fwd_tile_asm_body<LAZY, true>(lds, blockIdx.x, data2, data2, twk, consts, g2.L, LT + S1, npoly2, g2.Ls, g2.gap0, g2.gap_len);
 }
 
 // ---- inverse: first 12 stages (t = 1..2048) on a 4096-tile, values leave < 4q (N^-1 is applied by ntt_inv_cols).
 // Same contract as ntt_inv_tile(last = 0).  twk = kernel-order table built from RootsBackward.
 // MUL: the tile's input is MRedLazy(in, in2) formed on load (rh_ring_intt_mul; same contract as inv_tile_body<true>)
-template <bool MUL = false>
+template <bool MUL = false, bool NT = false>
 RH_DEV void inv_tile_asm_body(u64* lds, const u32 b, const u64* in, const u64* in2, u64* out, const tw2* __restrict__ twk,
                               const LimbConsts* __restrict__ consts, int L, int logN, int npoly, int in_Ls = 0, int out_Ls = 0) {
   const u32 limb = b % (u32)L;
@@ -196,24 +202,26 @@ RH_DEV void inv_tile_asm_body(u64* lds, const u32 b, const u64* in, const u64* i
   const u64 nq = (u64)0 - q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
   const u32 lds_off = uni32((u32)(size_t)lds);
   const u32 tid = threadIdx.x;
+#define RH_TILE_INV_MUL_ASM(BODY)                                                                                                 \
+  asm volatile(BODY : : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pin2] "s"(pin2), [pout] "s"(pout), [tw] "s"(tw),        \
+               [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)), [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)),     \
+               [nq4] "s"(nq4), [q4] "s"(q4), [q] "s"(q), [q0] "s"((u32)q), [q1] "s"((u32)(q >> 32)), [qi0] "s"((u32)qinv),           \
+               [qi1] "s"((u32)(qinv >> 32)) : NTT_TILE_ASM_CLOBBERS)
+#define RH_TILE_INV_ASM(BODY)                                                                                                     \
+  asm volatile(BODY : : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw),                          \
+               [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)), [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)),     \
+               [nq4] "s"(nq4), [q4] "s"(q4) : NTT_TILE_ASM_CLOBBERS)
   if constexpr (MUL) {
     const u64 pin2 = uni64((u64)(size_t)(in2 + base));
     const u64 qinv = uni64(consts[limb].qinv);
-    asm volatile(NTT_TILE_INV_MUL_ASM_BODY
-                 :
-                 : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pin2] "s"(pin2), [pout] "s"(pout), [tw] "s"(tw),
-                   [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)),
-                   [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4),
-                   [q] "s"(q), [q0] "s"((u32)q), [q1] "s"((u32)(q >> 32)), [qi0] "s"((u32)qinv), [qi1] "s"((u32)(qinv >> 32))
-                 : NTT_TILE_ASM_CLOBBERS);
+    if constexpr (NT) RH_TILE_INV_MUL_ASM(NTT_TILE_INV_MUL_ASM_BODY_NT);
+    else RH_TILE_INV_MUL_ASM(NTT_TILE_INV_MUL_ASM_BODY);
   } else {
-    asm volatile(NTT_TILE_INV_ASM_BODY
-                 :
-                 : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw),
-                   [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)),
-                   [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4)
-                 : NTT_TILE_ASM_CLOBBERS);
+    if constexpr (NT) RH_TILE_INV_ASM(NTT_TILE_INV_ASM_BODY_NT);
+    else RH_TILE_INV_ASM(NTT_TILE_INV_ASM_BODY);
   }
+#undef RH_TILE_INV_MUL_ASM
+#undef RH_TILE_INV_ASM
 }
 // inverse column stages with N^-1 folded in, S1 = 2..4: same contract as inv_cols_body<S1>(scale = 1)
 #define RH_COLS_INV_ASM(BODY)                                                                                                     \
@@ -221,7 +229,7 @@ RH_DEV void inv_tile_asm_body(u64* lds, const u32 b, const u64* in, const u64* i
                [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4), [iw0] "s"((u32)iw), [iw1] "s"((u32)(iw >> 32)),       \
                [ip0] "s"((u32)ip), [ip1] "s"((u32)(ip >> 32)), [lw0] "s"((u32)lw), [lw1] "s"((u32)(lw >> 32)),                   \
                [lp0] "s"((u32)lp), [lp1] "s"((u32)(lp >> 32)) : NTT_TILE_ASM_CLOBBERS)
-template <int S1>
+template <int S1, bool NT = false>
 RH_DEV void inv_cols_asm_body(const u32 b, u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
                               const LimbConsts* __restrict__ consts, int L, int Ls = 0) {
   if (Ls == 0) Ls = L;                     // rows per poly of the block (>= L)
@@ -237,7 +245,10 @@ RH_DEV void inv_cols_asm_body(const u32 b, u64* data, const tw2* __restrict__ tw
   const u64 lw = uni64(lastw[limb].w), lp = uni64(lastw[limb].wp);
   const u64 nq = (u64)0 - q, nq2 = (u64)0 - 2 * q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
   const u32 tid = threadIdx.x;
-  if constexpr (S1 == 4) RH_COLS_INV_ASM(NTT_COLS16_INV_ASM_BODY);
+  if constexpr (S1 == 4 && NT) RH_COLS_INV_ASM(NTT_COLS16_INV_ASM_BODY_NT);
+  else if constexpr (S1 == 3 && NT) RH_COLS_INV_ASM(NTT_COLS8_INV_ASM_BODY_NT);
+  else if constexpr (NT) RH_COLS_INV_ASM(NTT_COLS4_INV_ASM_BODY_NT);
+  else if constexpr (S1 == 4) RH_COLS_INV_ASM(NTT_COLS16_INV_ASM_BODY);
   else if constexpr (S1 == 3) RH_COLS_INV_ASM(NTT_COLS8_INV_ASM_BODY);
   else RH_COLS_INV_ASM(NTT_COLS4_INV_ASM_BODY);
 }
@@ -267,10 +278,10 @@ ntt_inv_fused_asm(const u64* in1, const u64* in1b, u64* out1, unsigned n1, int n
                   const LimbConsts* __restrict__ consts, int L, int logN) {
   __shared__ u64 lds[LDS_WORDS];
   if (blockIdx.x < n2) {
-    if constexpr (has_asm_cols(S1) && ASMCOLS) inv_cols_asm_body<S1>(blockIdx.x, data2, twn, lastw, consts, L);
+    if constexpr (has_asm_cols(S1) && ASMCOLS) inv_cols_asm_body<S1, true>(blockIdx.x, data2, twn, lastw, consts, L);
     else inv_cols_body<S1>(blockIdx.x, data2, twn, lastw, consts, L, logN, 1);
   }
-  if (blockIdx.x < n1) inv_tile_asm_body<MUL>(lds, blockIdx.x, in1, in1b, out1, twk, consts, L, logN, npoly1);
+  if (blockIdx.x < n1) inv_tile_asm_body<MUL, true>(lds, blockIdx.x, in1, in1b, out1, twk, consts, L, logN, npoly1);
 }
 
 // ---- conjugate-invariant ring (ring/ntt.go:716-1311): the fold fused with the column stages (tools/gen_tile_asm.py: gen_cols_ci).

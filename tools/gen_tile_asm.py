@@ -24,7 +24,21 @@ PRIO = int(os.environ.get("RH_ASM_PRIO", "0"))   # s_setprio around the load-iss
 out = []
 
 
+# Cache policy of the DATA streams (every 8-byte-per-lane global access of these bodies moves coefficients that pass through once; twiddles
+# are the 16-byte accesses and the scalar loads): " nt" = non-temporal, the streams do not age out the twiddle tables and each other's lines in
+# the caches.  Every body is rendered twice: NAME (default policy) and NAME_NT; the pipelined launches of large batches (working sets far
+# beyond the 256 MiB Infinity Cache) use the _NT bodies: 7.00 -> 6.74 ms per step of the metric, -2 .. -3 % on the key switch; batches that fit the
+# Infinity Cache (32 .. 256 MiB) run 3 - 6 % SLOWER with them (tools/exp_nt_sizes.sh), hence the two sets.  KEEP_CACHED: loads that ARE
+# re-used (the one coefficient-domain row every limb of a rescale re-expands) keep the default policy in both.
+DATA_FLAGS = ""          # set per generation pass below ("" and " nt")
+KEEP_CACHED = [False]
+
+
 def emit(s):
+    global DATA_FLAGS
+    if DATA_FLAGS and (s.startswith("global_load_dwordx2 ") or s.startswith("global_store_dwordx2 ")) and not (KEEP_CACHED[0] and s.startswith("global_load")):
+        if not s.rstrip().endswith(("nt", "sc0", "sc1")):
+            s = s + DATA_FLAGS
     out.append(s)
 
 
@@ -551,7 +565,9 @@ def gen_cols(S1=4, expand=False):
         emit("v_add_u32 v%d, %d, v%d" % (TW0 + k, 32768 * k, TW0))
     for kk in range(R):
         k = (kk >> 1) + (R >> 1) * (kk & 1)
+        KEEP_CACHED[0] = expand
         emit("global_load_dwordx2 %s, v%d, %%[pin]" % (pair(X(k)), TW0 + k))
+        KEEP_CACHED[0] = False
     emit("s_waitcnt lgkmcnt(0)")
     if PRIO in (1, 2):
         emit("s_setprio 0")
@@ -1052,53 +1068,63 @@ def render(name, lines):
     return "#define %s \\\n%s\n" % (name, body.replace("\n", " \\\n"))
 
 
-gen()
-fwd = list(out)
-if EXP:
-    keep, seen_epi = [], False
-    for l in fwd:
-        if "canonical reduction" in l:
-            seen_epi = True
-        if (EXP & 1) and (l.startswith("ds_") or l == "s_barrier"):
-            continue
-        if (EXP & 8) and l == "s_barrier":
-            continue
-        if (EXP & 2) and l.startswith("global_load_dwordx4"):
-            continue
-        if (EXP & 4) and seen_epi and (l.startswith("v_lshl_add_u64") or l.startswith("v_ashrrev") or l.startswith("v_bfi")):
-            continue
-        keep.append(l)
-    fwd = keep
-del out[:]
-cols, cols_inv, cols_exp = {}, {}, {}
-for s1 in (2, 3, 4):
-    gen_cols(s1)
-    cols[s1] = list(out)
+bodies_text = ""
+for _suffix, _flags in (("", ""), ("_NT", " nt")):
+    DATA_FLAGS = _flags
     del out[:]
-    gen_cols_inv(s1)
-    cols_inv[s1] = list(out)
+    gen()
+    fwd = list(out)
+    if EXP:
+        keep, seen_epi = [], False
+        for l in fwd:
+            if "canonical reduction" in l:
+                seen_epi = True
+            if (EXP & 1) and (l.startswith("ds_") or l == "s_barrier"):
+                continue
+            if (EXP & 8) and l == "s_barrier":
+                continue
+            if (EXP & 2) and l.startswith("global_load_dwordx4"):
+                continue
+            if (EXP & 4) and seen_epi and (l.startswith("v_lshl_add_u64") or l.startswith("v_ashrrev") or l.startswith("v_bfi")):
+                continue
+            keep.append(l)
+        fwd = keep
     del out[:]
-    gen_cols(s1, expand=True)
-    cols_exp[s1] = list(out)
+    cols, cols_inv, cols_exp = {}, {}, {}
+    for s1 in (2, 3, 4):
+        gen_cols(s1)
+        cols[s1] = list(out)
+        del out[:]
+        gen_cols_inv(s1)
+        cols_inv[s1] = list(out)
+        del out[:]
+        gen_cols(s1, expand=True)
+        cols_exp[s1] = list(out)
+        del out[:]
+    gen(lazy_out=True)
+    fwd_lazy = list(out)
     del out[:]
-gen(lazy_out=True)
-fwd_lazy = list(out)
-del out[:]
-gen(epilogue="submul")
-fwd_sm = list(out)
-del out[:]
-gen(epilogue="submul_add")
-fwd_sma = list(out)
-del out[:]
-gen_inverse()
-inv = list(out)
-del out[:]
-gen_inverse(mul=True)
-inv_mul = list(out)
+    gen(epilogue="submul")
+    fwd_sm = list(out)
+    del out[:]
+    gen(epilogue="submul_add")
+    fwd_sma = list(out)
+    del out[:]
+    gen_inverse()
+    inv = list(out)
+    del out[:]
+    gen_inverse(mul=True)
+    inv_mul = list(out)
+    bodies_text += (render("NTT_TILE_ASM_BODY" + _suffix, fwd) + render("NTT_TILE_LAZY_ASM_BODY" + _suffix, fwd_lazy) + render("NTT_TILE_SUBMUL_ASM_BODY" + _suffix, fwd_sm)
+                    + render("NTT_TILE_SUBMUL_ADD_ASM_BODY" + _suffix, fwd_sma)
+                    + "".join(render("NTT_COLS%d_ASM_BODY%s" % (1 << k, _suffix), cols[k]) + render("NTT_COLS%d_INV_ASM_BODY%s" % (1 << k, _suffix), cols_inv[k])
+                              + render("NTT_COLS%d_EXPAND_ASM_BODY%s" % (1 << k, _suffix), cols_exp[k]) for k in (2, 3, 4))
+                    + render("NTT_TILE_INV_ASM_BODY" + _suffix, inv) + render("NTT_TILE_INV_MUL_ASM_BODY" + _suffix, inv_mul))
+DATA_FLAGS = ""
 clob_v = ", ".join('"v%d"' % i for i in range(NVGPR_USED))
 clob_s = ", ".join('"s%d"' % i for i in range(36, 100))
-text = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  forward: %d instructions, inverse: %d.\n" % (len(fwd), len(inv))
-text += render("NTT_TILE_ASM_BODY", fwd) + render("NTT_TILE_LAZY_ASM_BODY", fwd_lazy) + render("NTT_TILE_SUBMUL_ASM_BODY", fwd_sm) + render("NTT_TILE_SUBMUL_ADD_ASM_BODY", fwd_sma) + "".join(render("NTT_COLS%d_ASM_BODY" % (1 << k), cols[k]) + render("NTT_COLS%d_INV_ASM_BODY" % (1 << k), cols_inv[k]) + render("NTT_COLS%d_EXPAND_ASM_BODY" % (1 << k), cols_exp[k]) for k in (2, 3, 4)) + render("NTT_TILE_INV_ASM_BODY", inv) + render("NTT_TILE_INV_MUL_ASM_BODY", inv_mul)
+text = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  forward: %d instructions, inverse: %d; NAME_NT = the same body with non-temporal data streams.\n" % (len(fwd), len(inv))
+text += bodies_text
 text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v, clob_s)
 path = sys.argv[1] if len(sys.argv) > 1 else "ntt_tile_asm.inc"
 open(path, "w").write(text)
