@@ -597,6 +597,10 @@ void rh_3n_launch_layer(bool inverse, int S1, unsigned nblocks, hipStream_t st, 
 bool rh_can_fuse_submul(const rh_ring* r) { return r->kind == RH_RING_STANDARD && r->logN >= LT && r->fuse_submul; }
 // Forward canonical transform of `buf` (in place up to its tile stages) fused with out = MRed(2q - y + NTT(buf), s_limb):
 // column stages as usual, then ntt_fwd_tile_submul.  y / out: (poly, limb) blocks with y_rows / out_rows limbs per poly.
+// Cache policy of a launch's data streams: non-temporal once the rows it moves exceed twice the 256 MiB Infinity Cache (the generated
+// bodies exist in both forms, tools/gen_tile_asm.py; smaller working sets are re-read from the caches and run 3-6 % slower with nt)
+static bool rh_streams_beyond_cache(const rh_ring* r, unsigned rows) { return (size_t)rows * (size_t)r->N * 8 >= ((size_t)512 << 20); }
+
 // rescale: column stages of limbs 0..Lrows-1 fed by the re-expansion of the coefficient-domain last limb `tmp` (N >= 8192)
 int rh_std_ntt_expand_cols_launch(rh_ring* r, const u64* tmp, u64* buf, int npoly, int Lrows, const void* table_dev, int mode, u64 qL) {
   const int S1 = r->logN - LT;
@@ -609,10 +613,14 @@ int rh_std_ntt_expand_cols_launch(rh_ring* r, const u64* tmp, u64* buf, int npol
   bool lazy_ok = r->asm_tile && r->asm_cols && S1 >= 2 && S1 <= 4;      // hand-scheduled body: needs qL + q <= 8q for every limb
   for (int i = 0; i < Lrows && lazy_ok; ++i) lazy_ok = qL / 7 <= r->moduli[i] && qL - 1 < 7 * r->moduli[i];
   if (lazy_ok) {
-    switch (S1) {
-      case 2: ntt_fwd_cols_expand_asm<2><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, mode, qL); break;
-      case 3: ntt_fwd_cols_expand_asm<3><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, mode, qL); break;
-      case 4: ntt_fwd_cols_expand_asm<4><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, mode, qL); break;
+    const bool nt = rh_streams_beyond_cache(r, rows);          // non-temporal data streams for working sets far beyond the Infinity Cache
+    switch (S1 * 2 + (nt ? 1 : 0)) {
+      case 4: ntt_fwd_cols_expand_asm<2, false><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, mode, qL); break;
+      case 5: ntt_fwd_cols_expand_asm<2, true><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, mode, qL); break;
+      case 6: ntt_fwd_cols_expand_asm<3, false><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, mode, qL); break;
+      case 7: ntt_fwd_cols_expand_asm<3, true><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, mode, qL); break;
+      case 8: ntt_fwd_cols_expand_asm<4, false><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, mode, qL); break;
+      case 9: ntt_fwd_cols_expand_asm<4, true><<<g, 256, 0, rh_stream(r)>>>(tmp, buf, r->d_tw_fwd, r->d_consts, T, Lrows, mode, qL); break;
     }
     return check_launch("ntt_fwd_cols_expand_asm");
   }
@@ -642,10 +650,15 @@ int rh_std_ntt_submul_launch(rh_ring* r, u64* buf, int npoly, int Lrows, int lim
       const u64 q = r->moduli[limb0 + i];
       sh.w[i] = rh::imform(scalars_host[i] % q, q); sh.wp[i] = rh::shoup_quotient(sh.w[i], q);
     }
-    if (z) ntt_fwd_tile_submul_asm<true><<<rows << S1, 256, 0, rh_stream(r)>>>(buf, r->d_twk_fwd + toff, r->d_consts + limb0, Lrows, r->logN, npoly, y, y_rows,
-                                                                                   out, out_rows, sh, z, z_rows);
-    else ntt_fwd_tile_submul_asm<false><<<rows << S1, 256, 0, rh_stream(r)>>>(buf, r->d_twk_fwd + toff, r->d_consts + limb0, Lrows, r->logN, npoly, y, y_rows,
-                                                                                 out, out_rows, sh, nullptr, 0);
+    const bool nt = rh_streams_beyond_cache(r, rows);
+    if (z && nt) ntt_fwd_tile_submul_asm<true, true><<<rows << S1, 256, 0, rh_stream(r)>>>(buf, r->d_twk_fwd + toff, r->d_consts + limb0, Lrows, r->logN, npoly, y, y_rows,
+                                                                                               out, out_rows, sh, z, z_rows);
+    else if (z) ntt_fwd_tile_submul_asm<true, false><<<rows << S1, 256, 0, rh_stream(r)>>>(buf, r->d_twk_fwd + toff, r->d_consts + limb0, Lrows, r->logN, npoly, y, y_rows,
+                                                                                               out, out_rows, sh, z, z_rows);
+    else if (nt) ntt_fwd_tile_submul_asm<false, true><<<rows << S1, 256, 0, rh_stream(r)>>>(buf, r->d_twk_fwd + toff, r->d_consts + limb0, Lrows, r->logN, npoly, y, y_rows,
+                                                                                                out, out_rows, sh, nullptr, 0);
+    else ntt_fwd_tile_submul_asm<false, false><<<rows << S1, 256, 0, rh_stream(r)>>>(buf, r->d_twk_fwd + toff, r->d_consts + limb0, Lrows, r->logN, npoly, y, y_rows,
+                                                                                         out, out_rows, sh, nullptr, 0);
     return check_launch("ntt_fwd_tile_submul_asm");
   }
   LimbScalars sc; memset(&sc, 0, sizeof(sc)); memcpy(sc.s, scalars_host, (size_t)Lrows * 8);

@@ -75,7 +75,7 @@ RH_DEV void fwd_cols_asm_body(const u32 b, const u64* in, u64* out, const tw2* _
 // Column stages fed by the re-expansion of a rescale step, hand-scheduled (same outputs contract as ntt_fwd_cols_expand,
 // ntt_kernels.hip.hpp: values < 8q congruent to the expanded limb): x = cred(t + hq, qL) + s is NOT reduced modulo the limb's q --
 // the launcher checks qL + q <= 8q for every limb, which the first stage's conditional subtraction needs.
-template <int S1>
+template <int S1, bool NT = false>
 __global__ void __launch_bounds__(256)
 ntt_fwd_cols_expand_asm(const u64* tmp, u64* out, const tw2* __restrict__ twn, const LimbConsts* __restrict__ consts,
                         const RescaleLimb* __restrict__ T, int L, int mode, u64 qL) {
@@ -94,7 +94,10 @@ ntt_fwd_cols_expand_asm(const u64* tmp, u64* out, const tw2* __restrict__ twn, c
 #define RH_COLS_EXP_ASM(BODY)                                                                                       \
   asm volatile(BODY : : [tid] "v"(tid), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw), [nq0] "s"((u32)nq),        \
                [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4), [hq] "s"(hq), [nqL] "s"(nqL), [sadd] "s"(sadd) : NTT_TILE_ASM_CLOBBERS)
-  if constexpr (S1 == 4) RH_COLS_EXP_ASM(NTT_COLS16_EXPAND_ASM_BODY);
+  if constexpr (S1 == 4 && NT) RH_COLS_EXP_ASM(NTT_COLS16_EXPAND_ASM_BODY_NT);
+  else if constexpr (S1 == 3 && NT) RH_COLS_EXP_ASM(NTT_COLS8_EXPAND_ASM_BODY_NT);
+  else if constexpr (NT) RH_COLS_EXP_ASM(NTT_COLS4_EXPAND_ASM_BODY_NT);
+  else if constexpr (S1 == 4) RH_COLS_EXP_ASM(NTT_COLS16_EXPAND_ASM_BODY);
   else if constexpr (S1 == 3) RH_COLS_EXP_ASM(NTT_COLS8_EXPAND_ASM_BODY);
   else RH_COLS_EXP_ASM(NTT_COLS4_EXPAND_ASM_BODY);
 #undef RH_COLS_EXP_ASM
@@ -122,7 +125,7 @@ ntt_fwd_tile_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const Lim
 //   out = [z +] MRed(2q - y + NTT(in), s_limb),
 // with MRed by the wave-uniform scalar done as a Shoup multiply by s*2^-64 mod q (sw / sp: that constant and its quotient, per limb).
 struct LimbShoup { u64 w[RH_MAX_LIMBS_K], wp[RH_MAX_LIMBS_K]; };
-template <bool ADD>
+template <bool ADD, bool NT = false>
 __global__ void __launch_bounds__(256)
 ntt_fwd_tile_submul_asm(const u64* in, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts, int L, int logN, int npoly,
                         const u64* y, int y_rows, u64* out, int out_rows, LimbShoup sc, const u64* z, int z_rows) {
@@ -143,22 +146,22 @@ ntt_fwd_tile_submul_asm(const u64* in, const tw2* __restrict__ twk, const LimbCo
   const u64 nq = (u64)0 - q, nq2 = (u64)0 - 2 * q, nq4 = (u64)0 - 4 * q, q4 = 4 * q, q2 = 2 * q;
   const u32 lds_off = uni32((u32)(size_t)lds);
   const u32 tid = threadIdx.x;
-  if constexpr (ADD)
-    asm volatile(NTT_TILE_SUBMUL_ADD_ASM_BODY
-                 :
-                 : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pout] "s"(pout), [py] "s"(py), [pz] "s"(pz), [tw] "s"(tw),
-                   [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)),
-                   [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4), [q2] "s"(q2),
-                   [sw0] "s"((u32)sw), [sw1] "s"((u32)(sw >> 32)), [sp0] "s"((u32)sp), [sp1] "s"((u32)(sp >> 32))
-                 : NTT_TILE_ASM_CLOBBERS);
-  else
-    asm volatile(NTT_TILE_SUBMUL_ASM_BODY
-                 :
-                 : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pout] "s"(pout), [py] "s"(py), [tw] "s"(tw),
-                   [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)),
-                   [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4), [q2] "s"(q2),
-                   [sw0] "s"((u32)sw), [sw1] "s"((u32)(sw >> 32)), [sp0] "s"((u32)sp), [sp1] "s"((u32)(sp >> 32))
-                 : NTT_TILE_ASM_CLOBBERS);
+#define RH_SUBMUL_ADD_ASM(BODY)                                                                                                      \
+  asm volatile(BODY : : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pout] "s"(pout), [py] "s"(py), [pz] "s"(pz), [tw] "s"(tw),     \
+               [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)), [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)),            \
+               [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4), [q2] "s"(q2), [sw0] "s"((u32)sw), [sw1] "s"((u32)(sw >> 32)),    \
+               [sp0] "s"((u32)sp), [sp1] "s"((u32)(sp >> 32)) : NTT_TILE_ASM_CLOBBERS)
+#define RH_SUBMUL_ASM(BODY)                                                                                                          \
+  asm volatile(BODY : : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pout] "s"(pout), [py] "s"(py), [tw] "s"(tw),                   \
+               [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)), [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)),            \
+               [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4), [q2] "s"(q2), [sw0] "s"((u32)sw), [sw1] "s"((u32)(sw >> 32)),    \
+               [sp0] "s"((u32)sp), [sp1] "s"((u32)(sp >> 32)) : NTT_TILE_ASM_CLOBBERS)
+  if constexpr (ADD && NT) RH_SUBMUL_ADD_ASM(NTT_TILE_SUBMUL_ADD_ASM_BODY_NT);
+  else if constexpr (ADD) RH_SUBMUL_ADD_ASM(NTT_TILE_SUBMUL_ADD_ASM_BODY);
+  else if constexpr (NT) RH_SUBMUL_ASM(NTT_TILE_SUBMUL_ASM_BODY_NT);
+  else RH_SUBMUL_ASM(NTT_TILE_SUBMUL_ASM_BODY);
+#undef RH_SUBMUL_ADD_ASM
+#undef RH_SUBMUL_ASM
 }
 
 // software-pipelined launch (see ntt_fwd_fused): column stages of span j, then the asm tile body of span j-1
