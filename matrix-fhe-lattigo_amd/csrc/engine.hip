@@ -530,13 +530,16 @@ int rh_std_ntt_fwd_blocks(rh_ring* r, u64* data, size_t block_stride, int npoly,
     if (!g1.L) g1.L = 1;
     if (!g2.L) g2.L = 1;
     u64* d1 = data + (size_t)(j < nblocks ? j : 0) * block_stride; u64* d2 = data + (size_t)(j >= 1 ? j - 1 : 0) * block_stride;
-#define RH_GAP(S, Z) ntt_fwd_fused_gap_asm<S, Z><<<grid, 256, 0, st>>>(d1, n1, g1, d2, n2, npoly, g2, r->d_tw_fwd, r->d_twk_fwd, r->d_consts)
+    // non-temporal data streams once a block is too large to be re-read from the Infinity Cache by the next launch's tile stages
+#define RH_GAP2(S, Z) do { if (nt) ntt_fwd_fused_gap_asm<S, Z, true><<<grid, 256, 0, st>>>(d1, n1, g1, d2, n2, npoly, g2, r->d_tw_fwd, r->d_twk_fwd, r->d_consts); \
+                           else ntt_fwd_fused_gap_asm<S, Z, false><<<grid, 256, 0, st>>>(d1, n1, g1, d2, n2, npoly, g2, r->d_tw_fwd, r->d_twk_fwd, r->d_consts); } while (0)
+    const bool nt = (size_t)npoly * (size_t)Ls * (size_t)r->N * 8 >= ((size_t)256 << 20);
     switch (S1) {
-      case 2: if (lazy_out) RH_GAP(2, true); else RH_GAP(2, false); break;
-      case 3: if (lazy_out) RH_GAP(3, true); else RH_GAP(3, false); break;
-      case 4: if (lazy_out) RH_GAP(4, true); else RH_GAP(4, false); break;
+      case 2: if (lazy_out) RH_GAP2(2, true); else RH_GAP2(2, false); break;
+      case 3: if (lazy_out) RH_GAP2(3, true); else RH_GAP2(3, false); break;
+      case 4: if (lazy_out) RH_GAP2(4, true); else RH_GAP2(4, false); break;
     }
-#undef RH_GAP
+#undef RH_GAP2
   }
   return check_launch("ntt_fwd_fused_gap_asm");
 }

@@ -177,13 +177,13 @@ ntt_fwd_fused_asm(const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n
 // The same pipeline over the digit blocks of a hybrid key-switch decomposition (rh_std_ntt_fwd_digits): launch j runs the
 // column stages of digit j's non-digit limbs and the tile stages of digit j-1's; each digit skips its own limbs (GapRows).
 struct GapRows { int L, Ls; u32 gap0, gap_len; };
-template <int S1, bool LAZY>
+template <int S1, bool LAZY, bool NT>
 __global__ void __launch_bounds__(256)
 ntt_fwd_fused_gap_asm(u64* data1, unsigned n1, GapRows g1, u64* data2, unsigned n2, int npoly2, GapRows g2,
                       const tw2* __restrict__ twn, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts) {
   __shared__ u64 lds[LDS_WORDS];
-  if (blockIdx.x < n1) fwd_cols_asm_body<S1, true>(blockIdx.x, data1, data1, twn, consts, g1.L, g1.Ls, g1.gap0, g1.gap_len);
-  if (blockIdx.x < n2) fwd_tile_asm_body<LAZY, true>(lds, blockIdx.x, data2, data2, twk, consts, g2.L, LT + S1, npoly2, g2.Ls, g2.gap0, g2.gap_len);
+  if (blockIdx.x < n1) fwd_cols_asm_body<S1, NT>(blockIdx.x, data1, data1, twn, consts, g1.L, g1.Ls, g1.gap0, g1.gap_len);
+  if (blockIdx.x < n2) fwd_tile_asm_body<LAZY, NT>(lds, blockIdx.x, data2, data2, twk, consts, g2.L, LT + S1, npoly2, g2.Ls, g2.gap0, g2.gap_len);
 }
 
 // ---- inverse: first 12 stages (t = 1..2048) on a 4096-tile, values leave < 4q (N^-1 is applied by ntt_inv_cols).
