@@ -356,12 +356,16 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
   }
   const int S1 = logN - LT;
   const unsigned tiles = rows << S1;
+  const bool nt = (size_t)rows * (size_t)r->N * 8 >= ((size_t)512 << 20);   // non-temporal data streams beyond the Infinity Cache (see rh_streams_beyond_cache)
   if (!inverse) {
     const u64* src = in;
     if (S1 > 0) {
       dim3 g1(rows * 16);
       if (phase != 2) {
         if (lazy) launch_fwd_cols<MontPolicy>(S1, g1, st, in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN, Ls);
+        else if (S1 == 4 && r->asm_cols && r->asm_tile && nt) ntt_fwd_cols_asm<4, true><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
+        else if (S1 == 3 && r->asm_cols && r->asm_tile && nt) ntt_fwd_cols_asm<3, true><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
+        else if (S1 == 2 && r->asm_cols && r->asm_tile && nt) ntt_fwd_cols_asm<2, true><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
         else if (S1 == 4 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<4><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
         else if (S1 == 3 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<3><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
         else if (S1 == 2 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<2><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
@@ -372,18 +376,23 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
     if (phase != 1) {
       const int ls = Ls ? Ls : Lrows;
       if (lazy) ntt_fwd_tile<MontPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd_mont + toff, c, Lrows, logN, 0, npoly, ls);
-      else if (r->asm_tile) ntt_fwd_tile_asm<<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, npoly, ls);
+      else if (r->asm_tile && nt) ntt_fwd_tile_asm<true><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, npoly, ls);
+      else if (r->asm_tile) ntt_fwd_tile_asm<false><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, npoly, ls);
       else      ntt_fwd_tile<ShoupPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, 1, npoly, ls);
     }
   } else {
     if (phase != 1) {
       // the hand-scheduled body leaves values < 4q unscaled: right whenever column stages follow, and for N = 4096
       // sub-rings of the 3N transform (inv_scale = false), which scale in their own last layer
-      if (r->asm_tile && (S1 > 0 || !r->inv_scale)) ntt_inv_tile_asm<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly, 0, 0);
+      if (r->asm_tile && (S1 > 0 || !r->inv_scale) && nt) ntt_inv_tile_asm<true><<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly, 0, 0);
+      else if (r->asm_tile && (S1 > 0 || !r->inv_scale)) ntt_inv_tile_asm<false><<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly, 0, 0);
       else ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, (S1 == 0 && r->inv_scale) ? 1 : 0, npoly);
     }
     const bool acols = phase != 2 && r->asm_cols && r->asm_tile && r->inv_scale;
-    if (S1 == 4 && acols) ntt_inv_cols_asm<4><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, 0);
+    if (S1 == 4 && acols && nt) ntt_inv_cols_asm<4, true><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, 0);
+    else if (S1 == 3 && acols && nt) ntt_inv_cols_asm<3, true><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, 0);
+    else if (S1 == 2 && acols && nt) ntt_inv_cols_asm<2, true><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, 0);
+    else if (S1 == 4 && acols) ntt_inv_cols_asm<4><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, 0);
     else if (S1 == 3 && acols) ntt_inv_cols_asm<3><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, 0);
     else if (S1 == 2 && acols) ntt_inv_cols_asm<2><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, 0);
     else if (S1 > 0 && phase != 2) launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, logN, r->inv_scale ? 1 : 0);

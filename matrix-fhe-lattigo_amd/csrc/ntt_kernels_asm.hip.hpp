@@ -108,17 +108,18 @@ RH_DEV void fwd_cols_best(const u32 b, const u64* in, u64* out, const tw2* __res
   if constexpr (has_asm_cols(S1) && ASMCOLS) fwd_cols_asm_body<S1, NT>(b, in, out, twn, consts, L);
   else fwd_cols_body<ShoupPolicy, S1>(b, in, out, twn, consts, L, logN);
 }
-template <int S1>
+template <int S1, bool NT = false>
 __global__ void __launch_bounds__(256)
 ntt_fwd_cols_asm(const u64* in, u64* out, const tw2* __restrict__ twn, const LimbConsts* __restrict__ consts, int L, int Ls) {
-  fwd_cols_asm_body<S1>(blockIdx.x, in, out, twn, consts, L, Ls);
+  fwd_cols_asm_body<S1, NT>(blockIdx.x, in, out, twn, consts, L, Ls);
 }
 
+template <bool NT = false>
 __global__ void __launch_bounds__(256)
 ntt_fwd_tile_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts,
                  int L, int logN, int npoly, int Ls) {
   __shared__ u64 lds[LDS_WORDS];
-  fwd_tile_asm_body(lds, blockIdx.x, in, out, twk, consts, L, logN, npoly, Ls);
+  fwd_tile_asm_body<false, NT>(lds, blockIdx.x, in, out, twk, consts, L, logN, npoly, Ls);
 }
 
 // Forward tile stages with the subtract-multiply epilogue, hand-scheduled: same contract as ntt_fwd_tile_submul (ntt_kernels.hip.hpp),
@@ -255,17 +256,18 @@ RH_DEV void inv_cols_asm_body(const u32 b, u64* data, const tw2* __restrict__ tw
   else if constexpr (S1 == 3) RH_COLS_INV_ASM(NTT_COLS8_INV_ASM_BODY);
   else RH_COLS_INV_ASM(NTT_COLS4_INV_ASM_BODY);
 }
-template <int S1>
+template <int S1, bool NT = false>
 __global__ void __launch_bounds__(256)
 ntt_inv_cols_asm(u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw, const LimbConsts* __restrict__ consts, int L, int Ls) {
-  inv_cols_asm_body<S1>(blockIdx.x, data, twn, lastw, consts, L, Ls);
+  inv_cols_asm_body<S1, NT>(blockIdx.x, data, twn, lastw, consts, L, Ls);
 }
 
+template <bool NT = false>
 __global__ void __launch_bounds__(256)
 ntt_inv_tile_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts,
                  int L, int logN, int npoly, int in_Ls, int out_Ls) {
   __shared__ u64 lds[LDS_WORDS];
-  inv_tile_asm_body<false>(lds, blockIdx.x, in, nullptr, out, twk, consts, L, logN, npoly, in_Ls, out_Ls);
+  inv_tile_asm_body<false, NT>(lds, blockIdx.x, in, nullptr, out, twk, consts, L, logN, npoly, in_Ls, out_Ls);
 }
 __global__ void __launch_bounds__(256)
 ntt_inv_tile_mul_asm(const u64* in, const u64* in2, u64* out, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts,
