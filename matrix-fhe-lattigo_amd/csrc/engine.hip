@@ -602,9 +602,13 @@ int rh_std_intt_rows(rh_ring* r, const u64* in, int in_rows, u64* out, int out_r
 
 // ---- 3N transform (ntt3n.hip), b = 1: the hand-scheduled layer kernels live in this translation unit with the tile bodies they fuse with
 void rh_3n_launch_layer(bool inverse, int S1, unsigned nblocks, hipStream_t st, const u64* in, u64* out, const N3Layer& a) {
-#define RH_3NL(S) do { if (inverse) ntt3n_layer_asm<S, true><<<nblocks, 256, 0, st>>>(in, out, a); else ntt3n_layer_asm<S, false><<<nblocks, 256, 0, st>>>(in, out, a); } while (0)
+  // a unit moves 6 * 2^S1 coefficients per thread: nblocks * 256 * 6 * 2^S1 * 8 bytes per direction; non-temporal streams beyond 512 MiB
+  const bool nt = (size_t)nblocks * 256 * 6 * ((size_t)8 << S1) >= ((size_t)512 << 20);
+#define RH_3NL2(S, I) do { if (nt) ntt3n_layer_asm<S, I, true><<<nblocks, 256, 0, st>>>(in, out, a); else ntt3n_layer_asm<S, I, false><<<nblocks, 256, 0, st>>>(in, out, a); } while (0)
+#define RH_3NL(S) do { if (inverse) RH_3NL2(S, true); else RH_3NL2(S, false); } while (0)
   if (S1 == 1) RH_3NL(1); else if (S1 == 2) RH_3NL(2); else RH_3NL(3);
 #undef RH_3NL
+#undef RH_3NL2
 }
 bool rh_can_fuse_submul(const rh_ring* r) { return r->kind == RH_RING_STANDARD && r->logN >= LT && r->fuse_submul; }
 // Forward canonical transform of `buf` (in place up to its tile stages) fused with out = MRed(2q - y + NTT(buf), s_limb):

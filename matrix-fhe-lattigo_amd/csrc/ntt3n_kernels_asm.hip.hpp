@@ -10,7 +10,7 @@
                [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4)      \
                : NTT3N_ASM_CLOBBERS)
 // unit b = (limb, column block of 256, poly): 6 * 2^S1 coefficients per thread, rows of N = 6 * 2^(12 + S1) words
-template <int S1, bool INV>
+template <int S1, bool INV, bool NT = false>
 RH_DEV void n3_layer_asm_body(const u32 b, const u64* in, u64* out, const N3Layer& a) {
   constexpr int log_n2 = 12 + S1;
   const u32 limb = b % (u32)a.L, rr = b / (u32)a.L;
@@ -21,10 +21,18 @@ RH_DEV void n3_layer_asm_body(const u32 b, const u64* in, u64* out, const N3Laye
   const u64 q = uni64(a.c[limb].q);
   const u64 nq = (u64)0 - q, nq2 = (u64)0 - 2 * q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
   const u32 wbase = uni32(threadIdx.x & ~63u);
-  if constexpr (INV) {
+  if constexpr (INV && NT) {
+    if constexpr (S1 == 3) RH_3N_LAYER_ASM(NTT3N_COLS_POST_INV8_ASM_BODY_NT);
+    else if constexpr (S1 == 2) RH_3N_LAYER_ASM(NTT3N_COLS_POST_INV4_ASM_BODY_NT);
+    else RH_3N_LAYER_ASM(NTT3N_COLS_POST_INV2_ASM_BODY_NT);
+  } else if constexpr (INV) {
     if constexpr (S1 == 3) RH_3N_LAYER_ASM(NTT3N_COLS_POST_INV8_ASM_BODY);
     else if constexpr (S1 == 2) RH_3N_LAYER_ASM(NTT3N_COLS_POST_INV4_ASM_BODY);
     else RH_3N_LAYER_ASM(NTT3N_COLS_POST_INV2_ASM_BODY);
+  } else if constexpr (NT) {
+    if constexpr (S1 == 3) RH_3N_LAYER_ASM(NTT3N_PRE_COLS_FWD8_ASM_BODY_NT);
+    else if constexpr (S1 == 2) RH_3N_LAYER_ASM(NTT3N_PRE_COLS_FWD4_ASM_BODY_NT);
+    else RH_3N_LAYER_ASM(NTT3N_PRE_COLS_FWD2_ASM_BODY_NT);
   } else {
     if constexpr (S1 == 3) RH_3N_LAYER_ASM(NTT3N_PRE_COLS_FWD8_ASM_BODY);
     else if constexpr (S1 == 2) RH_3N_LAYER_ASM(NTT3N_PRE_COLS_FWD4_ASM_BODY);
@@ -33,8 +41,8 @@ RH_DEV void n3_layer_asm_body(const u32 b, const u64* in, u64* out, const N3Laye
 }
 #undef RH_3N_LAYER_ASM
 
-template <int S1, bool INV>
+template <int S1, bool INV, bool NT>
 __global__ void __launch_bounds__(256)
-ntt3n_layer_asm(const u64* in, u64* out, N3Layer a) { n3_layer_asm_body<S1, INV>(blockIdx.x, in, out, a); }
+ntt3n_layer_asm(const u64* in, u64* out, N3Layer a) { n3_layer_asm_body<S1, INV, NT>(blockIdx.x, in, out, a); }
 // (A software-pipelined fusion with the sub-transforms' tile stages, the 3N counterpart of ntt_fwd_fused_asm, was measured and removed:
 // both halves hold ~128 VGPRs, and spans of 48 ... 384 rows ran 0-12 % slower than the two separate launches.)

@@ -1129,13 +1129,16 @@ text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" %
 path = sys.argv[1] if len(sys.argv) > 1 else "ntt_tile_asm.inc"
 open(path, "w").write(text)
 text3 = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  3N transform: column stages fused with the radix-3 layer and the split / merge, both directions.\n"
-for s1 in (1, 2, 3):
-    del out[:]
-    gen_3n_cols_post_inv(s1)
-    text3 += render("NTT3N_COLS_POST_INV%d_ASM_BODY" % (1 << s1), list(out))
-    del out[:]
-    gen_3n_pre_cols_fwd(s1)
-    text3 += render("NTT3N_PRE_COLS_FWD%d_ASM_BODY" % (1 << s1), list(out))
+for _suffix, _flags in (("", ""), ("_NT", " nt")):           # both cache policies, as for the power-of-two bodies
+    DATA_FLAGS = _flags
+    for s1 in (1, 2, 3):
+        del out[:]
+        gen_3n_cols_post_inv(s1)
+        text3 += render("NTT3N_COLS_POST_INV%d_ASM_BODY%s" % (1 << s1, _suffix), list(out))
+        del out[:]
+        gen_3n_pre_cols_fwd(s1)
+        text3 += render("NTT3N_PRE_COLS_FWD%d_ASM_BODY%s" % (1 << s1, _suffix), list(out))
+DATA_FLAGS = ""
 text3 += "#define NTT3N_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (", ".join('"v%d"' % i for i in range(128)), clob_s)
 open(os.path.join(os.path.dirname(path), "ntt3n_asm.inc"), "w").write(text3)
 textc = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  Conjugate-invariant ring: fold fused with the column stages, both directions.\n"
