@@ -229,3 +229,35 @@ def test_config4_ring_all_24_limbs(rh, oracle):
     for c in range(3):
         assert np.array_equal(out2.Value[c].numpy(), got[c]), "block-order Mul component %d" % c
     ring.close()
+
+
+def test_working_sets_beyond_the_infinity_cache_take_the_non_temporal_bodies(rh, oracle):
+    """launches whose rows exceed 512 MiB run the generated bodies with non-temporal data streams (engine.hip: rh_streams_beyond_cache; the same
+    instructions with a cache-policy hint): a two-launch forward / inverse transform (70 polys x 16 limbs at N = 2^16 = 560 MiB, not pipelined)
+    and DivRoundByLastModulusNTT on the same block (re-expansion column stages + subtract-multiply tile stages), spot rows against the oracle"""
+    import torch
+    N, L, B = 1 << 16, 16, 70
+    Q = QI60[:L]
+    dev = torch.device("cuda", 0)
+    ring = rh.Ring(N, Q)
+    g = torch.Generator(device=dev); g.manual_seed(99)
+    qs = torch.tensor(Q, dtype=torch.int64, device=dev).view(1, L, 1)
+    x = torch.randint(0, 1 << 62, (B, L, N), dtype=torch.int64, device=dev, generator=g) % qs
+    host = {k: x[k].cpu().numpy().view(np.uint64).copy() for k in (0, 37, B - 1)}
+    p = rh.DevicePoly.from_torch(ring, x)
+    ring.NTT(p, p)
+    srs = [oracle.SubRingConsts(N, q) for q in Q]
+    for k, a in host.items():
+        for i in (0, 9, L - 1):
+            assert np.array_equal(x[k, i].cpu().numpy().view(np.uint64), oracle.ntt(a[i], srs[i])), (k, i)
+    out = torch.zeros((B, L, N), dtype=torch.int64, device=dev)
+    po = rh.DevicePoly.from_torch(ring, out)
+    ring.DivRoundByLastModulusNTT(p, po)
+    for k, a in host.items():
+        down = oracle.div_by_last_modulus_many(a, Q, 1, True)
+        for i in (0, L - 2):
+            assert np.array_equal(out[k, i].cpu().numpy().view(np.uint64), oracle.ntt(down[i], srs[i])), ("rescale", k, i)
+    ring.INTT(p, p)
+    for k, a in host.items():
+        assert np.array_equal(x[k].cpu().numpy().view(np.uint64), a), ("round trip", k)
+    ring.close()
