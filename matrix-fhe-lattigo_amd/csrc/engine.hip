@@ -356,7 +356,7 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
   }
   const int S1 = logN - LT;
   const unsigned tiles = rows << S1;
-  const bool nt = (size_t)rows * (size_t)r->N * 8 >= ((size_t)512 << 20);   // non-temporal data streams beyond the Infinity Cache (see rh_streams_beyond_cache)
+  const bool nt = r->nt_streams && (size_t)rows * (size_t)r->N * 8 >= ((size_t)512 << 20);   // non-temporal data streams beyond the Infinity Cache (see rh_streams_beyond_cache)
   if (!inverse) {
     const u64* src = in;
     if (S1 > 0) {
@@ -406,7 +406,8 @@ static void launch_fused(rh_ring* r, const u64* in1, u64* out1, unsigned n1, u64
   const unsigned grid = n1 > n2 ? n1 : n2;
   hipStream_t st = rh_stream(r);
   if (r->asm_tile && S1 >= 2 && S1 <= 4 && r->asm_cols)
-    ntt_fwd_fused_asm<S1, true><<<grid, 256, 0, st>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN);
+    if (r->nt_streams) ntt_fwd_fused_asm<S1, true, true><<<grid, 256, 0, st>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN);
+    else ntt_fwd_fused_asm<S1, true, false><<<grid, 256, 0, st>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN);
   else if (r->asm_tile)
     ntt_fwd_fused_asm<S1, false><<<grid, 256, 0, st>>>(in1, out1, n1, data2, n2, npoly2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, r->logN);
   else
@@ -461,7 +462,8 @@ static void launch_inv_fused(rh_ring* r, const u64* in1, const u64* in1b, u64* o
     return;
   }
   const tw2* lw = r->d_lastw + limb0;
-  if (acols) ntt_inv_fused_asm<S1, true, false><<<grid, 256, 0, st>>>(in1, nullptr, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff, lw, c, Lrows, r->logN);
+  if (acols && !r->nt_streams) ntt_inv_fused_asm<S1, true, false, false><<<grid, 256, 0, st>>>(in1, nullptr, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff, lw, c, Lrows, r->logN);
+  else if (acols) ntt_inv_fused_asm<S1, true, false><<<grid, 256, 0, st>>>(in1, nullptr, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff, lw, c, Lrows, r->logN);
   else ntt_inv_fused_asm<S1, false, false><<<grid, 256, 0, st>>>(in1, nullptr, out1, n1, npoly1, data2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff, lw, c, Lrows, r->logN);
 }
 // Inverse transform of a large batch: launch j = tile stages of span j fused with column stages (+ N^-1) of span j-1.
@@ -542,7 +544,7 @@ int rh_std_ntt_fwd_blocks(rh_ring* r, u64* data, size_t block_stride, int npoly,
     // non-temporal data streams once a block is too large to be re-read from the Infinity Cache by the next launch's tile stages
 #define RH_GAP2(S, Z) do { if (nt) ntt_fwd_fused_gap_asm<S, Z, true><<<grid, 256, 0, st>>>(d1, n1, g1, d2, n2, npoly, g2, r->d_tw_fwd, r->d_twk_fwd, r->d_consts); \
                            else ntt_fwd_fused_gap_asm<S, Z, false><<<grid, 256, 0, st>>>(d1, n1, g1, d2, n2, npoly, g2, r->d_tw_fwd, r->d_twk_fwd, r->d_consts); } while (0)
-    const bool nt = (size_t)npoly * (size_t)Ls * (size_t)r->N * 8 >= ((size_t)256 << 20);
+    const bool nt = r->nt_streams && (size_t)npoly * (size_t)Ls * (size_t)r->N * 8 >= ((size_t)256 << 20);
     switch (S1) {
       case 2: if (lazy_out) RH_GAP2(2, true); else RH_GAP2(2, false); break;
       case 3: if (lazy_out) RH_GAP2(3, true); else RH_GAP2(3, false); break;
@@ -615,7 +617,7 @@ bool rh_can_fuse_submul(const rh_ring* r) { return r->kind == RH_RING_STANDARD &
 // column stages as usual, then ntt_fwd_tile_submul.  y / out: (poly, limb) blocks with y_rows / out_rows limbs per poly.
 // Cache policy of a launch's data streams: non-temporal once the rows it moves exceed twice the 256 MiB Infinity Cache (the generated
 // bodies exist in both forms, tools/gen_tile_asm.py; smaller working sets are re-read from the caches and run 3-6 % slower with nt)
-static bool rh_streams_beyond_cache(const rh_ring* r, unsigned rows) { return (size_t)rows * (size_t)r->N * 8 >= ((size_t)512 << 20); }
+static bool rh_streams_beyond_cache(const rh_ring* r, unsigned rows) { return r->nt_streams && (size_t)rows * (size_t)r->N * 8 >= ((size_t)512 << 20); }
 
 // rescale: column stages of limbs 0..Lrows-1 fed by the re-expansion of the coefficient-domain last limb `tmp` (N >= 8192)
 int rh_std_ntt_expand_cols_launch(rh_ring* r, const u64* tmp, u64* buf, int npoly, int Lrows, const void* table_dev, int mode, u64 qL) {
@@ -906,6 +908,7 @@ extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
     return RH_OK;
   }
   if (!strcmp(key, "asm_cols")) { r->asm_cols = (int)value; return RH_OK; }
+  if (!strcmp(key, "nt_streams")) { r->nt_streams = value != 0; return RH_OK; }     // 0: default cache policy everywhere (A/B runs: bench.py --tune nt_streams=0)
   return rh_fail(RH_ERR_ARG, "set_tuning: unknown key %s", key);
 }
 

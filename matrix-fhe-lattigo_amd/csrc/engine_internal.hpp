@@ -53,6 +53,7 @@ struct rh_ring {
   bool asm_tile = true;           // forward tile kernel: hand-scheduled body (ntt_kernels_asm.hip.hpp) vs the C++ one
   bool inv_scale = true;          // false: inverse leaves values < 4q without the N^-1 factor (3N sub-transform)
   int auto_span_rows = 2048;      // chunk_polys = -1: span size of the fused pipeline in (poly, limb) rows
+  bool nt_streams = true;         // non-temporal data streams for launches beyond the Infinity Cache (the generated _NT bodies); false: default policy everywhere
   int chunk_polys = -1;           // -1 = auto (128-poly spans for batches >= 256), 0 = whole batch in two launches, >0 = polys per span
 };
 

@@ -166,13 +166,13 @@ ntt_fwd_tile_submul_asm(const u64* in, const tw2* __restrict__ twk, const LimbCo
 }
 
 // software-pipelined launch (see ntt_fwd_fused): column stages of span j, then the asm tile body of span j-1
-template <int S1, bool ASMCOLS = false>
+template <int S1, bool ASMCOLS = false, bool NT = true>
 __global__ void __launch_bounds__(256)
 ntt_fwd_fused_asm(const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n2, int npoly2,
                   const tw2* __restrict__ twn, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts, int L, int logN) {
   __shared__ u64 lds[LDS_WORDS];
-  if (blockIdx.x < n1) fwd_cols_best<S1, ASMCOLS, true>(blockIdx.x, in1, out1, twn, consts, L, logN);
-  if (blockIdx.x < n2) fwd_tile_asm_body<false, true>(lds, blockIdx.x, data2, data2, twk, consts, L, logN, npoly2);
+  if (blockIdx.x < n1) fwd_cols_best<S1, ASMCOLS, NT>(blockIdx.x, in1, out1, twn, consts, L, logN);
+  if (blockIdx.x < n2) fwd_tile_asm_body<false, NT>(lds, blockIdx.x, data2, data2, twk, consts, L, logN, npoly2);
 }
 
 // The same pipeline over the digit blocks of a hybrid key-switch decomposition (rh_std_ntt_fwd_digits): launch j runs the
@@ -276,17 +276,17 @@ ntt_inv_tile_mul_asm(const u64* in, const u64* in2, u64* out, const tw2* __restr
   inv_tile_asm_body<true>(lds, blockIdx.x, in, in2, out, twk, consts, L, logN, npoly);
 }
 // software-pipelined inverse: tile stages of span j (in -> out), then column stages + N^-1 of span j-1 (in place)
-template <int S1, bool ASMCOLS = false, bool MUL = false>
+template <int S1, bool ASMCOLS = false, bool MUL = false, bool NT = true>
 __global__ void __launch_bounds__(256)
 ntt_inv_fused_asm(const u64* in1, const u64* in1b, u64* out1, unsigned n1, int npoly1, u64* data2, unsigned n2,
                   const tw2* __restrict__ twk, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
                   const LimbConsts* __restrict__ consts, int L, int logN) {
   __shared__ u64 lds[LDS_WORDS];
   if (blockIdx.x < n2) {
-    if constexpr (has_asm_cols(S1) && ASMCOLS) inv_cols_asm_body<S1, true>(blockIdx.x, data2, twn, lastw, consts, L);
+    if constexpr (has_asm_cols(S1) && ASMCOLS) inv_cols_asm_body<S1, NT>(blockIdx.x, data2, twn, lastw, consts, L);
     else inv_cols_body<S1>(blockIdx.x, data2, twn, lastw, consts, L, logN, 1);
   }
-  if (blockIdx.x < n1) inv_tile_asm_body<MUL, true>(lds, blockIdx.x, in1, in1b, out1, twk, consts, L, logN, npoly1);
+  if (blockIdx.x < n1) inv_tile_asm_body<MUL, NT>(lds, blockIdx.x, in1, in1b, out1, twk, consts, L, logN, npoly1);
 }
 
 // ---- conjugate-invariant ring (ring/ntt.go:716-1311): the fold fused with the column stages (tools/gen_tile_asm.py: gen_cols_ci).

@@ -1,11 +1,9 @@
 #!/bin/bash
-# EXPERIMENT: cache-policy hints on the streams of the two-pass pipeline (generator env: RH_ASM_COLS_LOAD / RH_ASM_TILE_LOAD / RH_ASM_TILE_STORE)
-mkdir -p gpurun_out
-out=gpurun_out/exp_nt.txt; : > $out
-for lib in base nt4 gnt gsc1nt gsysnt gsc1 base; do
-  echo "$lib" >> $out
-  for i in 1 2; do
-    RINGHIP_LIB=$PWD/gpurun_in/libringhip_$lib.so python bench.py --no-cpu --no-verify --no-power --steps 30 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['ms_per_step'])" >> $out || exit 1
+# same-box A/B of the non-temporal data streams: tuning key nt_streams = 0 (default cache policy everywhere) against the library's default
+# (profiles/r02_nt_policy_*.txt were produced with two builds of the library before the key existed: RINGHIP_LIB=<build without the _NT bodies>)
+for rep in 1 2 3; do
+  for v in 0 1; do
+    echo -n "nt_streams=$v: "
+    python bench.py --no-cpu --no-verify --no-power --steps 30 --tune nt_streams=$v "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(round(d['value']), round(d['ms_per_step'],4))"
   done
 done
-cat $out
