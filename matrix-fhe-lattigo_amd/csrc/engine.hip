@@ -968,7 +968,7 @@ extern "C" int rh_ntt_backward_lazy(rh_ring* r, int limb, const uint64_t* p1, ui
 // ------------------------------------------------------------------------------------------------ element-wise
 struct ScalarPack { u64 s[RH_MAX_LIMBS]; };
 
-struct RowStrides { int r1, r2, r3; unsigned pair0, pair1; };   // limbs per poly of the three operand blocks (>= L: ring.AtLevel views; r2 < 0: p2 is ONE
+struct RowStrides { int r1, r2, r3; unsigned pair0, pair1; int nt; };   // nt: non-temporal loads / stores (operands beyond the Infinity Cache; a broadcast row stays cached)   // limbs per poly of the three operand blocks (>= L: ring.AtLevel views; r2 < 0: p2 is ONE
                                                                  // row used for every (poly, limb)); the range of coefficient pairs processed
 template <int OP>
 __global__ void __launch_bounds__(256)
@@ -981,14 +981,21 @@ vec_op_packed(const u64* p1, const u64* p2, u64* p3, unsigned n, ScalarPack s0, 
   const size_t o1 = ((size_t)poly * rs.r1 + limb) * n, o2 = rs.r2 < 0 ? 0 : ((size_t)poly * rs.r2 + limb) * n, o3 = ((size_t)poly * rs.r3 + limb) * n;
   for (unsigned i = rs.pair0 + blockIdx.y * blockDim.x + threadIdx.x; i < rs.pair1; i += gridDim.y * blockDim.x) {
     const size_t e = 2 * (size_t)i;
+    typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
+    auto ld = [&](const u64* p, bool nt) {
+      if (!nt) return *reinterpret_cast<const ulonglong2*>(p);
+      const u64x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t*>(p));
+      return make_ulonglong2(v.x, v.y);
+    };
     ulonglong2 x = make_ulonglong2(0, 0), y = x, z = x;
-    if (op_reads_x(OP)) x = *reinterpret_cast<const ulonglong2*>(p1 + o1 + e);
-    if (op_reads_y(OP)) y = *reinterpret_cast<const ulonglong2*>(p2 + o2 + e);
-    if (op_reads_z(OP)) z = *reinterpret_cast<const ulonglong2*>(p3 + o3 + e);
+    if (op_reads_x(OP)) x = ld(p1 + o1 + e, rs.nt);
+    if (op_reads_y(OP)) y = ld(p2 + o2 + e, rs.nt && rs.r2 >= 0);
+    if (op_reads_z(OP)) z = ld(p3 + o3 + e, rs.nt);
     ulonglong2 w;
     w.x = vec_apply<OP>(x.x, y.x, z.x, a0, a1, c);
     w.y = vec_apply<OP>(x.y, y.y, z.y, a0, a1, c);
-    *reinterpret_cast<ulonglong2*>(p3 + o3 + e) = w;
+    if (rs.nt) { u64x2_t v; v.x = w.x; v.y = w.y; __builtin_nontemporal_store(v, reinterpret_cast<u64x2_t*>(p3 + o3 + e)); }
+    else *reinterpret_cast<ulonglong2*>(p3 + o3 + e) = w;
   }
 }
 
@@ -1014,7 +1021,8 @@ int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3,
   if (chunks < 1) chunks = 1;
   if (chunks > 64) chunks = 64;
   const unsigned npairs = n >> 1;
-  const RowStrides rs{rows1 ? rows1 : Lrows, rows2 ? rows2 : Lrows, rows3 ? rows3 : Lrows, half == 2 ? npairs / 2 : 0u, half == 1 ? npairs / 2 : npairs};
+  const RowStrides rs{rows1 ? rows1 : Lrows, rows2 ? rows2 : Lrows, rows3 ? rows3 : Lrows, half == 2 ? npairs / 2 : 0u, half == 1 ? npairs / 2 : npairs,
+                      (r->nt_streams && (size_t)rows * (size_t)r->N * 8 >= ((size_t)512 << 20)) ? 1 : 0};
   hipLaunchKernelGGL(table[opcode], dim3(rows, chunks), dim3(256), 0, rh_stream(r), p1, p2, p3, n, a, b, r->d_consts + limb0, Lrows, rs);
   return check_launch("vec_op");
 }

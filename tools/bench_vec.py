@@ -9,6 +9,7 @@ from conftest import QI60
 N, L, B = 1 << 16, 16, 512
 dev = torch.device("cuda", 0); stream = torch.cuda.current_stream()
 ring = rh.Ring(N, QI60[:L]); ring.set_stream(stream.cuda_stream)
+if len(sys.argv) > 1: ring.set_tuning("nt_streams", int(sys.argv[1]))     # bench_vec.py 0: default cache policy (A/B)
 qs = torch.tensor(QI60[:L], dtype=torch.int64, device=dev).view(1, L, 1)
 mk = lambda: rh.DevicePoly.from_torch(ring, torch.randint(0, 1 << 62, (B, L, N), dtype=torch.int64, device=dev) % qs)
 pa, pb, pc = mk(), mk(), mk()
