@@ -1056,14 +1056,24 @@ extern "C" int rh_ring_vec_op_halves(rh_ring* r, int opcode, const uint64_t* p1,
 // with the same formulas element by element (7 operands of traffic instead of 23).  Outputs may alias inputs element-wise.
 __global__ void __launch_bounds__(256)
 tensor_degree1_kernel(const u64* a0, const u64* a1, const u64* b0, const u64* b1, u64* c0, u64* c1, u64* c2, unsigned n,
-                      const LimbConsts* __restrict__ consts, int L, int mform_first) {   // 0: no MForm (matrix_ckks.Evaluator.Mul, evaluator.go:166-173)
+                      const LimbConsts* __restrict__ consts, int L, int mform_first, int nt) {   // mform_first 0: no MForm (matrix_ckks.Evaluator.Mul, evaluator.go:166-173); nt: non-temporal streams
+  typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
+  auto ld = [&](const u64* p) {
+    if (!nt) return *reinterpret_cast<const ulonglong2*>(p);
+    const u64x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t*>(p));
+    return make_ulonglong2(v.x, v.y);
+  };
+  auto st = [&](u64* p, const ulonglong2& w) {
+    if (nt) { u64x2_t v; v.x = w.x; v.y = w.y; __builtin_nontemporal_store(v, reinterpret_cast<u64x2_t*>(p)); }
+    else *reinterpret_cast<ulonglong2*>(p) = w;
+  };
   const u32 row = blockIdx.x, limb = row % (u32)L;
   const LimbConsts c = consts[limb];
   const size_t ro = (size_t)row * n;
   for (unsigned i = blockIdx.y * blockDim.x + threadIdx.x; i < (n >> 1); i += gridDim.y * blockDim.x) {
     const size_t o = ro + 2 * (size_t)i;
-    const ulonglong2 x0 = *reinterpret_cast<const ulonglong2*>(a0 + o), x1 = *reinterpret_cast<const ulonglong2*>(a1 + o);
-    const ulonglong2 y0 = *reinterpret_cast<const ulonglong2*>(b0 + o), y1 = *reinterpret_cast<const ulonglong2*>(b1 + o);
+    const ulonglong2 x0 = ld(a0 + o), x1 = ld(a1 + o);
+    const ulonglong2 y0 = ld(b0 + o), y1 = ld(b1 + o);
     ulonglong2 r0, r1, r2;
     {
       const u64 m0 = mform_first ? mform(x0.x, c.q, c.bred0, c.bred1) : x0.x, m1 = mform_first ? mform(x1.x, c.q, c.bred0, c.bred1) : x1.x;
@@ -1075,7 +1085,7 @@ tensor_degree1_kernel(const u64* a0, const u64* a1, const u64* b0, const u64* b1
       r0.y = mred(m0, y0.y, c.q, c.qinv); r2.y = mred(m1, y1.y, c.q, c.qinv);
       r1.y = cred(mred(m0, y1.y, c.q, c.qinv) + mred(m1, y0.y, c.q, c.qinv), c.q);
     }
-    *reinterpret_cast<ulonglong2*>(c0 + o) = r0; *reinterpret_cast<ulonglong2*>(c1 + o) = r1; *reinterpret_cast<ulonglong2*>(c2 + o) = r2;
+    st(c0 + o, r0); st(c1 + o, r1); st(c2 + o, r2);
   }
 }
 extern "C" int rh_ring_tensor_degree1(rh_ring* r, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0, const uint64_t* b1,
@@ -1088,7 +1098,8 @@ extern "C" int rh_ring_tensor_degree1(rh_ring* r, const uint64_t* a0, const uint
   (void)hipSetDevice(r->device);
   (void)hipGetLastError();
   unsigned chunks = (n / 2 + 1023) / 1024; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
-  tensor_degree1_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(a0, a1, b0, b1, c0, c1, c2, n, r->d_consts, level + 1, mform_first);
+  tensor_degree1_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(a0, a1, b0, b1, c0, c1, c2, n, r->d_consts, level + 1, mform_first,
+                                                                      rh_streams_beyond_cache(r, rows) ? 1 : 0);
   return check_launch("tensor_degree1");
 }
 
