@@ -3,8 +3,8 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/team_pmc; rm -rf $O; mkdir -p $O
 S=${1:-9}; W=${2:-4}
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/f -o f --output-format csv -- python3 tools/exp_team.py one $S $W > $O/f.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/w -o w --output-format csv -- python3 tools/exp_team.py one $S $W > $O/w.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/f -o f --output-format csv -- python3 experiments/team_one_pass/exp_team.py one $S $W > $O/f.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/w -o w --output-format csv -- python3 experiments/team_one_pass/exp_team.py one $S $W > $O/w.log 2>&1
 python3 - <<PY
 import csv, collections
 for tag, path in (("FETCH_SIZE", "$O/f/f_counter_collection.csv"), ("WRITE_SIZE", "$O/w/w_counter_collection.csv")):

@@ -106,6 +106,23 @@ int rh_ntt_forward_lazy(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2);
 int rh_ntt_backward(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2);
 int rh_ntt_backward_lazy(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2);
 
+/* ---- Ring.NTT / NTTLazy / INTT / INTTLazy on a whole host Poly in ONE call (ring/ntt.go:127-152: the loop over
+ * r.SubRings[:level+1] calling s.NTT(p1.Coeffs[i], p2.Coeffs[i]); Poly.Coeffs is [][]uint64, ring/poly.go:13-24).
+ * p1 / p2: host arrays of level+1 limb pointers (N words each; p2[i] may alias p1[i]); limb i uses modulus i.  Same results as level+1
+ * calls of rh_ntt_forward / _lazy / backward / _lazy, but pipelined: up to four limb groups alternate between two streams (upload of
+ * group g under the transform and download of group g-1), one batched launch pair per group, one host synchronisation.  Limbs in
+ * page-locked memory (rh_host_alloc / rh_host_register) are DMA'd where they lie; pageable limbs are staged through page-locked buffers
+ * owned by the handle.  Synchronous; any number of OS threads may call it on one handle (each call takes a slot of its own).
+ * The cgo wrapper pins the Go slices for the call (runtime.Pinner) and passes a C array of their data pointers. */
+int rh_ntt_poly_forward(rh_ring* r, int level, const uint64_t* const* p1, uint64_t* const* p2, int lazy);
+int rh_ntt_poly_backward(rh_ring* r, int level, const uint64_t* const* p1, uint64_t* const* p2, int lazy);
+/* Page-locked host memory for Poly.Coeffs backing arrays (a Go slice over it: unsafe.Slice): such limbs skip the staging copy.
+ * rh_host_register page-locks memory the caller already owns (it must stay allocated and unmoved until rh_host_unregister). */
+int rh_host_alloc(size_t words, uint64_t** hptr);
+int rh_host_free(uint64_t* hptr);
+int rh_host_register(uint64_t* hptr, size_t words);
+int rh_host_unregister(uint64_t* hptr);
+
 /* ---- Ring.NTT / NTTLazy / INTT / INTTLazy on device-resident batches (ring/ntt.go:127-152).
  * in/out: npoly polys of (level+1) limbs each, limbs 0..level of the ring (Ring.AtLevel view); may alias.
  * Asynchronous on the ring's stream. */

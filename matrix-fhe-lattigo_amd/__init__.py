@@ -5,7 +5,7 @@ package only binds it (ctypes) and mirrors the names of ring.Ring / ring.SubRing
 like the reference's.  There is no CPU fallback: importing works without a GPU (the library loads), any compute call
 without a device fails loudly."""
 from .ringhip import (  # noqa: F401
-    RingHipError, Ring, SubRing, DevicePoly, BasisExtender, Standard, ConjugateInvariant, Matrix3N, AutomorphismNTTIndex, OPS, lib, library_path,
+    RingHipError, Ring, SubRing, DevicePoly, PinnedBuffer, BasisExtender, Standard, ConjugateInvariant, Matrix3N, AutomorphismNTTIndex, OPS, lib, library_path,
 )
 from .schemes import Ciphertext, MatrixCKKSEvaluator, ckks_tensor_degree1, ckks_polymul  # noqa: F401,E402
 from . import rlwe  # noqa: F401,E402

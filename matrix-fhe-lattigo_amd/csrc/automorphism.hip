@@ -99,10 +99,11 @@ extern "C" int rh_ring_automorphism(rh_ring* r, int level, const uint64_t* in, u
 }
 
 // ---- ring.Shift and ring.MultByMonomial (ring/operations.go:278-282, 306-363): index maps over every limb of a block, out of place ----
+// (rows = npoly * limbs on gridDim.x like every other kernel of the library: gridDim.y is capped at 65535)
 __global__ void __launch_bounds__(256)
 shift_kernel(const u64* in, u64* out, unsigned N, unsigned k) {              // p2[j] = p1[(j + k) mod N] (utils.RotateSliceAllocFree: left rotation)
-  const size_t base = (size_t)blockIdx.y * N;
-  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+  const size_t base = (size_t)blockIdx.x * N;
+  for (unsigned j = blockIdx.y * blockDim.x + threadIdx.x; j < N; j += gridDim.y * blockDim.x) {
     unsigned src = j + k; if (src >= N) src -= N;
     out[base + j] = in[base + src];
   }
@@ -111,11 +112,11 @@ __global__ void __launch_bounds__(256)
 monomial_kernel(const u64* in, u64* out, unsigned N, unsigned shift2n, const LimbConsts* __restrict__ consts, int L) {
   // shift2n = (k + 2N) mod 2N, not 0.  tmp = shift2n < N ? p1 : q - p1 (q - 0 = q, as the reference writes it); s = shift2n mod N;
   // p2[j] = q - tmp[N - s + j] for j < s, tmp[j - s] otherwise (:324-361)
-  const u64 q = consts[blockIdx.y % (unsigned)L].q;
-  const size_t base = (size_t)blockIdx.y * N;
+  const u64 q = consts[blockIdx.x % (unsigned)L].q;
+  const size_t base = (size_t)blockIdx.x * N;
   const bool neg = shift2n >= N;
   const unsigned s = shift2n >= N ? shift2n - N : shift2n;
-  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+  for (unsigned j = blockIdx.y * blockDim.x + threadIdx.x; j < N; j += gridDim.y * blockDim.x) {
     const unsigned src = j < s ? N - s + j : j - s;
     u64 v = in[base + src];
     if (neg) v = q - v;
@@ -138,7 +139,7 @@ extern "C" int rh_ring_shift(rh_ring* r, int level, const uint64_t* in, uint64_t
   const int N = r->N;
   int kk = k % N; if (kk < 0) kk += N;
   unsigned chunks = ((unsigned)N + 1023) / 1024; if (chunks > 64) chunks = 64;
-  shift_kernel<<<dim3(chunks, rows), 256, 0, rh_stream(r)>>>(in, out, (unsigned)N, (unsigned)kk);
+  shift_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(in, out, (unsigned)N, (unsigned)kk);
   return done("shift_kernel");
 }
 extern "C" int rh_ring_mult_by_monomial(rh_ring* r, int level, const uint64_t* in, uint64_t* out, int k, int npoly) {
@@ -152,15 +153,15 @@ extern "C" int rh_ring_mult_by_monomial(rh_ring* r, int level, const uint64_t* i
     return RH_OK;
   }
   unsigned chunks = ((unsigned)N + 1023) / 1024; if (chunks > 64) chunks = 64;
-  monomial_kernel<<<dim3(chunks, rows), 256, 0, rh_stream(r)>>>(in, out, (unsigned)N, (unsigned)sh, r->d_consts, level + 1);
+  monomial_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(in, out, (unsigned)N, (unsigned)sh, r->d_consts, level + 1);
   return done("monomial_kernel");
 }
 
 // ---- AutomorphismNTTWithIndex / ...ThenAddLazy (:50-117): the caller's lookup table (N words on the device), any permutation
 __global__ void __launch_bounds__(256)
 automorphism_index_kernel(const u64* in, u64* out, const u64* __restrict__ index, unsigned N, int add_lazy) {
-  const size_t base = (size_t)blockIdx.y * N;
-  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+  const size_t base = (size_t)blockIdx.x * N;
+  for (unsigned j = blockIdx.y * blockDim.x + threadIdx.x; j < N; j += gridDim.y * blockDim.x) {
     const u64 v = in[base + index[j]];
     out[base + j] = add_lazy ? out[base + j] + v : v;
   }
@@ -172,7 +173,7 @@ extern "C" int rh_ring_automorphism_ntt_index(rh_ring* r, int level, const uint6
   const unsigned rows = (unsigned)npoly * (unsigned)(level + 1);
   if (!rows) return RH_OK;
   unsigned chunks = ((unsigned)r->N + 1023) / 1024; if (chunks > 64) chunks = 64;
-  automorphism_index_kernel<<<dim3(chunks, rows), 256, 0, rh_stream(r)>>>(in, out, index, (unsigned)r->N, add_lazy);
+  automorphism_index_kernel<<<dim3(rows, chunks), 256, 0, rh_stream(r)>>>(in, out, index, (unsigned)r->N, add_lazy);
   return done("automorphism_index_kernel");
 }
 
@@ -180,16 +181,16 @@ extern "C" int rh_ring_automorphism_ntt_index(rh_ring* r, int level, const uint6
 // unfold (:8-26): std[j] = ci[j], std[n + k] = ci[n - 1 - k]; one thread per word of the 2n-word output row
 __global__ void __launch_bounds__(256)
 ci_unfold_kernel(const u64* ci, u64* std_, unsigned n) {
-  const size_t bi = (size_t)blockIdx.y * n, bo = (size_t)blockIdx.y * 2 * n;
-  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < 2 * n; j += gridDim.x * blockDim.x)
+  const size_t bi = (size_t)blockIdx.x * n, bo = (size_t)blockIdx.x * 2 * n;
+  for (unsigned j = blockIdx.y * blockDim.x + threadIdx.x; j < 2 * n; j += gridDim.y * blockDim.x)
     std_[bo + j] = ci[bi + (j < n ? j : 2 * n - 1 - j)];
 }
 // fold (:31-49): AutomorphismNTTWithIndex over the first n outputs, then SubRing.Add with the first n words of the standard poly
 __global__ void __launch_bounds__(256)
 ci_fold_std_kernel(const u64* std_, const u64* __restrict__ index, u64* ci, unsigned n, const LimbConsts* __restrict__ consts, int L) {
-  const u64 q = consts[blockIdx.y % (unsigned)L].q;
-  const size_t bi = (size_t)blockIdx.y * 2 * n, bo = (size_t)blockIdx.y * n;
-  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+  const u64 q = consts[blockIdx.x % (unsigned)L].q;
+  const size_t bi = (size_t)blockIdx.x * 2 * n, bo = (size_t)blockIdx.x * n;
+  for (unsigned j = blockIdx.y * blockDim.x + threadIdx.x; j < n; j += gridDim.y * blockDim.x) {
     const u64 v = std_[bi + index[j]] + std_[bi + j];
     ci[bo + j] = v >= q ? v - q : v;                            // CRed (addvec, ring/vec_ops.go:7-29)
   }
@@ -198,10 +199,10 @@ ci_fold_std_kernel(const u64* std_, const u64* __restrict__ index, u64* ci, unsi
 // first half wrote; the closed form of that is what each thread writes (ringhip.h).  Words n..2n-1 of the output row are not touched.
 __global__ void __launch_bounds__(256)
 ci_pad_kernel(const u64* std_, u64* ci, unsigned n, int is_ntt, const LimbConsts* __restrict__ consts, int L) {
-  const u64 q = consts[blockIdx.y % (unsigned)L].q;
-  const size_t bi = (size_t)blockIdx.y * n, bo = (size_t)blockIdx.y * 2 * n;
+  const u64 q = consts[blockIdx.x % (unsigned)L].q;
+  const size_t bi = (size_t)blockIdx.x * n, bo = (size_t)blockIdx.x * 2 * n;
   const unsigned h = n / 2;
-  for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+  for (unsigned k = blockIdx.y * blockDim.x + threadIdx.x; k < n; k += gridDim.y * blockDim.x) {
     u64 v;
     if (is_ntt) v = std_[bi + (k < h ? k : n - 1 - k)];
     else if (k == 0) v = 0;
@@ -217,7 +218,7 @@ extern "C" int rh_ring_unfold_ci_to_standard(rh_ring* r, int level, const uint64
   if (r->kind != RH_RING_STANDARD || r->N < 2) return rh_fail(RH_ERR_ARG, "unfold_ci_to_standard: the receiver is the standard ring of degree 2n");
   const unsigned rows = (unsigned)npoly * (unsigned)(level + 1), n = (unsigned)r->N / 2;
   if (!rows) return RH_OK;
-  ci_unfold_kernel<<<dim3(bridge_chunks(2 * n), rows), 256, 0, rh_stream(r)>>>(ci, std_, n);
+  ci_unfold_kernel<<<dim3(rows, bridge_chunks(2 * n)), 256, 0, rh_stream(r)>>>(ci, std_, n);
   return done("ci_unfold_kernel");
 }
 extern "C" int rh_ring_fold_standard_to_ci(rh_ring* r, int level, const uint64_t* std_, const uint64_t* index, uint64_t* ci, int npoly) {
@@ -225,7 +226,7 @@ extern "C" int rh_ring_fold_standard_to_ci(rh_ring* r, int level, const uint64_t
   if (int rc = index_map_common(r, level, std_, ci, npoly, "fold_standard_to_ci")) return rc;
   const unsigned rows = (unsigned)npoly * (unsigned)(level + 1), n = (unsigned)r->N;
   if (!rows) return RH_OK;
-  ci_fold_std_kernel<<<dim3(bridge_chunks(n), rows), 256, 0, rh_stream(r)>>>(std_, index, ci, n, r->d_consts, level + 1);
+  ci_fold_std_kernel<<<dim3(rows, bridge_chunks(n)), 256, 0, rh_stream(r)>>>(std_, index, ci, n, r->d_consts, level + 1);
   return done("ci_fold_std_kernel");
 }
 extern "C" int rh_ring_pad_default_to_ci(rh_ring* r, int level, const uint64_t* std_, int is_ntt, uint64_t* ci, int npoly) {
@@ -233,6 +234,6 @@ extern "C" int rh_ring_pad_default_to_ci(rh_ring* r, int level, const uint64_t* 
   if (r->N < 2) return rh_fail(RH_ERR_ARG, "pad_default_to_ci: degree < 2");
   const unsigned rows = (unsigned)npoly * (unsigned)(level + 1), n = (unsigned)r->N;
   if (!rows) return RH_OK;
-  ci_pad_kernel<<<dim3(bridge_chunks(n), rows), 256, 0, rh_stream(r)>>>(std_, ci, n, is_ntt ? 1 : 0, r->d_consts, level + 1);
+  ci_pad_kernel<<<dim3(rows, bridge_chunks(n)), 256, 0, rh_stream(r)>>>(std_, ci, n, is_ntt ? 1 : 0, r->d_consts, level + 1);
   return done("ci_pad_kernel");
 }

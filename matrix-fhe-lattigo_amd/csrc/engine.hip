@@ -230,6 +230,7 @@ extern "C" int rh_ring_create_auto(rh_ring** out, int device, int kind, int N, i
                         pow2 ? rf.data() : nullptr, pow2 ? rb.data() : nullptr, kind == RH_RING_3N ? om.data() : nullptr);
 }
 
+void rh_poly_slots_teardown(rh_ring* r);
 extern "C" void rh_ring_destroy(rh_ring* r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
@@ -240,6 +241,7 @@ extern "C" void rh_ring_destroy(rh_ring* r) {
     if (sl->stream) (void)hipStreamDestroy(sl->stream);
     delete sl;
   }
+  rh_poly_slots_teardown(r);
   rh_rescale_teardown(r);
   for (int i = 0; i < 2; ++i) if (r->d_rs[i]) (void)hipFree(r->d_rs[i]);
   rh_ring3n_teardown(r);
@@ -603,9 +605,9 @@ int rh_std_intt_rows(rh_ring* r, const u64* in, int in_rows, u64* out, int out_r
 }
 
 // ---- 3N transform (ntt3n.hip), b = 1: the hand-scheduled layer kernels live in this translation unit with the tile bodies they fuse with
-void rh_3n_launch_layer(bool inverse, int S1, unsigned nblocks, hipStream_t st, const u64* in, u64* out, const N3Layer& a) {
+void rh_3n_launch_layer(bool inverse, int S1, unsigned nblocks, hipStream_t st, const u64* in, u64* out, const N3Layer& a, bool nt_streams) {
   // a unit moves 6 * 2^S1 coefficients per thread: nblocks * 256 * 6 * 2^S1 * 8 bytes per direction; non-temporal streams beyond 512 MiB
-  const bool nt = (size_t)nblocks * 256 * 6 * ((size_t)8 << S1) >= ((size_t)512 << 20);
+  const bool nt = nt_streams && (size_t)nblocks * 256 * 6 * ((size_t)8 << S1) >= ((size_t)512 << 20);   // tuning nt_streams = 0: default policy everywhere
 #define RH_3NL2(S, I) do { if (nt) ntt3n_layer_asm<S, I, true><<<nblocks, 256, 0, st>>>(in, out, a); else ntt3n_layer_asm<S, I, false><<<nblocks, 256, 0, st>>>(in, out, a); } while (0)
 #define RH_3NL(S) do { if (inverse) RH_3NL2(S, true); else RH_3NL2(S, false); } while (0)
   if (S1 == 1) RH_3NL(1); else if (S1 == 2) RH_3NL(2); else RH_3NL(3);
@@ -908,7 +910,7 @@ extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
     return RH_OK;
   }
   if (!strcmp(key, "asm_cols")) { r->asm_cols = (int)value; return RH_OK; }
-  if (!strcmp(key, "nt_streams")) { r->nt_streams = value != 0; return RH_OK; }     // 0: default cache policy everywhere (A/B runs: bench.py --tune nt_streams=0)
+  if (!strcmp(key, "nt_streams")) { r->nt_streams = value != 0; if (r->kind == RH_RING_3N) rh_ring3n_set_nt_streams(r, value != 0); return RH_OK; }     // 0: default cache policy everywhere (A/B runs: bench.py --tune nt_streams=0)
   return rh_fail(RH_ERR_ARG, "set_tuning: unknown key %s", key);
 }
 
@@ -964,6 +966,130 @@ extern "C" int rh_ntt_forward(rh_ring* r, int limb, const uint64_t* p1, uint64_t
 extern "C" int rh_ntt_forward_lazy(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2) { return ntt_host_limb(r, limb, p1, p2, false, true); }
 extern "C" int rh_ntt_backward(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2) { return ntt_host_limb(r, limb, p1, p2, true, false); }
 extern "C" int rh_ntt_backward_lazy(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2) { return ntt_host_limb(r, limb, p1, p2, true, true); }
+
+// ---- a whole Poly, host pointers: Ring.NTT / NTTLazy / INTT / INTTLazy (ring/ntt.go:127-152) as ONE call -------------------------------
+// The reference loops `for i, s := range r.SubRings[:r.level+1] { s.NTT(p1.Coeffs[i], p2.Coeffs[i]) }` over Poly.Coeffs [][]uint64
+// (ring/poly.go:13-24); through rh_ntt_forward that is level+1 synchronous H2D -> kernel -> D2H -> synchronise round trips.  Here the
+// level+1 limb pointers arrive together: the limbs are cut into up to four groups that alternate between two streams, so group g's
+// upload runs under group g-1's transform and download (PCIe is full duplex), every group is ONE batched launch pair over its limbs, and
+// the host synchronises once.  Page-locked limbs (rh_host_alloc / rh_host_register) are DMA'd where they lie; pageable limbs are staged
+// through the slot's page-locked buffers (the CPU copy of group g overlaps the DMA of group g-1).
+struct RhPolySlot {
+  hipStream_t st[2] = {nullptr, nullptr};
+  hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};
+  u64* dbuf = nullptr; size_t dwords = 0;                 // device: the limbs (+ the 3N transform's workspace)
+  u64* hin = nullptr; u64* hout = nullptr; size_t hwords = 0;   // page-locked staging, allocated when a pageable limb is first seen
+};
+static void poly_slot_free(RhPolySlot* sl) {
+  if (sl->dbuf) (void)hipFree(sl->dbuf);
+  if (sl->hin) (void)hipHostFree(sl->hin);
+  if (sl->hout) (void)hipHostFree(sl->hout);
+  for (hipStream_t s : sl->st) if (s) (void)hipStreamDestroy(s);
+  for (hipEvent_t e : sl->done) if (e) (void)hipEventDestroy(e);
+  delete sl;
+}
+void rh_poly_slots_teardown(rh_ring* r) { for (RhPolySlot* sl : r->all_poly_slots) poly_slot_free(sl); r->all_poly_slots.clear(); r->free_poly_slots.clear(); }
+static int poly_slot_acquire(rh_ring* r, RhPolySlot** out) {
+  {
+    std::lock_guard<std::mutex> lk(r->slot_mu);
+    if (!r->free_poly_slots.empty()) { *out = r->free_poly_slots.back(); r->free_poly_slots.pop_back(); return RH_OK; }
+  }
+  RhPolySlot* sl = new (std::nothrow) RhPolySlot();
+  if (!sl) return rh_fail(RH_ERR_NOMEM, "out of host memory");
+  sl->dwords = (size_t)r->N * r->L * (r->kind == RH_RING_3N ? 2 : 1);
+  bool ok = hipMalloc((void**)&sl->dbuf, sl->dwords * 8) == hipSuccess;
+  for (int k = 0; k < 2 && ok; ++k) ok = hipStreamCreateWithFlags(&sl->st[k], hipStreamNonBlocking) == hipSuccess;
+  for (int k = 0; k < 4 && ok; ++k) ok = hipEventCreateWithFlags(&sl->done[k], hipEventDisableTiming) == hipSuccess;
+  if (!ok) { poly_slot_free(sl); return rh_fail(RH_ERR_NOMEM, "whole-poly host path: device buffer / stream / event creation failed"); }
+  std::lock_guard<std::mutex> lk(r->slot_mu);
+  r->all_poly_slots.push_back(sl);
+  *out = sl;
+  return RH_OK;
+}
+static void poly_slot_release(rh_ring* r, RhPolySlot* sl) { std::lock_guard<std::mutex> lk(r->slot_mu); r->free_poly_slots.push_back(sl); }
+static bool host_ptr_is_pinned(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // an ordinary (pageable) pointer is "invalid value" to the runtime
+  return a.type == hipMemoryTypeHost;
+}
+static int ntt_host_poly(rh_ring* r, int level, const uint64_t* const* p1, uint64_t* const* p2, bool inverse, bool lazy) {
+  if (!r) return rh_fail(RH_ERR_ARG, "null ring");
+  if (!p1 || !p2) return rh_fail(RH_ERR_ARG, "cannot NTT: nil Poly.Coeffs");
+  if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "ntt: level %d out of range [0,%d)", level, r->L);
+  const int Lr = level + 1, N = r->N;
+  for (int i = 0; i < Lr; ++i) if (!p1[i] || !p2[i]) return rh_fail(RH_ERR_ARG, "cannot NTT: nil slice at limb %d (len(p1[i]), len(p2[i]) must be >= N=%d)", i, N);
+  (void)hipSetDevice(r->device);
+  RhPolySlot* sl;
+  if (int rc = poly_slot_acquire(r, &sl)) return rc;
+  const size_t bytes = (size_t)N * 8;
+  bool pin_in[RH_MAX_LIMBS], pin_out[RH_MAX_LIMBS], staged = false;
+  for (int i = 0; i < Lr; ++i) { pin_in[i] = host_ptr_is_pinned(p1[i]); pin_out[i] = host_ptr_is_pinned(p2[i]); staged |= !pin_in[i] || !pin_out[i]; }
+  int rc = RH_OK;
+  if (staged && !sl->hin) {
+    sl->hwords = (size_t)N * r->L;
+    if (hipHostMalloc((void**)&sl->hin, sl->hwords * 8, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void**)&sl->hout, sl->hwords * 8, hipHostMallocDefault) != hipSuccess) {
+      if (sl->hin) { (void)hipHostFree(sl->hin); sl->hin = nullptr; }
+      rc = rh_fail(RH_ERR_NOMEM, "hipHostMalloc(page-locked staging) failed");
+    }
+  }
+  // groups: enough bytes per group to amortise a launch pair (>= 256 KiB), at most 4
+  int G = (int)(((size_t)Lr * bytes) / ((size_t)256 << 10)); if (G > 4) G = 4; if (G > Lr) G = Lr; if (G < 1) G = 1;
+  int used = 0;
+  for (int g = 0; g < G && !rc; ++g, ++used) {
+    const int g0 = (int)((long)Lr * g / G), g1 = (int)((long)Lr * (g + 1) / G);
+    hipStream_t st = sl->st[g & 1];
+    hipError_t e = hipSuccess;
+    for (int i = g0; i < g1 && e == hipSuccess; ++i) {
+      const u64* src = p1[i];
+      if (!pin_in[i]) { memcpy(sl->hin + (size_t)i * N, p1[i], bytes); src = sl->hin + (size_t)i * N; }
+      e = hipMemcpyAsync(sl->dbuf + (size_t)i * N, src, bytes, hipMemcpyHostToDevice, st);
+    }
+    if (e != hipSuccess) { rc = rh_fail(RH_ERR_DEVICE, "H2D: %s", hipGetErrorString(e)); break; }
+    {
+      u64* d = sl->dbuf + (size_t)g0 * N;
+      RhCallScope scope(st, r->kind == RH_RING_3N ? sl->dbuf + (size_t)(r->L + g0) * N : nullptr, (size_t)(g1 - g0) * N);
+      rc = (r->kind == RH_RING_3N) ? rh_ring3n_ntt_launch(r, d, d, 1, g1 - g0, g0, inverse)
+         : (r->kind == RH_RING_CI) ? ci_ntt_launch(r, d, d, 1, g1 - g0, g0, inverse)
+                                   : rh_std_ntt_launch(r, d, d, 1, g1 - g0, g0, inverse, lazy, 0);
+    }
+    for (int i = g0; i < g1 && !rc; ++i) {
+      u64* dst = pin_out[i] ? p2[i] : sl->hout + (size_t)i * N;
+      e = hipMemcpyAsync(dst, sl->dbuf + (size_t)i * N, bytes, hipMemcpyDeviceToHost, st);
+      if (e != hipSuccess) rc = rh_fail(RH_ERR_DEVICE, "D2H: %s", hipGetErrorString(e));
+    }
+    if (!rc && hipEventRecord(sl->done[g], st) != hipSuccess) rc = rh_fail(RH_ERR_DEVICE, "hipEventRecord failed");
+  }
+  if (rc) { (void)hipStreamSynchronize(sl->st[0]); (void)hipStreamSynchronize(sl->st[1]); poly_slot_release(r, sl); return rc; }
+  for (int g = 0; g < G; ++g) {                         // staged outputs leave as soon as their group has landed
+    const int g0 = (int)((long)Lr * g / G), g1 = (int)((long)Lr * (g + 1) / G);
+    hipError_t e = hipEventSynchronize(sl->done[g]);
+    if (e != hipSuccess) { rc = rh_fail(RH_ERR_DEVICE, "whole-poly host path: %s", hipGetErrorString(e)); (void)hipStreamSynchronize(sl->st[0]); (void)hipStreamSynchronize(sl->st[1]); break; }
+    for (int i = g0; i < g1; ++i) if (!pin_out[i]) memcpy(p2[i], sl->hout + (size_t)i * N, bytes);
+  }
+  poly_slot_release(r, sl);
+  return rc;
+}
+extern "C" int rh_ntt_poly_forward(rh_ring* r, int level, const uint64_t* const* p1, uint64_t* const* p2, int lazy) { return ntt_host_poly(r, level, p1, p2, false, lazy != 0); }
+extern "C" int rh_ntt_poly_backward(rh_ring* r, int level, const uint64_t* const* p1, uint64_t* const* p2, int lazy) { return ntt_host_poly(r, level, p1, p2, true, lazy != 0); }
+// page-locked host memory for Poly.Coeffs backing arrays: limbs that live here are DMA'd directly by rh_ntt_* / rh_ntt_poly_*
+extern "C" int rh_host_alloc(size_t words, uint64_t** hptr) {
+  if (!hptr) return rh_fail(RH_ERR_ARG, "rh_host_alloc: null argument");
+  if (hipHostMalloc((void**)hptr, (words ? words : 1) * 8, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return rh_fail(RH_ERR_NOMEM, "hipHostMalloc(%zu words) failed", words); }
+  return RH_OK;
+}
+extern "C" int rh_host_free(uint64_t* hptr) { if (hptr) (void)hipHostFree(hptr); return RH_OK; }
+extern "C" int rh_host_register(uint64_t* hptr, size_t words) {
+  if (!hptr || !words) return rh_fail(RH_ERR_ARG, "rh_host_register: null argument");
+  hipError_t e = hipHostRegister(hptr, words * 8, hipHostRegisterDefault);
+  if (e != hipSuccess) { (void)hipGetLastError(); return rh_fail(RH_ERR_DEVICE, "hipHostRegister: %s", hipGetErrorString(e)); }
+  return RH_OK;
+}
+extern "C" int rh_host_unregister(uint64_t* hptr) {
+  if (!hptr) return RH_OK;
+  hipError_t e = hipHostUnregister(hptr);
+  if (e != hipSuccess) { (void)hipGetLastError(); return rh_fail(RH_ERR_DEVICE, "hipHostUnregister: %s", hipGetErrorString(e)); }
+  return RH_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ element-wise
 struct ScalarPack { u64 s[RH_MAX_LIMBS]; };

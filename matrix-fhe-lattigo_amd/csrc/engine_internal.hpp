@@ -36,6 +36,7 @@ struct rh_ring {
   // host-pointer single-limb path (rh_ntt_*): a pool of (stream, scratch) slots, one per concurrent caller
   std::mutex slot_mu;
   std::vector<struct RhHostSlot*> free_slots, all_slots;
+  std::vector<struct RhPolySlot*> free_poly_slots, all_poly_slots;   // whole-Poly host path (rh_ntt_poly_*): two streams + staging per concurrent caller
   // serialises the HOST side of the entry points that touch lazily built shared state (rescale tables / scratch, the 3N
   // transform's scratch); device work stays stream-ordered.  Tables, twiddles and tuning are read-only after creation.
   std::recursive_mutex mu;
@@ -96,10 +97,11 @@ int rh_upload_consts(rh_ring* r, const std::vector<LimbConsts>& hc);
 void rh_rescale_teardown(rh_ring* r);
 int rh_rescale_reserve(rh_ring* r, int npoly);
 int rh_ring3n_reserve(rh_ring* r, int npoly);
-void rh_3n_launch_layer(bool inverse, int S1, unsigned nblocks, hipStream_t st, const u64* in, u64* out, const N3Layer& a);
+void rh_3n_launch_layer(bool inverse, int S1, unsigned nblocks, hipStream_t st, const u64* in, u64* out, const N3Layer& a, bool nt_streams);
 // 3N-cyclotomic transform (ntt3n.hip)
 int rh_ring3n_setup(rh_ring* r, std::vector<LimbConsts>& hc);
 void rh_ring3n_teardown(rh_ring* r);
+void rh_ring3n_set_nt_streams(rh_ring* r, bool on);
 int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool block_order = false);
 int rh_ring3n_reorder_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, bool to_reference);
 

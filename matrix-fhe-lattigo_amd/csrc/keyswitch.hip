@@ -370,13 +370,18 @@ extern "C" int rh_bext_gadget_product_coeff(rh_bext* be, int levelQ, int levelP,
 // (ring.MaskVec), the same small vector under every modulus.  Each digit is transformed and multiply-accumulated against its key
 // row with the reference's Reduce schedule.  The reference transforms with NTTLazy and accumulates MRedLazy values; the closing
 // Reduce / ModDown outputs are canonical, so the canonical forward transform used here gives the same bits.
+// The window of limb i is < q_i (or < 2^pw2), which may exceed another modulus q_u by any factor (mixed-size chains, e.g. 60- and
+// 40-bit primes): each target limb gets the canonical residue BRedAdd(v, q_u) (ring/modular_reduction.go:110-117), inside the
+// range the forward transform's first stage assumes.  The reference feeds the raw window to NTTLazy; its closing Reduce makes both
+// routes agree bit for bit.
 __global__ void __launch_bounds__(256)
-mask_broadcast_kernel(const u64* in, int in_rows, int src_limb, int shift, u64 mask, u64* outQ, int LQ, u64* outP, int LP, int N) {
+mask_broadcast_kernel(const u64* in, int in_rows, int src_limb, int shift, u64 mask, u64* outQ, int LQ, u64* outP, int LP, int N,
+                      const LimbConsts* __restrict__ cQ, const LimbConsts* __restrict__ cP) {
   const int k = blockIdx.x * 256 + threadIdx.x, poly = blockIdx.y;
   if (k >= N) return;
   const u64 v = (in[((size_t)poly * in_rows + src_limb) * N + k] >> shift) & mask;           // MaskVec (ring/vec_ops.go:870)
-  for (int u = 0; u < LQ; ++u) outQ[((size_t)poly * LQ + u) * N + k] = v;
-  for (int u = 0; u < LP; ++u) outP[((size_t)poly * LP + u) * N + k] = v;
+  for (int u = 0; u < LQ; ++u) outQ[((size_t)poly * LQ + u) * N + k] = bred_add(v, cQ[u].q, cQ[u].bred0);
+  for (int u = 0; u < LP; ++u) outP[((size_t)poly * LP + u) * N + k] = bred_add(v, cP[u].q, cP[u].bred0);
 }
 static int reduce_pair(rh_ring* R, int L, u64* a0, u64* a1, int npoly) {
   if (int rc = rh_vec_launch(R, RH_OP_REDUCE, a0, nullptr, a0, npoly, L, 0, nullptr, nullptr)) return rc;
@@ -415,6 +420,7 @@ static int single_p_core(rh_bext* be, int levelQ, int levelP, const uint64_t* cx
   // reads limb 0); such gadget ciphertexts are built with a power-of-two decomposition (core/rlwe/params.go:615-633)
   if (pw2 == 0 && levelP < 0 && !raw_limb_digits) return rh_fail(RH_ERR_UNSUPPORTED, "gadget_product_single_p: no P modulus needs BaseTwoDecomposition > 0");
   if (npoly <= 0) return RH_OK;
+  if (npoly > 65535) return rh_fail(RH_ERR_ARG, "gadget_product_single_p: at most 65535 polys per call (split the batch)");
   (void)hipSetDevice(RQ->device);
   (void)hipGetLastError();
   const int LQ = levelQ + 1, LP = levelP + 1, N = RQ->N;
@@ -441,14 +447,14 @@ static int single_p_core(rh_bext* be, int levelQ, int levelP, const uint64_t* cx
   const int PiOverF = LP ? rh_overflow_margin(RP->moduli, levelP) >> 1 : 1;
   const size_t evq = (size_t)RQ->L * N, evp = LP ? (size_t)RP->L * N : 0;
   const u64 mask = pw2 ? (((u64)1 << pw2) - 1) : 0;
-  const dim3 grid((N + 255) / 256, npoly);
+  const dim3 grid((N + 255) / 256, npoly);                          // polys on gridDim.y: a batch is far below its 65535 cap
   int e = 0, reduce = 0;
   for (int i = 0; i < LQ; ++i) {
     const int nd = pw2 ? digits_per_limb[i] : 1;
     if (!maskform) if (int rc = rh_bext_decompose_and_split(be, levelQ, levelP, LP, i, cxInv, c2Q, c2P, npoly)) return rc;   // (:243-245)
     for (int j = 0; j < nd; ++j, ++e) {
       if (maskform) {
-        mask_broadcast_kernel<<<grid, 256, 0, rh_stream(RQ)>>>(cxInv, LQ, i, j * pw2, pw2 ? mask : mask_all, c2Q, LQ, c2P, LP, N);   // (:249-252)
+        mask_broadcast_kernel<<<grid, 256, 0, rh_stream(RQ)>>>(cxInv, LQ, i, j * pw2, pw2 ? mask : mask_all, c2Q, LQ, c2P, LP, N, RQ->d_consts, LP ? RP->d_consts : nullptr);   // (:249-252)
         if (hipGetLastError() != hipSuccess) return rh_fail(RH_ERR_DEVICE, "mask_broadcast_kernel launch failed");
       }
       if (maskform || j == 0) {                                        // s.NTTLazy under every modulus (:258-262, :285-289)

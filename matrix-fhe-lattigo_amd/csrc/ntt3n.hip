@@ -504,7 +504,7 @@ static int ensure_tmp(rh_ring3n_state* s, size_t words) {
 // Supported for b = 1 rings with n2 >= 4096 (N >= 24576); the host-limb interface always speaks the reference order.
 static void launch_pre_cols_fwd(rh_ring* r, int S1sub, dim3 g, hipStream_t st, const u64* in, u64* out, int N, const tw2* r3, int r3_stride,
                                 const Limb3N* l3, const LimbConsts* c, int Lrows, const tw2* stw, int log_n2) {
-  if (r->asm_tile) { rh_3n_launch_layer(false, S1sub, g.x, st, in, out, N3Layer{r3, r3_stride, l3, c, Lrows, stw, N}); return; }
+  if (r->asm_tile) { rh_3n_launch_layer(false, S1sub, g.x, st, in, out, N3Layer{r3, r3_stride, l3, c, Lrows, stw, N}, r->nt_streams); return; }
   if (S1sub == 1) ntt3n_pre_cols_fwd<1><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw, log_n2);
   else if (S1sub == 2) ntt3n_pre_cols_fwd<2><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw, log_n2);
   else ntt3n_pre_cols_fwd<3><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw, log_n2);
@@ -512,7 +512,7 @@ static void launch_pre_cols_fwd(rh_ring* r, int S1sub, dim3 g, hipStream_t st, c
 
 static void launch_cols_post_inv(rh_ring* r, int S1sub, dim3 g, hipStream_t st, const u64* in, u64* out, int N, const tw2* r3, int r3_stride,
                                  const Limb3N* l3, const LimbConsts* c, int Lrows, const tw2* stw, int log_n2) {
-  if (r->asm_tile) { rh_3n_launch_layer(true, S1sub, g.x, st, in, out, N3Layer{r3, r3_stride, l3, c, Lrows, stw, N}); return; }   // hand-scheduled body (tuning asm_tile = 0: the compiled kernel)
+  if (r->asm_tile) { rh_3n_launch_layer(true, S1sub, g.x, st, in, out, N3Layer{r3, r3_stride, l3, c, Lrows, stw, N}, r->nt_streams); return; }   // hand-scheduled body (tuning asm_tile = 0: the compiled kernel)
   if (S1sub == 1) ntt3n_cols_post_inv<1><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw, log_n2);
   else if (S1sub == 2) ntt3n_cols_post_inv<2><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw, log_n2);
   else ntt3n_cols_post_inv<3><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw, log_n2);
@@ -662,5 +662,8 @@ int rh_ring3n_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "3N transform launch failed: %s", hipGetErrorString(e));
   return RH_OK;
 }
+
+// tuning keys that must reach the radix-2 sub-ring as well (its tile stages choose their cache policy by size like any standard ring)
+void rh_ring3n_set_nt_streams(rh_ring* r, bool on) { if (r->s3n && r->s3n->sub) r->s3n->sub->nt_streams = on; }
 
 int rh_ring3n_reserve(rh_ring* r, int npoly) { return ensure_tmp(r->s3n, (size_t)npoly * r->L * r->N); }

@@ -90,6 +90,8 @@ def lib():
         "rh_ring_pad_default_to_ci": (i, [vp, i, vp, i, vp, i]),
         "rh_ntt_forward": (i, [vp, i, U64P, U64P]), "rh_ntt_forward_lazy": (i, [vp, i, U64P, U64P]),
         "rh_ntt_backward": (i, [vp, i, U64P, U64P]), "rh_ntt_backward_lazy": (i, [vp, i, U64P, U64P]),
+        "rh_ntt_poly_forward": (i, [vp, i, C.POINTER(vp), C.POINTER(vp), i]), "rh_ntt_poly_backward": (i, [vp, i, C.POINTER(vp), C.POINTER(vp), i]),
+        "rh_host_alloc": (i, [sz, C.POINTER(vp)]), "rh_host_free": (i, [vp]), "rh_host_register": (i, [vp, sz]), "rh_host_unregister": (i, [vp]),
         "rh_ring_ntt": (i, [vp, vp, vp, i, i, i]), "rh_ring_intt": (i, [vp, vp, vp, i, i, i]),
         "rh_ring_ntt_phase": (i, [vp, vp, vp, i, i, i, i]),
         "rh_ring_ntt_rows": (i, [vp, vp, i, vp, i, i, i, i]), "rh_ring_intt_rows": (i, [vp, vp, i, vp, i, i, i, i]),
@@ -187,6 +189,29 @@ class DevicePoly:
         if self._own and self.ptr:
             lib().rh_dev_free(None, self.ptr)      # the ring handle may already be closed; the free does not need it
             self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PinnedBuffer:
+    """page-locked host words (rh_host_alloc) as a numpy array: backing store for Poly.Coeffs that the engine DMAs without staging"""
+
+    def __init__(self, shape):
+        n = int(np.prod(shape))
+        p = C.c_void_p()
+        _check(lib().rh_host_alloc(n, C.byref(p)))
+        self.ptr = p.value
+        self.array = np.ctypeslib.as_array((C.c_uint64 * n).from_address(self.ptr)).reshape(shape)
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            lib().rh_host_free(self.ptr)
+            self.ptr = None
 
     def __del__(self):
         try:
@@ -336,6 +361,24 @@ class Ring:
     def INTT(self, p1, p2): self._ntt(p1, p2, True, 0)
     def INTTLazy(self, p1, p2): self._ntt(p1, p2, True, 1)
 
+    # ---- whole host polys: Ring.NTT(p1, p2 Poly) as the reference's callers issue it (ring/ntt.go:127-152) --------------------
+    def _host_poly(self, fn, p1, p2, lazy):
+        """p1 / p2: sequences of level+1 host limbs (numpy uint64 arrays of >= N words: Poly.Coeffs); p2[i] may be p1[i]"""
+        n = self.level + 1
+        if len(p1) < n or len(p2) < n:
+            raise RingHipError("cannot NTT: poly has %d / %d limbs, ring level needs %d" % (len(p1), len(p2), n))
+        for a in list(p1[:n]) + list(p2[:n]):
+            if a.dtype != np.uint64 or not a.flags["C_CONTIGUOUS"] or a.size < self.N:
+                raise RingHipError("cannot NTT: ensure that every limb is a contiguous uint64 slice of len >= N=%d" % self.N)
+        ins = (C.c_void_p * n)(*[a.ctypes.data for a in p1[:n]])
+        outs = (C.c_void_p * n)(*[a.ctypes.data for a in p2[:n]])
+        _check(fn(self._h, self.level, ins, outs, lazy))
+
+    def NTTHost(self, p1, p2): self._host_poly(lib().rh_ntt_poly_forward, p1, p2, 0)
+    def NTTLazyHost(self, p1, p2): self._host_poly(lib().rh_ntt_poly_forward, p1, p2, 1)
+    def INTTHost(self, p1, p2): self._host_poly(lib().rh_ntt_poly_backward, p1, p2, 0)
+    def INTTLazyHost(self, p1, p2): self._host_poly(lib().rh_ntt_poly_backward, p1, p2, 1)
+
     def NTT3NReorder(self, p1, p2, to_reference=True):
         """3N rings: NTT-domain block between block order (tuning ntt3n_block_order) and the Go transformer's order; out of place"""
         self._chk(p1, p2); _check(lib().rh_ring_ntt3n_reorder(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 1 if to_reference else 0))
@@ -376,12 +419,15 @@ class Ring:
         self._chk(polIn, polOut)
         _check(lib().rh_ring_automorphism_ntt(self._h, self.level, polIn.ptr, int(gen), polOut.ptr, polIn.npoly, 1))
 
-    def _index_table(self, index):
+    def _index_table(self, index, bound=1):
         """the lookup table as a device block: a DevicePoly of N words, or a host array uploaded for the call"""
         if isinstance(index, DevicePoly):
-            return index
-        arr = _u64(index).reshape(1, 1, self.N)
-        return DevicePoly.from_numpy(self.AtLevel(0), arr)
+            return index                   # a table already on the device is the caller's responsibility, like a Go slice index
+        arr = _u64(index).reshape(-1)
+        if arr.size != self.N or int(arr.max()) >= bound * self.N:
+            # the reference panics (index out of range) on such a table; the kernel would read out of bounds instead
+            raise RingHipError("index table needs N = %d entries below %d" % (self.N, bound * self.N))
+        return DevicePoly.from_numpy(self.AtLevel(0), arr.reshape(1, 1, self.N))
 
     def AutomorphismNTTWithIndex(self, polIn, index, polOut):
         """ring/automorphism.go:50-78: polOut[j] = polIn[index[j]] on every limb (index: AutomorphismNTTIndex or any permutation)"""
@@ -615,10 +661,7 @@ class Ring:
         if isinstance(permuteNTTIndexInv, DevicePoly):
             t = permuteNTTIndexInv
         else:
-            idx = _u64(permuteNTTIndexInv).reshape(-1)[:self.N]
-            if idx.size != self.N or int(idx.max()) >= 2 * self.N:
-                raise RingHipError("FoldStandardToConjugateInvariant: the index table needs N entries below 2N")
-            t = self._index_table(idx)
+            t = self._index_table(_u64(permuteNTTIndexInv).reshape(-1)[:self.N], bound=2)
         _check(lib().rh_ring_fold_standard_to_ci(self._h, self.level, polyStandard.ptr, t.ptr, polyConjugateInvariant.ptr, polyStandard.npoly))
 
     def PadDefaultRingToConjugateInvariant(self, polyStandard, IsNTT, polyConjugateInvariant):

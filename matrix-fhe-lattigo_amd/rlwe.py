@@ -170,6 +170,7 @@ class Evaluator:
         if ctQP.LevelP() < levelP:
             raise RingHipError("ctQP.LevelP()=%d < gadgetCt.LevelP()=%d" % (ctQP.LevelP(), levelP))
         self._rows(levelQ, dq, q0, q1)
+        self._rows(levelP, dp, p0, p1)          # the P accumulators are strided by levelP+1 rows per poly too
         _check(lib().rh_bext_gadget_product_hoisted_lazy(self.be._h, levelQ, levelP, dq.ptr, dp.ptr, gadgetCt.Q.ptr, gadgetCt.P.ptr,
                                                          gadgetCt.digits, q0.ptr, q1.ptr, p0.ptr, p1.ptr, q0.npoly))
         ctQP.IsNTT = True
@@ -206,6 +207,7 @@ class Evaluator:
             raise RingHipError("ModDown: the mixed-domain forms are not built on the device path")
         if ctQP.IsNTT:
             self._rows(levelQ, ct.Value[0], ct.Value[1], ctQP.Value[0].Q, ctQP.Value[1].Q)
+            self._rows(levelP, ctQP.Value[0].P, ctQP.Value[1].P)
             _check(lib().rh_bext_moddown_qp_to_q_ntt_pair(self.be._h, levelQ, levelP, ctQP.Value[0].Q.ptr, ctQP.Value[1].Q.ptr,
                                                           ctQP.Value[0].P.ptr, ctQP.Value[1].P.ptr, ct.Value[0].ptr, ct.Value[1].ptr,
                                                           ct.Value[0].npoly))
@@ -309,12 +311,14 @@ class Evaluator:
         tmp = ElementQP([PolyQP(self.buffer("lazyQ0", ringQ, npoly, levelQ + 1), self.buffer("lazyP0", ringP, npoly, levelP + 1)),
                          PolyQP(self.buffer("lazyQ1", ringQ, npoly, levelQ + 1), self.buffer("lazyP1", ringP, npoly, levelP + 1))])
         self.GadgetProductHoistedLazy(levelQ, c1DecompQP, evk, tmp)
-        ringQ.AutomorphismNTT(tmp.Value[1].Q, galEl, ctQP.Value[1].Q)                     # ringQP.AutomorphismNTTWithIndex (:135)
-        ringP.AutomorphismNTT(tmp.Value[1].P, galEl, ctQP.Value[1].P)
+        # "Result NTT domain is returned according to the NTT flag of ctQP" (:105): the flag only selects which index map is applied
+        # (:134-157) -- ringQP.AutomorphismNTTWithIndex or the coefficient-domain ringQP.Automorphism -- and is left as the caller set it
+        autQ, autP = (ringQ.AutomorphismNTT, ringP.AutomorphismNTT) if ctQP.IsNTT else (ringQ.Automorphism, ringP.Automorphism)
+        autQ(tmp.Value[1].Q, galEl, ctQP.Value[1].Q)                                      # ringQP.Automorphism(NTTWithIndex) (:136 / :147)
+        autP(tmp.Value[1].P, galEl, ctQP.Value[1].P)
         P = 1
         for p in self.ringP.moduli[:levelP + 1]:
             P *= int(p)
-        ringQ.MulScalarBigintThenAdd(ctIn.Value[0], P, tmp.Value[0].Q)                    # + ctIn[0] * P (:138, :141 as one pass: same canonical values)
-        ringQ.AutomorphismNTT(tmp.Value[0].Q, galEl, ctQP.Value[0].Q)                     # (:143)
-        ringP.AutomorphismNTT(tmp.Value[0].P, galEl, ctQP.Value[0].P)
-        ctQP.IsNTT = True
+        ringQ.MulScalarBigintThenAdd(ctIn.Value[0], P, tmp.Value[0].Q)                    # + ctIn[0] * P (:138-142 as one pass: same canonical values)
+        autQ(tmp.Value[0].Q, galEl, ctQP.Value[0].Q)                                      # (:144 / :155)
+        autP(tmp.Value[0].P, galEl, ctQP.Value[0].P)

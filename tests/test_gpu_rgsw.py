@@ -82,3 +82,37 @@ def test_external_product_single_p_and_bit_decomposition(rh, oracle, N, nq, leve
     ev.close(); rq.close()
     if rp is not None:
         rp.close()
+
+
+@pytest.mark.parametrize("N,pw2,levelP", [(4096, 0, 0), (4096, 20, 0), (8192, 16, -1), (4096, 0, -1)])
+def test_external_product_single_p_mixed_size_moduli(rh, oracle, N, pw2, levelP):
+    """the MaskVec digit of limb i (< q_i, or < 2^pw2) is used under EVERY modulus; with 61-, 41- and 37-bit primes in one chain it
+    exceeds the small ones by up to 2^24 x, far outside the [0, 8q) the forward transform's first stage assumes.  The kernel writes the
+    canonical residue per target limb; the oracle restates the reference (raw window into NTTLazy): both end in the same canonical bits."""
+    from oracle import compose
+    Q = [QI60[0], 0x10000140001, 0x10004a0001, QI60[1]]               # 61, 41, 37, 61 bits; all = 1 mod 2^17
+    P = [0x100003e0001]                                               # a 41-bit special modulus
+    nq, levelQ = len(Q), len(Q) - 1
+    rng = np.random.default_rng(N + pw2 + levelP + 5)
+    B = 2
+    rq = rh.Ring(N, Q)
+    rp = rh.Ring(N, P) if levelP == 0 else None
+    ev = rh.rgsw.Evaluator(rq, rp)
+    dpl = [-(-int(q).bit_length() // pw2) for q in Q] if pw2 else None
+    rows = sum(dpl) if pw2 else nq
+    kq = [_key(rng, rows, Q, N) for _ in (0, 1)]
+    kp = [_key(rng, rows, P, N) for _ in (0, 1)] if rp is not None else [None, None]
+    mk = lambda k: rh.rlwe.GadgetCiphertext(rq, rp, kq[k], kp[k], BaseTwoDecomposition=pw2, digits_per_limb=dpl)
+    rgsw = rh.rgsw.Ciphertext(mk(0), mk(1))
+    c = [np.stack([np.stack([uniform_mod(rng, q, N) for q in Q]) for _ in range(B)]) for _ in (0, 1)]
+    op0 = rh.Ciphertext([rh.DevicePoly.from_numpy(rq, c[0]), rh.DevicePoly.from_numpy(rq, c[1])], is_ntt=True)
+    out = rh.Ciphertext([rq.NewPoly(B), rq.NewPoly(B)], is_ntt=True)
+    ev.ExternalProduct(op0, rgsw, out)
+    g0, g1 = out.Value[0].numpy(), out.Value[1].numpy()
+    for k in range(B):
+        e0, e1 = compose.external_product_single_p(N, Q, P, levelQ, levelP, np.stack([c[0][k], c[1][k]]), pw2, dpl, kq, kp)
+        assert np.array_equal(g0[k], e0), "component 0, poly %d" % k
+        assert np.array_equal(g1[k], e1), "component 1, poly %d" % k
+    ev.close(); rq.close()
+    if rp is not None:
+        rp.close()

@@ -180,3 +180,54 @@ def test_gadget_product_lazy_and_decompose_single(rh, oracle):
         ev.DecomposeSingleNTT(levelQ, levelP, np_, d, pcx, inv, oq, op)
         assert np.array_equal(oq.numpy(), dq[d * 2:(d + 1) * 2]) and np.array_equal(op.numpy(), dp[d * 2:(d + 1) * 2])
     ev.close(); rq.close(); rp.close()
+
+
+def test_lazy_forms_refuse_batches_with_more_p_limbs_and_keep_the_flag(rh, oracle):
+    # the C entries stride the P accumulators by levelP+1 rows per poly, so a BATCH whose P part carries more limbs than
+    # gadgetCt.LevelP()+1 (allowed by the reference: ctQP.LevelP() >= levelP) must be refused, not strided wrongly; a single poly is fine.
+    N, nq = 4096, 5
+    Q, P3 = QI60[:nq], PI60[:3]
+    Q_, P, rq, rp, beta, evkQ, evkP, c0, c1 = make_case(rh, N, nq, 2, 2, 991)
+    rp3 = rh.Ring(N, P3)                                         # a P ring with one more limb than the key's
+    gal = 5
+    gct = rh.rlwe.GadgetCiphertext(rq, rp, evkQ, evkP)
+    ev = rh.rlwe.Evaluator(rq, rp, galois_keys={gal: gct})
+    levelQ, levelP = nq - 1, 1
+    ct = rh.Ciphertext([rh.DevicePoly.from_numpy(rq, c0), rh.DevicePoly.from_numpy(rq, c1)], is_ntt=True)
+    dec = ev.DecomposeNTT(levelQ, levelP, ct.Value[1], True)
+    wide = rh.rlwe.ElementQP.alloc(rq, rp3, 2, levelQ, 2)          # batch of 2, P blocks of 3 limbs: LevelP() = 2 > levelP = 1
+    assert wide.LevelP() == 2
+    with pytest.raises(rh.RingHipError):
+        ev.GadgetProductHoistedLazy(levelQ, dec, gct, wide)
+    out = rh.Ciphertext([rq.NewPoly(2), rq.NewPoly(2)], is_ntt=True)
+    with pytest.raises(rh.RingHipError):
+        ev.ModDown(levelQ, levelP, wide, out)
+    # one poly with more P limbs: leading limbs are contiguous, accepted and equal to the exact-size call
+    one = rh.Ciphertext([rh.DevicePoly.from_numpy(rq, c0[:1]), rh.DevicePoly.from_numpy(rq, c1[:1])], is_ntt=True)
+    dec1 = ev.DecomposeNTT(levelQ, levelP, one.Value[1], True)
+    w1 = rh.rlwe.ElementQP.alloc(rq, rp3, 1, levelQ, 2)
+    e1 = rh.rlwe.ElementQP.alloc(rq, rp, 1, levelQ, levelP)
+    ev.GadgetProductHoistedLazy(levelQ, dec1, gct, w1)
+    ev.GadgetProductHoistedLazy(levelQ, dec1, gct, e1)
+    for c in (0, 1):
+        assert np.array_equal(w1.Value[c].Q.numpy(), e1.Value[c].Q.numpy())
+        assert np.array_equal(w1.Value[c].P.numpy()[:, :2], e1.Value[c].P.numpy())
+    # AutomorphismHoistedLazy with ctQP.IsNTT == False (evaluator_automorphism.go:146-157): the coefficient-domain index map of
+    # ring.Automorphism is applied to the accumulators, and the caller's flag is left as it was
+    lzn = rh.rlwe.ElementQP.alloc(rq, rp, 2, levelQ, levelP); lzn.IsNTT = False
+    ev.AutomorphismHoistedLazy(levelQ, ct, dec, gal, lzn)
+    assert lzn.IsNTT is False
+    acc = rh.rlwe.ElementQP.alloc(rq, rp, 2, levelQ, levelP)
+    ev.GadgetProductHoistedLazy(levelQ, dec, gct, acc)
+    Pbig = int(P[0]) * int(P[1])
+    for c in (0, 1):
+        aq, ap = acc.Value[c].Q.numpy(), acc.Value[c].P.numpy()
+        for k in range(2):
+            for i, q in enumerate(Q):
+                x = aq[k, i]
+                if c == 0:
+                    x = ((x.astype(object) + c0[k, i].astype(object) * (Pbig % int(q))) % int(q)).astype(np.uint64)
+                assert np.array_equal(lzn.Value[c].Q.numpy()[k, i], oracle.automorphism(x, gal, int(q))), (c, k, i)
+            for j, p in enumerate(P):
+                assert np.array_equal(lzn.Value[c].P.numpy()[k, j], oracle.automorphism(ap[k, j], gal, int(p))), (c, k, j)
+    ev.close(); rq.close(); rp.close(); rp3.close()
