@@ -6,9 +6,12 @@
   value = polys transformed per second over all ranks (weak scaling: every rank owns its own batch; limbs and polys are
   independent, so there is no data-path collective -- torch.distributed only carries the barrier and the max-over-ranks).
 --workload keyswitch (BASELINE config 5): a step = rlwe.Evaluator.GadgetProduct (core/rlwe/evaluator_gadget_product.go:16-30)
-  of `--batch` polys at N = 2^16, Q = Qi60[0:24], P = Pi60[0:6], LIMB-sharded over the ranks (sharding.LimbShardedKeySwitch):
-  the one path with a real exchange step (all-gather of the digit's source limbs and of the P part, RCCL over xGMI).
-  value = key switches per second of the whole job (strong scaling: the same batch, limbs divided).
+  of `--batch` polys at N = 2^16, Q = Qi60[0:24], P = Pi60[0:6].  --shard limb (default, BASELINE's wording): LIMB-sharded over the
+  ranks (rh_kshard_gadget_product behind the C ABI; the one path with a real exchange step: all-gather of the source limbs and of the P
+  part, RCCL over xGMI, chunked so that an exchange runs under the other chunk's arithmetic).  --shard batch: the batch divided, the 120 MiB
+  key replicated, no collective (DESIGN.md 7 prices both).  value = key switches per second of the whole job (strong scaling).
+--gather (ntt workload): after the timed region, the north star's one collective -- the final gather of `--gather-polys` result polys per
+  rank as ONE all_gather_into_tensor on device memory (sharding.gather_polys) -- timed on its own and reported OUTSIDE `value`.
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (fresh processes, before
 any GPU call) and relays rank 0's JSON line; under torchrun (WORLD_SIZE set) it is one rank.
@@ -58,7 +61,25 @@ def parse():
     ap.add_argument("--asm-cols", type=int, default=-1, help="hand-scheduled column stages (default on)")
     ap.add_argument("--asm", type=int, default=-1, help="1/0: hand-scheduled vs C++ tile kernels; -1 = engine default")
     ap.add_argument("--tune", action="append", default=[], help="key=value for rh_ring_set_tuning (repeatable)")
+    ap.add_argument("--shard", default="limb", choices=["limb", "batch"], help="keyswitch workload: limb-shard (exchange steps) or batch-shard (key replicated, no collective)")
+    ap.add_argument("--chunks", type=int, default=0, help="keyswitch --shard limb: chunks of the batch pipelined on two streams (0 = auto: 4 on more than one rank)")
+    ap.add_argument("--gather", action="store_true", help="ntt workload: time the final device-tensor gather of result polys (outside `value`)")
+    ap.add_argument("--gather-polys", type=int, default=64, help="polys per rank in the --gather leg (64 -> 512 MiB per rank at the default shape)")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0, help="--gpus N without a launcher: the parent gives up (and stops its ranks) after this many seconds")
     return ap.parse_args()
+
+
+def csrc_tree_hash():
+    """sha256 (16 hex digits) over the kernel sources libringhip.so is built from: ties a counter file under profiles/ to the code it was
+    collected on (the GPU box has no .git, so this is a content hash, not `git rev-parse HEAD:.../csrc`)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "matrix-fhe-lattigo_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".inc")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def spawn_ranks(args):
@@ -68,6 +89,8 @@ def spawn_ranks(args):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # this pool's host driver only supports dmabuf IPC: without it RCCL's intra-node buffer exchange (and any CUDA-IPC tensor sharing)
+        # fails with `hipIpcGetMemHandle: invalid argument`.  The image exports it already; kept for a shell that dropped the variable.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
@@ -77,12 +100,17 @@ def spawn_ranks(args):
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
     failed = False
+    t_start = time.time()
     while True:
         rcs = [p.poll() for p in procs]
         if any(rc not in (None, 0) for rc in rcs):
             failed = True
             break
         if all(rc == 0 for rc in rcs):
+            break
+        if time.time() - t_start > args.rank_timeout:       # a hang no rank dies of (e.g. a collective one rank never enters)
+            sys.stderr.write("bench.py: ranks still running after %.0f s, stopping them\n" % args.rank_timeout)
+            failed = True
             break
         time.sleep(0.2)
     if failed:
@@ -148,11 +176,26 @@ def timed_region(step, args, dist, dev, stream):
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)
+    per_rank = {"device_ms_per_step": [dev_ms / args.steps]}
     if dist is not None:
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev_ms = float(t[0]), float(t[1])
-    return wall, dev_ms
+        cdev = dev if args.dist_backend == "nccl" else "cpu"
+        mine = torch.tensor([wall, dev_ms], dtype=torch.float64, device=cdev)
+        every = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)                       # every rank's own clock: an imbalanced node shows here
+        per_rank = {"device_ms_per_step": [float(t[1]) / args.steps for t in every]}
+        wall, dev_ms = max(float(t[0]) for t in every), max(float(t[1]) for t in every)
+    per_rank["min"], per_rank["max"] = min(per_rank["device_ms_per_step"]), max(per_rank["device_ms_per_step"])
+    return wall, dev_ms, per_rank
+
+
+def all_ranks_ok(ok, args, dist, dev):
+    """AND of a per-rank flag over the job (every rank verifies its own output)"""
+    import torch
+    if dist is None:
+        return bool(ok)
+    flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item() == 1.0)
 
 
 def cpu_model():
@@ -298,27 +341,60 @@ def run_ntt(args):
         data[b0:b0 + blk.shape[0]] = blk % qs
     poly = rh.DevicePoly.from_torch(ring, data)
     spots = sorted({(0, 0), (min(B - 1, B // 2 + 1), min(L - 1, 7)), (B - 1, L - 1)})
-    saved = {s: data[s[0], s[1]].cpu().numpy().view(np.uint64).copy() for s in spots} if rank == 0 else {}
+    saved = {s: data[s[0], s[1]].cpu().numpy().view(np.uint64).copy() for s in spots}      # every rank verifies its own batch
 
     def step():
         ring.NTT(poly, poly)
 
-    wall, dev_ms = timed_region(step, args, dist, dev, stream)
+    wall, dev_ms, per_rank = timed_region(step, args, dist, dev, stream)
     ring.sync()
-    # verification of the timed region's own output (rank 0): the buffer has been transformed warmup + steps times in place
+    # verification of the timed region's own output, on EVERY rank: the buffer has been transformed warmup + steps times in place
     verified = None
-    if rank == 0 and not args.no_verify:
+    if not args.no_verify:
         import oracle
         k = args.warmup + args.steps
-        verified = True
+        ok = True
         for (p, l), x in saved.items():
             sr = oracle.SubRingConsts(N, mods[l])
             for _ in range(k):
                 x = oracle.ntt(x, sr)
             if not np.array_equal(data[p, l].cpu().numpy().view(np.uint64), x):
-                verified = False
-        if not verified:
-            sys.stderr.write("bench.py: OUTPUT MISMATCH vs oracle after %d forward transforms\n" % k)
+                ok = False
+        if not ok:
+            sys.stderr.write("bench.py: rank %d: OUTPUT MISMATCH vs oracle after %d forward transforms\n" % (rank, k))
+        verified = all_ranks_ok(ok, args, dist, dev)
+
+    # the final gather of results (north star: "RCCL over xGMI used only for the final gather"), timed on its own, never part of `value`
+    gather = None
+    if args.gather:
+        from matrix_fhe_lattigo_amd import sharding
+        gp = max(1, min(args.gather_polys, B))
+        block = data[:gp]
+        out = torch.empty((world, gp, L, N), dtype=torch.int64, device=dev)
+        sharding.gather_polys(block, dist, out=out)                                 # warm-up (RCCL builds its rings on first use)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            sharding.gather_polys(block, dist, out=out)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        g_ms = (time.perf_counter() - t0) * 1e3 / reps
+        # what arrived: this rank's slot is its own block; every other slot carries that rank's fingerprint (exchanged apart, tiny)
+        fp = block[0, 0, :8].cpu()
+        fps = [fp]
+        if dist is not None:
+            fps = [torch.empty_like(fp) for _ in range(world)]
+            dist.all_gather(fps, fp)
+        ok = bool(torch.equal(out[rank], block)) and all(bool(torch.equal(out[r, 0, 0, :8].cpu(), fps[r])) for r in range(world))
+        recv = (world - 1) * gp * L * N * 8
+        gather = {"ms": g_ms, "polys_per_rank": gp, "bytes_received_per_gpu": recv, "GBps_received_per_gpu": recv / (g_ms * 1e-3) / 1e9 if world > 1 else None,
+                  "verified": all_ranks_ok(ok, args, dist, dev),
+                  "what": "one all_gather_into_tensor of every rank's (%d, %d, %d) result block (sharding.gather_polys), %s; outside `value`"
+                          % (gp, L, N, "RCCL" if args.dist_backend == "nccl" else "host-staged over " + args.dist_backend)}
 
     # per-kernel device time (HIP events on the same stream), outside the timed region
     kern = {}
@@ -345,12 +421,20 @@ def run_ntt(args):
     alg_bytes = 16.0 * N * L * B                        # 16*N bytes per limb transform (8 in + 8 out)
     launch_ms = dev_ms / args.steps                     # device time of one whole forward transform of the batch
     achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, stale = None, None
+    tree = csrc_tree_hash()
     tj = load_json("latest_traffic.json")
     if tj and tj.get("config", {}).get("logn") == args.logn and tj.get("config", {}).get("limbs") == L:
-        traffic = tj["hbm_bytes_per_poly"] * B          # PMC-measured bytes (profiles/), valid for the profiled shape only
+        if tj.get("csrc_tree") == tree:
+            traffic = tj["hbm_bytes_per_poly"] * B      # PMC-measured bytes (profiles/), valid for the profiled shape and THESE sources only
+        else:
+            stale = "profiles/latest_traffic.json was collected on csrc tree %s, this run is %s: refresh with tools/refresh_profiles.sh" % (tj.get("csrc_tree"), tree)
     # what is actually launched inside the timed region (engine.hip: rh_std_ntt_launch)
-    span = max(1, 2048 // L)
+    span_rows = 2048
+    for kv in args.tune:
+        if kv.split("=")[0] == "auto_span_rows":
+            span_rows = int(kv.split("=")[1])
+    span = max(1, span_rows // L)
     chunk = args.chunk if args.chunk >= 0 else (span if B > span else 0)   # engine.hip auto rule
     if args.logn > 12 and chunk > 0 and B > chunk:
         launches = -(-B // chunk) + 1
@@ -358,13 +442,19 @@ def run_ntt(args):
                  "(first and last carry one half), each moves the algorithmic bytes of one span's whole transform" % (args.logn - 12, chunk, launches))
     else:
         launches, kname = (2 if args.logn > 12 else 1), "ntt_fwd_cols + ntt_fwd_tile_asm (two launches = one forward transform)"
-    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+    # "bound": the roofline the fraction is quoted against (the north star's: HBM).  "limited_by": what measurably binds this kernel --
+    # the 1400 W package cap under full-rate 64-bit VALU work + 4.8 TB/s of fabric traffic (roofline.power / .valu below)
+    roof = {"bound": "hbm", "limited_by": "power/valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": (traffic / launches) if traffic is not None else None,      # PMC bytes per launch, like algorithmic_bytes_per_launch
+            "traffic_note": stale, "csrc_tree": tree,
             "traffic_per_step": traffic, "kernel": kname, "launches_per_step": launches,
             "avg_launch_ms": launch_ms / launches, "algorithmic_bytes_per_launch": alg_bytes / launches,
             "algorithmic_bytes_per_step": alg_bytes, "device_ms_per_step": launch_ms, "standalone_kernel_ms": kern}
-    vj = load_json("latest_valu.json")                  # SQ_INSTS_VALU per step + measured issue peak (profiles/), profiled shape only
-    if vj and vj.get("config", {}).get("logn") == args.logn and vj.get("config", {}).get("limbs") == L:
+    vj = load_json("latest_valu.json")                  # SQ_INSTS_VALU per step + measured issue peak (profiles/), profiled shape and sources only
+    if vj and vj.get("config", {}).get("logn") == args.logn and vj.get("config", {}).get("limbs") == L and vj.get("csrc_tree") != tree:
+        roof["valu"] = None
+        roof["valu_note"] = "profiles/latest_valu.json was collected on csrc tree %s, this run is %s" % (vj.get("csrc_tree"), tree)
+    elif vj and vj.get("config", {}).get("logn") == args.logn and vj.get("config", {}).get("limbs") == L:
         winstr = vj["valu_wave_instructions_per_poly"] * B
         issue = winstr / (launch_ms * 1e-3) / 1e9
         roof["valu"] = {"note": "the transform is VALU-issue bound before it is HBM-bound (DESIGN.md 3): 64-bit modular butterflies, no MFMA-shaped work",
@@ -377,7 +467,7 @@ def run_ntt(args):
         # the package power cap, not a pipeline, sets the clock this kernel runs at: both ceilings above are
         # quoted at the 2.4 GHz the chip holds for pure VALU streams; at the clock measured under THIS kernel they scale by sclk / 2400
         roof["power"] = power
-        if traffic is not None and "valu" in roof and power.get("package_cap_w"):
+        if traffic is not None and roof.get("valu") and power.get("package_cap_w"):
             # energy floor of this design at the cap (constants measured on this chip, profiles/r02_mem_power_l2_mall.txt,
             # profiles/r02_power_clock_samples.txt): HBM-path traffic 0.137 nJ per byte, a VALU wave-instruction of this mix ~1.1 nJ,
             # 291 W drawn idle; (traffic + arithmetic energy) / (cap - idle) = the time the cap allows for one step
@@ -385,7 +475,7 @@ def run_ntt(args):
             floor_ms = (e_mem + e_valu) / (power["package_cap_w"] - idle_w) * 1e3
             roof["power"]["energy_model"] = {"traffic_J_per_step": e_mem, "valu_J_per_step": e_valu, "idle_w": idle_w,
                                              "floor_ms_per_step_at_cap": floor_ms, "frac_of_floor": floor_ms / launch_ms}
-        if "valu" in roof:
+        if roof.get("valu"):
             k = power["sclk_mhz_under_load"] / power["sclk_peak_mhz"]
             roof["valu"]["issue_peak_at_measured_clock_Gwinstr_per_s"] = roof["valu"]["issue_peak_Gwinstr_per_s"] * k
             roof["valu"]["frac_of_issue_peak_at_measured_clock"] = roof["valu"]["frac_of_issue_peak"] / k
@@ -396,9 +486,12 @@ def run_ntt(args):
         "dtype": "u64", "data": "synthetic", "verified": verified,
         "config": {"workload": "Ring.NTT forward, N=2^%d, %d limbs (Qi60[0:%d]), batch %d polys/GPU, in place, device-resident" % (args.logn, L, L, B),
                    "parallelism": "batch-shard x%d, no data-path collective" % world, "limb_ntt_per_s": value * L,
-                   "dist_backend": args.dist_backend if world > 1 else None, "rccl_ranks" if args.dist_backend == "nccl" else "dist_ranks": ranks_seen},
+                   "dist_backend": args.dist_backend if world > 1 else None, "rccl_ranks" if args.dist_backend == "nccl" else "dist_ranks": ranks_seen,
+                   "per_rank_device_ms_per_step": per_rank, "verified_on": "every rank (its own batch, %d spot rows each)" % len(spots)},
         "roofline": roof,
     }
+    if gather is not None:
+        out["final_gather"] = gather
     if world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args, N, mods)
     print(json.dumps(out), flush=True)
@@ -417,10 +510,21 @@ def run_keyswitch(args):
     B = args.batch if args.batch > 0 else 64
     Q, P = QI60[:24], PI60[:6]
     nq, npl = len(Q), len(P)
-    ks = sharding.LimbShardedKeySwitch(N, Q, P, rank, world, dist=dist if world > 1 else None, device=local_rank)
-    beta = ks.beta
+    limb = args.shard == "limb"
     stream = torch.cuda.current_stream()
-    # synthetic inputs: the SAME (seeded) full-size case on every rank, each keeps its limbs (uniform key: SURVEY 8d)
+    ks = be = None
+    if limb:
+        ks = sharding.LimbShardedKeySwitch(N, Q, P, rank, world, dist=dist if world > 1 else None, device=local_rank)
+        beta, ownQ, ownP = ks.beta, ks.ownQ, ks.ownP
+        lo, hi = 0, B                                                   # every rank works on the whole batch, on its limbs
+    else:
+        ringQ, ringP = rh.Ring(N, Q, device=local_rank), rh.Ring(N, P, device=local_rank)
+        ringQ.set_stream(stream.cuda_stream); ringP.set_stream(stream.cuda_stream)
+        be = rh.BasisExtender(ringQ, ringP)
+        beta, ownQ, ownP = (nq - 1 + npl) // npl, list(range(nq)), list(range(npl))
+        lo, hi = sharding.poly_shard(B, rank, world)                   # this rank's polys, all limbs, the whole key
+    nb = hi - lo
+    # synthetic inputs: the SAME (seeded) full-size case on every rank, each keeps its limbs / polys (uniform key: SURVEY 8d)
     g = torch.Generator(device=dev)
 
     def limb_rows(seed, nlead, mods, i):
@@ -428,57 +532,78 @@ def run_keyswitch(args):
         g.manual_seed(seed * 1000 + i)
         return torch.randint(0, 1 << 62, (nlead, N), dtype=torch.int64, device=dev, generator=g) % mods[i]
 
-    def rows(seed, lead, mods, own):
-        out = torch.empty(tuple(lead) + (len(own), N), dtype=torch.int64, device=dev)
+    def rows(seed, lead, mods, own, sl=None):
+        n0 = 1
+        for d in lead:
+            n0 *= d
+        sel = slice(0, n0) if sl is None else sl            # sl: a range of the (single) leading axis -- this rank's polys
+        shape = tuple(lead) if sl is None else (sel.stop - sel.start,)
+        out = torch.empty(shape + (len(own), N), dtype=torch.int64, device=dev)
         flat = out.view(-1, len(own), N)
         for k, i in enumerate(own):
-            flat[:, k] = limb_rows(seed, flat.shape[0], mods, i)
+            flat[:, k] = limb_rows(seed, n0, mods, i)[sel]
         return out
-    cx = rows(1, (B,), Q, ks.ownQ)
-    evkQ = rows(2, (beta, 2), Q, ks.ownQ)
-    evkP = rows(3, (beta, 2), P, ks.ownP) if ks.ownP else None
+    cx = rows(1, (B,), Q, ownQ, slice(lo, hi))
+    evkQ = rows(2, (beta, 2), Q, ownQ)
+    evkP = rows(3, (beta, 2), P, ownP) if ownP else None
     ct0, ct1 = torch.empty_like(cx), torch.empty_like(cx)
+    if limb:
+        def step():
+            ks.GadgetProduct(cx, evkQ, evkP, ct0, ct1, chunks=args.chunks)
+    else:
+        dp = lambda ring, t: rh.DevicePoly.from_torch(ring, t.view(-1, t.shape[-2], N))
+        pcx, p0, p1 = dp(ringQ, cx), dp(ringQ, ct0), dp(ringQ, ct1)
 
-    def step():
-        ks.GadgetProduct(cx, evkQ, evkP, ct0, ct1)
+        def step():
+            if nb:
+                be.GadgetProduct(nq - 1, npl - 1, pcx, evkQ.data_ptr(), evkP.data_ptr(), beta, p0, p1)
 
-    wall, dev_ms = timed_region(step, args, dist, dev, stream)
+    wall, dev_ms, per_rank = timed_region(step, args, dist, dev, stream)
+    exch = {"exchanges_per_product": ks.exchanges, "bytes_received_per_gpu_per_product": ks.exchange_words * 8} if limb else None
     verified = None
-    if not args.no_verify:                                 # poly 0 of this rank's owned limbs against the oracle composition
+    if not args.no_verify:                                 # EVERY rank: first, middle and last poly of its share against the oracle composition
         from oracle import compose
         host = lambda t: t.cpu().numpy().view(np.uint64)
-        cx_f = np.stack([host(limb_rows(1, B, Q, i)[0]) for i in range(nq)])                                   # poly 0, every limb
         ekq = np.stack([host(limb_rows(2, beta * 2, Q, i)) for i in range(nq)], axis=1).reshape(beta, 2, nq, N)
         ekp = np.stack([host(limb_rows(3, beta * 2, P, j)) for j in range(npl)], axis=1).reshape(beta, 2, npl, N)
-        e0, e1 = compose.gadget_product(N, Q, P, nq - 1, npl - 1, cx_f, ekq, ekp)
-        ok = np.array_equal(host(ct0[0]), e0[ks.ownQ]) and np.array_equal(host(ct1[0]), e1[ks.ownQ])
-        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        if dist is not None:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        verified = bool(flag.item() == 1.0)
+        ok = True
+        for k in sorted({0, nb // 2, nb - 1}) if nb else []:
+            cx_f = np.stack([host(limb_rows(1, B, Q, i)[lo + k]) for i in range(nq)])                          # poly lo + k, every limb
+            e0, e1 = compose.gadget_product(N, Q, P, nq - 1, npl - 1, cx_f, ekq, ekp)
+            ok = ok and np.array_equal(host(ct0[k]), e0[ownQ]) and np.array_equal(host(ct1[k]), e1[ownQ])
+        if not ok:
+            sys.stderr.write("bench.py: rank %d: key-switch OUTPUT MISMATCH vs the oracle composition\n" % rank)
+        verified = all_ranks_ok(ok, args, dist, dev)
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         value = B * args.steps / wall
         launch_ms = dev_ms / args.steps
         # limb transforms x 16 N + the evaluation-key read 2 beta (L+k) 8 N, whole job
         limb_ntts = nq + beta * (nq + npl) - nq + 2 * (npl + nq)      # INTT(cx) + per digit NTTs (own limbs skipped: -nq in total) + 2 ModDowns
-        alg = B * limb_ntts * 16.0 * N + 2.0 * beta * (nq + npl) * 8.0 * N
+        alg = B * limb_ntts * 16.0 * N + 2.0 * beta * (nq + npl) * 8.0 * N * (1 if limb else world)   # batch-shard: every rank reads the whole key
         achieved = alg / (launch_ms * 1e-3) / 1e9
+        par = ("limb-shard x%d (round-robin over Q++P): orchestration behind the C ABI (rh_kshard_gadget_product), %s chunks on two streams, two "
+               "all-gathers per chunk (source limbs, P parts)" % (world, args.chunks or "auto")) if limb else \
+              "batch-shard x%d: %s polys per rank, the 120 MiB key replicated, no data-path collective" % (world, "/".join(str(sharding.poly_shard(B, r, world)[1] - sharding.poly_shard(B, r, world)[0]) for r in range(world)))
         out = {
-            "metric": "key-switch (hybrid gadget product)/s at N=2^%d, %d Q + %d P moduli, limb-sharded" % (args.logn, nq, npl),
+            "metric": "key-switch (hybrid gadget product)/s at N=2^%d, %d Q + %d P moduli, %s-sharded" % (args.logn, nq, npl, args.shard),
             "value": value, "unit": "key-switch/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic", "verified": verified,
             "config": {"workload": "rlwe.Evaluator.GadgetProduct, N=2^%d, Q=Qi60[0:24], P=Pi60[0:6], beta=%d, batch %d polys per step (whole job), "
                                    "uniform key shared by the batch" % (args.logn, beta, B),
-                       "parallelism": "limb-shard x%d (round-robin over Q++P), one all-gather of the source limbs and one of the P parts per product" % world,
-                       "dist_backend": args.dist_backend if world > 1 else None, "rccl_ranks" if args.dist_backend == "nccl" else "dist_ranks": ranks_seen},
+                       "parallelism": par, "shard": args.shard, "exchange": exch,
+                       "dist_backend": args.dist_backend if world > 1 else None, "rccl_ranks" if args.dist_backend == "nccl" else "dist_ranks": ranks_seen,
+                       "per_rank_device_ms_per_step": per_rank, "verified_on": "every rank (first, middle, last poly of its share, owned limbs)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * world),
                          "traffic": None, "kernel": "whole gadget product (%d limb transforms + key multiply-accumulate + basis extensions per poly)" % limb_ntts,
                          "algorithmic_bytes_per_step": alg, "device_ms_per_step": launch_ms},
         }
         print(json.dumps(out), flush=True)
-    ks.close()
+    if ks is not None:
+        ks.close()
+    if be is not None:
+        be.close(); ringQ.close(); ringP.close()
     if dist is not None:
         dist.destroy_process_group()
 

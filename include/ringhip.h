@@ -358,6 +358,32 @@ int rh_kshard_product(rh_kshard* ks, const uint64_t* src_all_dev, const uint64_t
  * INTTLazy of the P part gathered from its owners. */
 int rh_kshard_moddown(rh_kshard* ks, const uint64_t* srcP_dev, const uint64_t* ctQ_in_loc, uint64_t* ctQ_out_loc, int npoly);
 
+
+/* The WHOLE limb-sharded product in one call, orchestration included: ringQ.INTT(cx) -> exchange of every limb of INTT(cx) ->
+ * gadgetProductMultiplePLazy on the owned limbs -> INTTLazy of the owned P limbs -> exchange of the P part of both accumulators ->
+ * ModDownQPtoQNTT on the owned Q limbs (core/rlwe/evaluator_gadget_product.go:16-30, 33-46, 122-188, 455-478).  The library still never
+ * communicates: both exchanges are calls of `allgather`, which the HOST supplies -- ncclAllGather on the node's RCCL communicator from a cgo
+ * host, torch.distributed from Python (sharding.LimbShardedKeySwitch).
+ *   rh_allgather_fn(ctx, send_dev, recv_dev, send_words, hip_stream): every rank contributes send_words uint64 at send_dev and receives
+ *       world * send_words at recv_dev, rank-major (the semantics of ncclAllGather), ENQUEUED on hip_stream; 0 on success.  All ranks make
+ *       the same sequence of calls (two per chunk), so the collectives match up.
+ *   rh_kshard_set_world: the owner of every limb of Q ++ P (owner[i], i <= levelQ: Q limb i; owner[levelQ+1+j]: P limb j); the entries equal
+ *       to `rank` must be exactly the owned limbs the handle was created with.  A handle that owns every limb needs no map (world = 1).
+ *   chunks: the batch is cut into this many chunks alternating between two side streams, so that one chunk's exchange runs under the other's
+ *       arithmetic (<= 0: auto = 4 for npoly >= 4 on more than one rank, else 1).  The call returns with everything enqueued; the ring's
+ *       stream (rh_ring_set_stream of the local Q ring) waits for the side streams, so the caller synchronises as for any other entry.
+ *   rh_kshard_exchange_words / rh_kshard_set_exchange: optional.  The exchange blocks are carved from memory the library allocates, unless
+ *       the host registers an arena of at least rh_kshard_exchange_words(...) words (a host whose all-gather must map the pointers it is
+ *       handed back to its own buffer objects, e.g. torch tensors).
+ * cx_loc, ct0_loc, ct1_loc: (npoly, owned Q limbs, N); evkQ_loc / evkP_loc: [digit][component < 2][owned limb][N].  Outputs stay limb-sharded,
+ * every owned limb bit-identical to the same limb of rh_bext_gadget_product. */
+typedef int (*rh_allgather_fn)(void* ctx, const uint64_t* send_dev, uint64_t* recv_dev, size_t send_words, void* hip_stream);
+int rh_kshard_set_world(rh_kshard* ks, int world, int rank, const int* owner);
+int rh_kshard_exchange_words(const rh_kshard* ks, int npoly, int chunks, size_t* words);
+int rh_kshard_set_exchange(rh_kshard* ks, uint64_t* arena_dev, size_t words);
+int rh_kshard_gadget_product(rh_kshard* ks, const uint64_t* cx_loc, const uint64_t* evkQ_loc, const uint64_t* evkP_loc,
+                             uint64_t* ct0_loc, uint64_t* ct1_loc, int npoly, rh_allgather_fn allgather, void* ctx, int chunks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1034,15 +1034,19 @@ static int ntt_host_poly(rh_ring* r, int level, const uint64_t* const* p1, uint6
   }
   // groups: enough bytes per group to amortise a launch pair (>= 256 KiB), at most 4
   int G = (int)(((size_t)Lr * bytes) / ((size_t)256 << 10)); if (G > 4) G = 4; if (G > Lr) G = Lr; if (G < 1) G = 1;
-  int used = 0;
-  for (int g = 0; g < G && !rc; ++g, ++used) {
+  // the host side of every limb: the caller's slice when it is page-locked, else its place in the staging blocks.  Limbs that are adjacent in
+  // host memory move as ONE copy (a copy costs ~10 us to issue and start whatever its size): always the case for staged limbs, and for a
+  // Poly whose limbs were carved from one page-locked allocation
+  const u64* hsrc[RH_MAX_LIMBS]; u64* hdst[RH_MAX_LIMBS];
+  for (int i = 0; i < Lr; ++i) { hsrc[i] = pin_in[i] ? p1[i] : sl->hin + (size_t)i * N; hdst[i] = pin_out[i] ? p2[i] : sl->hout + (size_t)i * N; }
+  for (int g = 0; g < G && !rc; ++g) {
     const int g0 = (int)((long)Lr * g / G), g1 = (int)((long)Lr * (g + 1) / G);
     hipStream_t st = sl->st[g & 1];
     hipError_t e = hipSuccess;
-    for (int i = g0; i < g1 && e == hipSuccess; ++i) {
-      const u64* src = p1[i];
-      if (!pin_in[i]) { memcpy(sl->hin + (size_t)i * N, p1[i], bytes); src = sl->hin + (size_t)i * N; }
-      e = hipMemcpyAsync(sl->dbuf + (size_t)i * N, src, bytes, hipMemcpyHostToDevice, st);
+    for (int i = g0; i < g1; ++i) if (!pin_in[i]) memcpy(sl->hin + (size_t)i * N, p1[i], bytes);
+    for (int i = g0, j; i < g1 && e == hipSuccess; i = j) {
+      for (j = i + 1; j < g1 && hsrc[j] == hsrc[j - 1] + N; ++j) {}
+      e = hipMemcpyAsync(sl->dbuf + (size_t)i * N, hsrc[i], (size_t)(j - i) * bytes, hipMemcpyHostToDevice, st);
     }
     if (e != hipSuccess) { rc = rh_fail(RH_ERR_DEVICE, "H2D: %s", hipGetErrorString(e)); break; }
     {
@@ -1052,9 +1056,9 @@ static int ntt_host_poly(rh_ring* r, int level, const uint64_t* const* p1, uint6
          : (r->kind == RH_RING_CI) ? ci_ntt_launch(r, d, d, 1, g1 - g0, g0, inverse)
                                    : rh_std_ntt_launch(r, d, d, 1, g1 - g0, g0, inverse, lazy, 0);
     }
-    for (int i = g0; i < g1 && !rc; ++i) {
-      u64* dst = pin_out[i] ? p2[i] : sl->hout + (size_t)i * N;
-      e = hipMemcpyAsync(dst, sl->dbuf + (size_t)i * N, bytes, hipMemcpyDeviceToHost, st);
+    for (int i = g0, j; i < g1 && !rc; i = j) {
+      for (j = i + 1; j < g1 && hdst[j] == hdst[j - 1] + N; ++j) {}
+      e = hipMemcpyAsync(hdst[i], sl->dbuf + (size_t)i * N, (size_t)(j - i) * bytes, hipMemcpyDeviceToHost, st);
       if (e != hipSuccess) rc = rh_fail(RH_ERR_DEVICE, "D2H: %s", hipGetErrorString(e));
     }
     if (!rc && hipEventRecord(sl->done[g], st) != hipSuccess) rc = rh_fail(RH_ERR_DEVICE, "hipEventRecord failed");

@@ -27,19 +27,29 @@ struct rh_kshard {
   std::map<int, BextPlan> digit_plans;
   BextPlan md_plan; bool have_md = false;
   std::vector<u64> md_scalars;                           // q_k - (P^-1 mod q_k) Montgomery form, per owned Q limb
-  u64* buf[5] = {}; size_t buf_words[5] = {};           // c2Q, c2P, buffQ; 3, 4: all digits' c2Q / c2P (rh_kshard_product)
+  // scratch per pipeline slot (rh_kshard_gadget_product runs chunks of the batch on two streams): 0 c2Q, 1 c2P, 2 buffQ; 3, 4: all digits'
+  // c2Q / c2P (rh_kshard_product); 5 cxinv, 6 accP (both components), 7 gathered source limbs in chain order, 8 send, 9 recv (exchange)
+  u64* buf[2][10] = {}; size_t buf_words[2][10] = {};
+  int slot = 0;                                          // slot the calling orchestrator is enqueueing (under mu)
   int reduce = 0, QiOverF = 1, PiOverF = 1;
+  // whole-product orchestration (rh_kshard_gadget_product): who owns which limb of Q ++ P, side streams for the chunk pipeline
+  int world = 1, rank = 0;
+  std::vector<int> owner;                                // owner[i] for i < levelQ+1 (Q), owner[levelQ+1+j] (P)
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  u64* arena = nullptr; size_t arena_words = 0;          // caller-registered exchange memory (send / recv blocks are carved from it)
   std::recursive_mutex mu;                               // one key switch at a time per handle (digits are fed in order)
 };
 
 static int ks_buf(rh_kshard* ks, int which, size_t words, u64** out) {
-  if (ks->buf_words[which] < words) {
-    if (ks->buf[which]) (void)hipFree(ks->buf[which]);
-    ks->buf[which] = nullptr; ks->buf_words[which] = 0;
-    if (hipMalloc((void**)&ks->buf[which], (words ? words : 1) * 8) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc(key-switch shard scratch) failed");
-    ks->buf_words[which] = words;
+  const int sl = ks->slot;
+  if (ks->buf_words[sl][which] < words) {
+    if (ks->buf[sl][which]) (void)hipFree(ks->buf[sl][which]);           // hipFree waits for the device: never frees under a running kernel
+    ks->buf[sl][which] = nullptr; ks->buf_words[sl][which] = 0;
+    if (hipMalloc((void**)&ks->buf[sl][which], (words ? words : 1) * 8) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc(key-switch shard scratch) failed");
+    ks->buf_words[sl][which] = words;
   }
-  *out = ks->buf[which];
+  *out = ks->buf[sl][which];
   return 0;
 }
 
@@ -77,7 +87,9 @@ extern "C" void rh_kshard_destroy(rh_kshard* ks) {
   if (!ks) return;
   for (auto& kv : ks->digit_plans) rh_bext_free_plan(kv.second);
   if (ks->have_md) rh_bext_free_plan(ks->md_plan);
-  for (int i = 0; i < 5; ++i) if (ks->buf[i]) (void)hipFree(ks->buf[i]);
+  for (int sl = 0; sl < 2; ++sl) for (int i = 0; i < 10; ++i) if (ks->buf[sl][i]) (void)hipFree(ks->buf[sl][i]);
+  for (int k = 0; k < 2; ++k) { if (ks->side[k]) (void)hipStreamDestroy(ks->side[k]); if (ks->ev_join[k]) (void)hipEventDestroy(ks->ev_join[k]); }
+  if (ks->ev_fork) (void)hipEventDestroy(ks->ev_fork);
   delete ks;
 }
 
@@ -254,4 +266,171 @@ extern "C" int rh_kshard_moddown(rh_kshard* ks, const uint64_t* srcP, const uint
   if (rh_can_fuse_submul(RQ)) return rh_std_ntt_submul_launch(RQ, buffQ, npoly, nQ, 0, ctQ_in, nQ, ctQ_out, nQ, ks->md_scalars.data());
   if (int rc = rh_std_ntt_launch(RQ, buffQ, buffQ, npoly, nQ, 0, false, false, 0)) return rc;
   return rh_vec_launch(RQ, RH_OP_SUB_THEN_MUL_SCALAR_MONT_TWO_MODULUS, buffQ, ctQ_in, ctQ_out, npoly, nQ, 0, ks->md_scalars.data(), nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The whole limb-sharded product behind the C ABI: rlwe.Evaluator.GadgetProduct (core/rlwe/evaluator_gadget_product.go:16-30) =
+// ringQ.INTT(cx) (:138) -> [exchange: every limb of INTT(cx)] -> gadgetProductMultiplePLazy on the owned limbs (:122-188, DecomposeSingleNTT
+// :455-478) -> INTTLazy of the owned P limbs -> [exchange: the P part of both accumulators] -> ModDownQPtoQNTT on the owned Q limbs (:33-46).
+// The library still never communicates: the two exchanges are calls of the host's all-gather (RCCL ncclAllGather from a cgo host,
+// torch.distributed from Python), stream-ordered on the stream the library passes.  The batch is cut into chunks that alternate
+// between two side streams, so chunk k+1's exchange runs under chunk k's arithmetic (collectives of one communicator execute in
+// issue order; what overlaps is an exchange with the OTHER chunk's kernels).
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct GatherMap { unsigned char owner[RH_MAX_LIMBS], slot[RH_MAX_LIMBS]; };
+// recv: (world, npoly, cmax, N) as an all-gather of (npoly, cmax, N) blocks leaves it; out: (npoly, nl, N) in chain order
+__global__ void __launch_bounds__(256)
+kshard_unpack_kernel(const u64* __restrict__ recv, u64* __restrict__ out, int npoly, int nl, int cmax, int N, GatherMap m) {
+  const int row = blockIdx.x, poly = row / nl, i = row - poly * nl;
+  const u64* src = recv + (((size_t)m.owner[i] * npoly + poly) * cmax + m.slot[i]) * (size_t)N;
+  u64* dst = out + (size_t)row * N;
+  for (int j = (blockIdx.y * 256 + threadIdx.x) * 2; j < N; j += gridDim.y * 512)
+    *reinterpret_cast<ulonglong2*>(dst + j) = *reinterpret_cast<const ulonglong2*>(src + j);
+}
+
+extern "C" int rh_kshard_set_world(rh_kshard* ks, int world, int rank, const int* owner) {
+  if (!ks || !owner || world < 1 || world > 255 || rank < 0 || rank >= world) return rh_fail(RH_ERR_ARG, "rh_kshard_set_world: bad argument");
+  const int LQ = ks->levelQ + 1, LP = ks->levelP + 1;
+  std::vector<int> oq, op;
+  for (int i = 0; i < LQ + LP; ++i) {
+    if (owner[i] < 0 || owner[i] >= world) return rh_fail(RH_ERR_ARG, "rh_kshard_set_world: owner[%d] = %d outside [0,%d)", i, owner[i], world);
+    if (owner[i] == rank) (i < LQ ? oq : op).push_back(i < LQ ? i : i - LQ);
+  }
+  if (oq != ks->ownQ || op != ks->ownP) return rh_fail(RH_ERR_ARG, "rh_kshard_set_world: rank %d's limbs in the owner map are not the owned limbs the handle was created with", rank);
+  std::lock_guard<std::recursive_mutex> lk(ks->mu);
+  ks->world = world; ks->rank = rank; ks->owner.assign(owner, owner + LQ + LP);
+  return RH_OK;
+}
+
+// exchange geometry of one chain (Q: base 0, P: base levelQ+1): padded limb count per rank and the unpack map
+static int chain_map(const rh_kshard* ks, int base, int nl, GatherMap* m) {
+  std::vector<int> cnt(ks->world, 0);
+  for (int i = 0; i < nl; ++i) { const int r = ks->owner[base + i]; m->owner[i] = (unsigned char)r; m->slot[i] = (unsigned char)cnt[r]++; }
+  int cmax = 1;
+  for (int r = 0; r < ks->world; ++r) if (cnt[r] > cmax) cmax = cnt[r];
+  return cmax;
+}
+static size_t slot_exchange_words(const rh_kshard* ks, int pc) {                    // send + recv of the larger of the two exchanges of a chunk
+  if (ks->world == 1) return 0;
+  GatherMap m;
+  const size_t N = (size_t)ks->Q->N;
+  const size_t sq = (size_t)pc * chain_map(ks, 0, ks->levelQ + 1, &m) * N, sp = (size_t)2 * pc * chain_map(ks, ks->levelQ + 1, ks->levelP + 1, &m) * N;
+  return (sq > sp ? sq : sp) * (size_t)(1 + ks->world);
+}
+static int pick_chunks(const rh_kshard* ks, int npoly, int chunks) {
+  if (chunks <= 0) chunks = (ks->world > 1 && npoly >= 4) ? 4 : 1;                 // auto: four chunks hide three of four exchanges
+  return chunks > npoly ? npoly : chunks;
+}
+extern "C" int rh_kshard_exchange_words(const rh_kshard* ks, int npoly, int chunks, size_t* words) {
+  if (!ks || !words || npoly < 0) return rh_fail(RH_ERR_ARG, "rh_kshard_exchange_words: bad argument");
+  if (ks->owner.empty()) return rh_fail(RH_ERR_ARG, "rh_kshard_exchange_words: call rh_kshard_set_world first");
+  const int nc = npoly ? pick_chunks(ks, npoly, chunks) : 1, pc = npoly ? (npoly + nc - 1) / nc : 0;
+  *words = slot_exchange_words(ks, pc) * (size_t)(nc > 1 ? 2 : 1);
+  return RH_OK;
+}
+extern "C" int rh_kshard_set_exchange(rh_kshard* ks, uint64_t* arena_dev, size_t words) {
+  if (!ks) return rh_fail(RH_ERR_ARG, "rh_kshard_set_exchange: null handle");
+  std::lock_guard<std::recursive_mutex> lk(ks->mu);
+  ks->arena = arena_dev; ks->arena_words = arena_dev ? words : 0;
+  return RH_OK;
+}
+
+// one exchange: the owned limbs of `loc` (npoly, nown, N) -> every limb of the chain in chain order, `out` (npoly, nl, N)
+static int exchange_chain(rh_kshard* ks, hipStream_t st, const u64* loc, int nown, int npoly, int base, int nl, u64* xsend, u64* xrecv,
+                          u64* out, rh_allgather_fn ag, void* ctx) {
+  GatherMap m;
+  const int cmax = chain_map(ks, base, nl, &m), N = ks->Q->N;
+  const u64* send = loc;
+  if (nown != cmax || ks->arena) {                                                 // pad this rank's block to the largest per-rank limb count (with a
+                                                                                   // registered arena always: the host maps BOTH pointers back to it)
+    if (nown && hipMemcpy2DAsync(xsend, (size_t)cmax * N * 8, loc, (size_t)nown * N * 8, (size_t)nown * N * 8, (size_t)npoly, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return rh_fail(RH_ERR_DEVICE, "rh_kshard_gadget_product: packing the exchange block failed");
+    send = xsend;
+  }
+  if (int rc = ag(ctx, send, xrecv, (size_t)npoly * cmax * N, (void*)st)) return rh_fail(RH_ERR_DEVICE, "rh_kshard_gadget_product: the caller's all-gather returned %d", rc);
+  unsigned cy = ((unsigned)N + 2047) / 2048; if (cy > 16) cy = 16;
+  kshard_unpack_kernel<<<dim3((unsigned)npoly * nl, cy), 256, 0, st>>>(xrecv, out, npoly, nl, cmax, N, m);
+  if (hipGetLastError() != hipSuccess) return rh_fail(RH_ERR_DEVICE, "kshard_unpack_kernel launch failed");
+  return RH_OK;
+}
+
+static int product_chunk(rh_kshard* ks, hipStream_t st, const u64* cx, const u64* evkQ, const u64* evkP, u64* ct0, u64* ct1, int pc, u64* xsend,
+                         u64* xrecv, rh_allgather_fn ag, void* ctx) {
+  rh_ring* RQ = ks->Q; rh_ring* RP = ks->P;
+  const int N = RQ->N, nQ = RQ->L, nP = RP ? RP->L : 0, LQ = ks->levelQ + 1, LP = ks->levelP + 1;
+  RhCallScope scope(st, nullptr, 0);
+  u64 *cxinv, *acc, *src;
+  if (int rc = ks_buf(ks, 5, (size_t)pc * nQ * N, &cxinv)) return rc;
+  if (int rc = ks_buf(ks, 6, (size_t)2 * pc * (nP ? nP : 1) * N, &acc)) return rc;
+  if (int rc = rh_std_ntt_launch(RQ, cx, cxinv, pc, nQ, 0, true, false, 0)) return rc;                    // ringQ.INTT(cx, cxInvNTT) (:138)
+  const u64* srcQ = cxinv;
+  if (ks->world > 1) {
+    if (int rc = ks_buf(ks, 7, (size_t)pc * (LQ > 2 * LP ? LQ : 2 * LP) * N, &src)) return rc;
+    if (int rc = exchange_chain(ks, st, cxinv, nQ, pc, 0, LQ, xsend, xrecv, src, ag, ctx)) return rc;
+    srcQ = src;
+  }
+  u64* a0 = acc; u64* a1 = acc + (size_t)pc * nP * N;
+  if (int rc = rh_kshard_product(ks, srcQ, cx, evkQ, evkP, ct0, ct1, nP ? a0 : nullptr, nP ? a1 : nullptr, pc)) return rc;
+  if (nP) if (int rc = rh_std_ntt_launch(RP, acc, acc, 2 * pc, nP, 0, true, true, 0)) return rc;           // INTTLazy of the owned P limbs, both components (:241-246)
+  const u64* srcP = acc;
+  if (ks->world > 1) {
+    if (int rc = exchange_chain(ks, st, acc, nP, 2 * pc, LQ, LP, xsend, xrecv, src, ag, ctx)) return rc;
+    srcP = src;
+  }
+  if (int rc = rh_kshard_moddown(ks, srcP, ct0, ct0, pc)) return rc;
+  return rh_kshard_moddown(ks, srcP + (size_t)pc * LP * N, ct1, ct1, pc);
+}
+
+extern "C" int rh_kshard_gadget_product(rh_kshard* ks, const uint64_t* cx_loc, const uint64_t* evkQ_loc, const uint64_t* evkP_loc,
+                                        uint64_t* ct0_loc, uint64_t* ct1_loc, int npoly, rh_allgather_fn allgather, void* ctx, int chunks) {
+  if (!ks || !cx_loc || !evkQ_loc || !ct0_loc || !ct1_loc) return rh_fail(RH_ERR_ARG, "rh_kshard_gadget_product: null argument");
+  if (ks->P && !evkP_loc) return rh_fail(RH_ERR_ARG, "rh_kshard_gadget_product: null P-part key");
+  if (npoly <= 0) return RH_OK;
+  rh_ring* RQ = ks->Q;
+  (void)hipSetDevice(RQ->device);
+  std::lock_guard<std::recursive_mutex> lk(ks->mu);
+  if (ks->owner.empty()) {                                  // no map given: legal only when this rank owns everything
+    if ((int)ks->ownQ.size() != ks->levelQ + 1 || (int)ks->ownP.size() != ks->levelP + 1)
+      return rh_fail(RH_ERR_ARG, "rh_kshard_gadget_product: call rh_kshard_set_world first (this handle owns a subset of the limbs)");
+    ks->world = 1; ks->rank = 0; ks->owner.assign(ks->levelQ + ks->levelP + 2, 0);
+  }
+  if (ks->world > 1 && !allgather) return rh_fail(RH_ERR_ARG, "rh_kshard_gadget_product: %d ranks need the caller's all-gather", ks->world);
+  const int N = RQ->N, nQ = RQ->L, nc = pick_chunks(ks, npoly, chunks), pc = (npoly + nc - 1) / nc;
+  const size_t xw = slot_exchange_words(ks, pc);
+  hipStream_t main = rh_stream(RQ);
+  if (nc > 1 && !ks->side[0]) {
+    bool ok = hipEventCreateWithFlags(&ks->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < 2 && ok; ++k)
+      ok = hipStreamCreateWithFlags(&ks->side[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ks->ev_join[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) return rh_fail(RH_ERR_DEVICE, "rh_kshard_gadget_product: stream / event creation failed");
+  }
+  // exchange memory per slot: the caller's arena when it is large enough (a host that must map the pointers back to its own buffers), else ours
+  u64 *xs[2] = {nullptr, nullptr}, *xr[2] = {nullptr, nullptr};
+  const int nslots = nc > 1 ? 2 : 1;
+  for (int sl = 0; sl < nslots && xw; ++sl) {
+    const size_t sw = xw / (size_t)(1 + ks->world);
+    if (ks->arena && ks->arena_words >= xw * nslots) { xs[sl] = ks->arena + (size_t)sl * xw; xr[sl] = xs[sl] + sw; }
+    else {
+      ks->slot = sl;
+      if (int rc = ks_buf(ks, 8, sw, &xs[sl])) return rc;
+      if (int rc = ks_buf(ks, 9, xw - sw, &xr[sl])) return rc;
+    }
+  }
+  int rc = RH_OK;
+  if (nc == 1) { ks->slot = 0; rc = product_chunk(ks, main, cx_loc, evkQ_loc, evkP_loc, ct0_loc, ct1_loc, npoly, xs[0], xr[0], allgather, ctx); return rc; }
+  if (hipEventRecord(ks->ev_fork, main) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "rh_kshard_gadget_product: fork failed");
+  for (int k = 0; k < 2; ++k) (void)hipStreamWaitEvent(ks->side[k], ks->ev_fork, 0);
+  for (int k = 0; k < nc && !rc; ++k) {
+    const int p0 = k * pc, n = npoly - p0 < pc ? npoly - p0 : pc;
+    if (n <= 0) break;
+    const size_t off = (size_t)p0 * nQ * N;
+    ks->slot = k & 1;
+    rc = product_chunk(ks, ks->side[k & 1], cx_loc + off, evkQ_loc, evkP_loc, ct0_loc + off, ct1_loc + off, n, xs[k & 1], xr[k & 1], allgather, ctx);
+  }
+  ks->slot = 0;
+  for (int k = 0; k < 2; ++k) {                             // join even after an error: the caller's stream must not run ahead of the side streams
+    (void)hipEventRecord(ks->ev_join[k], ks->side[k]);
+    (void)hipStreamWaitEvent(main, ks->ev_join[k], 0);
+  }
+  return rc;
 }

@@ -11,6 +11,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 U64P = C.POINTER(C.c_uint64)
+# rh_allgather_fn (ringhip.h): (ctx, send_dev, recv_dev, send_words, hip_stream) -> 0 on success
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 Standard = 0   # ring.Standard (ring/ring.go Type)
 ConjugateInvariant = 1   # ring.ConjugateInvariant, Z[X+X^-1]/(X^2N+1)
@@ -128,6 +130,9 @@ def lib():
         "rh_kshard_digit": (i, [vp, i, vp, vp, vp, vp, vp, vp, vp, vp, i]),
         "rh_kshard_product": (i, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i]),
         "rh_kshard_moddown": (i, [vp, vp, vp, vp, i]),
+        "rh_kshard_set_world": (i, [vp, i, i, C.POINTER(i)]), "rh_kshard_exchange_words": (i, [vp, i, i, C.POINTER(sz)]),
+        "rh_kshard_set_exchange": (i, [vp, vp, sz]),
+        "rh_kshard_gadget_product": (i, [vp, vp, vp, vp, vp, vp, i, ALLGATHER_FN, vp, i]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)

@@ -33,6 +33,31 @@ def gather_shards(local, dist):
     return out
 
 
+def gather_polys(block, dist=None, out=None):
+    """The north star's one collective for the batch-sharded workloads (metric, configs 3 / 4): the final gather of the results.
+    `block`: this rank's (B/G, L, N) device tensor (every rank the same shape: pad the last shard).  Returns the (G, B/G, L, N) tensor of
+    every rank's block on every rank -- ONE all_gather_into_tensor on device memory (RCCL over xGMI with backend "nccl"); under "gloo"
+    (CPU rehearsal) the block is staged through the host.  `out` lets the caller supply the destination (no allocation when timing)."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        if out is None:
+            return block.unsqueeze(0)
+        out[0].copy_(block)
+        return out
+    world = dist.get_world_size()
+    if out is None:
+        out = torch.empty((world,) + tuple(block.shape), dtype=block.dtype, device=block.device)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out.view(-1), block.contiguous().view(-1))
+        return out
+    host = block.contiguous().cpu()
+    parts = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(parts, host)
+    for r in range(world):
+        out[r].copy_(parts[r])
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Limb-sharded hybrid key switch (SURVEY 8e, BASELINE config 5)
 # ---------------------------------------------------------------------------------------------------------------
@@ -121,6 +146,13 @@ class LimbShardedKeySwitch:
         self.ringQ.set_stream(stream)
         if self.ringP:
             self.ringP.set_stream(stream)
+        # the whole product behind the C ABI (rh_kshard_gadget_product): tell the handle who owns which limb of Q ++ P and hand it the
+        # all-gather this host has -- torch.distributed here, ncclAllGather from a cgo host
+        owner = [qp_owner(i, world) for i in range(nq + len(P))]
+        rh._check(rh.lib().rh_kshard_set_world(h, world, rank, (C.c_int * len(owner))(*owner)))
+        self._arena, self._arena_words = None, 0
+        self._cb = rh.ALLGATHER_FN(self._allgather)                       # keep the thunk alive as long as the handle
+        self.exchanges, self.exchange_words, self.cb_error = 0, 0, None   # counters of the last product (tests, bench)
 
     # ---- helpers -------------------------------------------------------------------------------------------
     def digit_range(self, d):
@@ -147,8 +179,67 @@ class LimbShardedKeySwitch:
     def _gather_limbs(self, local, own, base, st, ed):
         return gather_limbs(local, own, base, st, ed, self.world, self.dist)
 
+    # ---- the all-gather the library calls back (rh_allgather_fn) ------------------------------------------------
+    def _allgather(self, ctx, send, recv, words, stream):
+        """every rank contributes `words` uint64 at `send` and receives world * words at `recv`, rank-major, enqueued on `stream`.
+        Both pointers lie in the arena tensor registered with rh_kshard_set_exchange, so they map back to tensor views."""
+        torch = self.torch
+        try:
+            base = self._arena.data_ptr()
+            so, ro = (send - base) // 8, (recv - base) // 8
+            if not (0 <= so and so + words <= self._arena_words and 0 <= ro and ro + self.world * words <= self._arena_words):
+                raise RuntimeError("exchange block outside the registered arena")
+            s, r = self._arena[so:so + words], self._arena[ro:ro + self.world * words]
+            self.exchanges += 1
+            self.exchange_words += (self.world - 1) * words                # words this rank RECEIVES from the others
+            if self.gather_override is not None:                           # dry runs (DESIGN.md 7: per-rank arithmetic without a fabric)
+                self.gather_override(s, r, words, stream)
+                return 0
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
+                if self.dist.get_backend() == "nccl":
+                    self.dist.all_gather_into_tensor(r, s)                 # RCCL over xGMI, ordered after / before the kernels of `stream`
+                else:                                                      # gloo (tests on one GPU): staged through the host
+                    host = s.cpu()
+                    parts = [torch.empty_like(host) for _ in range(self.world)]
+                    self.dist.all_gather(parts, host)
+                    r.copy_(torch.cat(parts))
+            return 0
+        except Exception as e:                                             # never let an exception cross the C frames
+            self.cb_error = repr(e)
+            return 1
+
+    gather_override = None
+
+    def _ensure_arena(self, npoly, chunks):
+        import ctypes as C
+        w = C.c_size_t()
+        self.rh._check(self.rh.lib().rh_kshard_exchange_words(self._h, npoly, chunks, C.byref(w)))
+        if w.value > self._arena_words:
+            self.torch.cuda.synchronize(self.device)
+            self._arena = self.torch.empty(w.value, dtype=self.torch.int64, device=self.device)
+            self._arena_words = w.value
+            self.rh._check(self.rh.lib().rh_kshard_set_exchange(self._h, self._arena.data_ptr(), w.value))
+
     # ---- the product ---------------------------------------------------------------------------------------
-    def GadgetProduct(self, cx, evkQ, evkP, ct0, ct1, per_digit=False):
+    def GadgetProduct(self, cx, evkQ, evkP, ct0, ct1, per_digit=False, orchestrate="c", chunks=0):
+        """rlwe.Evaluator.GadgetProduct on the owned limbs.  orchestrate="c" (default): ONE call of rh_kshard_gadget_product -- the INTT ->
+        exchange -> product -> exchange -> ModDown sequence, cut into `chunks` chunks on two streams (0: auto), lives behind the C ABI and
+        only the all-gather is this host's.  orchestrate="python": the same sequence issued call by call from here (round 2's form; kept as
+        a cross-check, and for per_digit=True)."""
+        if orchestrate == "c" and not per_digit:
+            npoly, npl = cx.shape[0], len(self.ownP)
+            self.exchanges = self.exchange_words = 0
+            if self.world > 1:
+                self._ensure_arena(npoly, chunks)
+            rc = self.rh.lib().rh_kshard_gadget_product(self._h, cx.data_ptr(), evkQ.data_ptr(), evkP.data_ptr() if npl else None,
+                                                        ct0.data_ptr(), ct1.data_ptr(), npoly, self._cb if self.world > 1 else self.rh.ALLGATHER_FN(), None, chunks)
+            if rc and self.cb_error:
+                raise self.rh.RingHipError("all-gather callback: %s" % self.cb_error)
+            self.rh._check(rc)
+            return
+        return self._gadget_product_python(cx, evkQ, evkP, ct0, ct1, per_digit)
+
+    def _gadget_product_python(self, cx, evkQ, evkP, ct0, ct1, per_digit=False):
         """cx: owned limbs of the NTT-domain input, (npoly, owned Q, N); evkQ / evkP: owned key slices
         (beta, 2, owned, N) on the device; ct0 / ct1: outputs, owned Q limbs (NTT domain, canonical).
         Default: TWO exchanges per product -- every limb of INTT(cx) in one all-gather (rh_kshard_product: all digits in one call,

@@ -47,8 +47,21 @@ def _run_shard(rh, sharding, N, Q, P, cx, evkQ, evkP, rank, world, dist):
     dkq = ks.to_device(kq)
     dkp = ks.to_device(kp) if kp is not None else None
     ct0, ct1 = torch.empty_like(dcx), torch.empty_like(dcx)
+    npoly = dcx.shape[0]
+    # the whole product behind the C ABI (rh_kshard_gadget_product): this host only supplies the all-gather (a ctypes callback here)
     ks.GadgetProduct(dcx, dkq, dkp, ct0, ct1)
+    auto = 4 if (world > 1 and npoly >= 4) else 1
+    chunks_run = len(range(0, npoly, -(-npoly // auto)))
+    assert ks.exchanges == (2 * chunks_run if world > 1 else 0), (ks.exchanges, chunks_run)
     d0, d1 = torch.empty_like(dcx), torch.empty_like(dcx)
+    for ch in (1, 2, 3):                                                # chunk pipelines on two side streams: same bits
+        d0.zero_(); d1.zero_()
+        ks.GadgetProduct(dcx, dkq, dkp, d0, d1, chunks=ch)
+        torch.cuda.synchronize()
+        assert torch.equal(d0, ct0) and torch.equal(d1, ct1), ch
+    ks.GadgetProduct(dcx, dkq, dkp, d0, d1, orchestrate="python")       # round 2's host-side sequence of the same calls
+    torch.cuda.synchronize()
+    assert torch.equal(d0, ct0) and torch.equal(d1, ct1)
     ks.GadgetProduct(dcx, dkq, dkp, d0, d1, per_digit=True)             # the digit-by-digit form gives the same bits
     torch.cuda.synchronize()
     assert torch.equal(d0, ct0) and torch.equal(d1, ct1)
@@ -61,7 +74,7 @@ def _run_shard(rh, sharding, N, Q, P, cx, evkQ, evkP, rank, world, dist):
 @pytest.mark.parametrize("N,nq,np_", [(4096, 5, 2), (64, 6, 3), (8192, 7, 1 + 1), (16384, 7, 3), (16384, 6, 2)])
 def test_single_rank_shard_path_equals_unsharded(rh, N, nq, np_):
     from matrix_fhe_lattigo_amd import sharding
-    Q, P, beta, cx, evkQ, evkP = _case(N, nq, np_, 2, N + nq)
+    Q, P, beta, cx, evkQ, evkP = _case(N, nq, np_, 3, N + nq)
     e0, e1 = _unsharded(rh, N, Q, P, beta, cx, evkQ, evkP)
     g0, g1, ownQ, ownP, b = _run_shard(rh, sharding, N, Q, P, cx, evkQ, evkP, 0, 1, None)
     assert b == beta and ownQ == list(range(nq)) and ownP == list(range(np_))
@@ -79,7 +92,7 @@ def _worker(rank, world, port, q, N, nq, np_):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import matrix_fhe_lattigo_amd as rh
     from matrix_fhe_lattigo_amd import sharding
-    Q, P, beta, cx, evkQ, evkP = _case(N, nq, np_, 2, 99)              # same case on every rank; each keeps its limbs
+    Q, P, beta, cx, evkQ, evkP = _case(N, nq, np_, 5, 99)              # same case on every rank; each keeps its limbs (5 polys: chunks of 2, 2, 1)
     g0, g1, ownQ, ownP, _ = _run_shard(rh, sharding, N, Q, P, cx, evkQ, evkP, rank, world, dist)
     ok = None
     if rank == 0:

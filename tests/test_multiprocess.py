@@ -117,3 +117,59 @@ def test_limb_exchange_gloo(world):
     assert all(r[1] for r in res)
     if world == 4:
         assert any(r[2] == 0 for r in res)
+
+
+def _gather_polys_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import matrix_fhe_lattigo_amd  # noqa: F401
+    from matrix_fhe_lattigo_amd import sharding
+    sys.path.insert(0, ROOT)
+    import bench
+    # the final gather of a batch-sharded result (SURVEY 8e / north star): every rank contributes its (B/G, L, N) block
+    B, L, N = 3, 4, 32
+    block = (torch.arange(B * L * N, dtype=torch.int64).reshape(B, L, N) + 1000000 * rank)
+    out = sharding.gather_polys(block, dist)
+    ok = tuple(out.shape) == (world, B, L, N) and all(bool(torch.equal(out[r], block - 1000000 * rank + 1000000 * r)) for r in range(world))
+    pre = torch.empty((world, B, L, N), dtype=torch.int64)
+    ok = ok and sharding.gather_polys(block, dist, out=pre) is pre and bool(torch.equal(pre, out))
+    # bench.py's rank plumbing on the same job: the AND over ranks of a per-rank flag, shards with remainders, the batch-shard key-switch split
+
+    class A:
+        dist_backend = "gloo"
+    ok = ok and bench.all_ranks_ok(True, A, dist, "cpu") is True and bench.all_ranks_ok(rank != world - 1, A, dist, "cpu") is False
+    spans = [sharding.poly_shard(64, r, world) for r in range(world)]
+    ok = ok and spans[rank][1] - spans[rank][0] == 64 // world + (1 if rank < 64 % world else 0)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_final_gather_of_result_polys_gloo(world):
+    # row e' of the verdict: one all-gather of every rank's result block; 8 ranks = the rendezvous of the driver's 8-GPU run
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_gather_polys_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(world)) and all(r[1] for r in res)
+
+
+def test_gather_polys_single_process():
+    sys.path.insert(0, ROOT)
+    import torch
+    import matrix_fhe_lattigo_amd  # noqa: F401
+    from matrix_fhe_lattigo_amd import sharding
+    b = torch.arange(24, dtype=torch.int64).reshape(2, 3, 4)
+    out = sharding.gather_polys(b, None)
+    assert tuple(out.shape) == (1, 2, 3, 4) and torch.equal(out[0], b)
