@@ -11,6 +11,7 @@ package ringhip
 /*
 #cgo CFLAGS: -I${SRCDIR}/../../include
 #cgo LDFLAGS: -L${SRCDIR}/../../matrix-fhe-lattigo_amd/lib -lringhip -Wl,-rpath,${SRCDIR}/../../matrix-fhe-lattigo_amd/lib
+#include <stdlib.h>
 #include "ringhip.h"
 */
 import "C"
@@ -256,6 +257,7 @@ func NewDeviceRingWithOmega(r *ring.Ring, device int, omega []uint64) (*DeviceRi
 type DevPoly struct {
 	ptr          *C.uint64_t
 	npoly, limbs int
+	BlockOrder   bool // 3N rings: the block holds NTT-domain data in block order (see NTTTagged); false: the reference's order
 }
 
 func (d *DeviceRing) NewPoly(npoly, limbs int) (*DevPoly, error) {
@@ -472,3 +474,176 @@ func (k *KeySwitcher) ExternalProduct(levelQ, levelP int, c0, c1 *DevPoly, rgsw0
 func (k *KeySwitcher) ModDownQPtoQNTT(levelQ, levelP int, p1Q, p1P, p2Q *DevPoly) {
 	k.q.must(C.rh_bext_moddown_qp_to_q_ntt(k.be, C.int(levelQ), C.int(levelP), p1Q.ptr, p1P.ptr, p2Q.ptr, C.int(p1Q.npoly)))
 }
+
+// ---- round 3 additions -------------------------------------------------------------------------------------------------------------
+
+// HostRing runs Ring.NTT / NTTLazy / INTT / INTTLazy on whole host polys through ONE engine call per poly (rh_ntt_poly_forward /
+// rh_ntt_poly_backward): the reference's loop over r.SubRings[:level+1] (ring/ntt.go:127-152) costs level+1 synchronous PCIe round
+// trips through the per-limb seam; here the level+1 limb pointers travel together, the engine pipelines upload / transform / download
+// over two streams and synchronises once (profiles/r03_host_path.json: 2.8 x faster at N = 2^16, 16 limbs).
+// Poly.Coeffs is [][]uint64 (Go pointers to Go pointers), which cgo may not receive: the limb data pointers are copied into a C array
+// and every limb is pinned against the (currently non-moving, but unspecified) collector for the duration of the call.
+type HostRing struct{ d *DeviceRing }
+
+func NewHostRing(d *DeviceRing) *HostRing { return &HostRing{d: d} }
+
+func (h *HostRing) transform(level int, p1, p2 ring.Poly, inverse, lazy bool) {
+	n := level + 1
+	if len(p1.Coeffs) < n || len(p2.Coeffs) < n {
+		panic(fmt.Sprintf("cannot NTT: poly has %d / %d limbs, ring level needs %d", len(p1.Coeffs), len(p2.Coeffs), n))
+	}
+	in := (*[1 << 20]*C.uint64_t)(C.malloc(C.size_t(2*n) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	defer C.free(unsafe.Pointer(in))
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	for i := 0; i < n; i++ {
+		if len(p1.Coeffs[i]) < h.d.N || len(p2.Coeffs[i]) < h.d.N { // ring/ntt.go:212-214
+			panic(fmt.Sprintf("cannot NTT: ensure that len(p1)=%d, len(p2)=%d >= N=%d", len(p1.Coeffs[i]), len(p2.Coeffs[i]), h.d.N))
+		}
+		pin.Pin(&p1.Coeffs[i][0])
+		pin.Pin(&p2.Coeffs[i][0])
+		in[i] = (*C.uint64_t)(unsafe.Pointer(&p1.Coeffs[i][0]))
+		in[n+i] = (*C.uint64_t)(unsafe.Pointer(&p2.Coeffs[i][0]))
+	}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	lz := C.int(0)
+	if lazy {
+		lz = 1
+	}
+	var rc C.int
+	if inverse {
+		rc = C.rh_ntt_poly_backward(h.d.h, C.int(level), (**C.uint64_t)(unsafe.Pointer(&in[0])), (**C.uint64_t)(unsafe.Pointer(&in[n])), lz)
+	} else {
+		rc = C.rh_ntt_poly_forward(h.d.h, C.int(level), (**C.uint64_t)(unsafe.Pointer(&in[0])), (**C.uint64_t)(unsafe.Pointer(&in[n])), lz)
+	}
+	if rc != 0 {
+		panic(fmt.Sprintf("ringhip: status %d: %s", int(rc), C.GoString(C.rh_last_error())))
+	}
+}
+func (h *HostRing) NTT(level int, p1, p2 ring.Poly)      { h.transform(level, p1, p2, false, false) }
+func (h *HostRing) NTTLazy(level int, p1, p2 ring.Poly)  { h.transform(level, p1, p2, false, true) }
+func (h *HostRing) INTT(level int, p1, p2 ring.Poly)     { h.transform(level, p1, p2, true, false) }
+func (h *HostRing) INTTLazy(level int, p1, p2 ring.Poly) { h.transform(level, p1, p2, true, true) }
+
+// NewPinnedPoly is ring.NewPoly (ring/poly.go:17-24) over ONE page-locked allocation (rh_host_alloc): its limbs are DMA'd where they lie
+// (no staging copy) and, being adjacent, as one copy per limb group.  Free with FreePinnedPoly; the Go collector never sees this memory.
+func NewPinnedPoly(N, level int) (ring.Poly, *C.uint64_t, error) {
+	var base *C.uint64_t
+	if rc := C.rh_host_alloc(C.size_t(N*(level+1)), &base); rc != 0 {
+		return ring.Poly{}, nil, fmt.Errorf("ringhip: %s", C.GoString(C.rh_last_error()))
+	}
+	coeffs := make([][]uint64, level+1)
+	for i := range coeffs {
+		coeffs[i] = unsafe.Slice((*uint64)(unsafe.Add(unsafe.Pointer(base), 8*i*N)), N)
+	}
+	return ring.Poly{Coeffs: coeffs}, base, nil
+}
+func FreePinnedPoly(base *C.uint64_t) { C.rh_host_free(base) }
+
+// Layout tag of a 3N ring's NTT-domain device block (DevPoly.BlockOrder): set by NTTTagged, read by INTTTagged and
+// DivRoundByLastModulusManyNTTTagged; coefficient-wise calls keep it (both operands must carry the same tag, else convert one with
+// ToReferenceOrder first).  Block order saves the permutation pass of every transform (2 HBM passes instead of 3); a block that crosses
+// the host boundary is converted back (Download of a tagged block calls ToReferenceOrder on a copy).
+func (d *DeviceRing) BlockOrderSupported() bool { return C.rh_ring_ntt3n_block_order_supported(d.h) != 0 }
+func (d *DeviceRing) NTTTagged(p1, p2 *DevPoly, blockOrder bool) {
+	b := C.int(0)
+	if blockOrder {
+		b = 1
+	}
+	d.must(C.rh_ring_ntt_layout(d.h, p1.ptr, C.int(p1.limbs), p2.ptr, C.int(p2.limbs), C.int(p1.npoly), C.int(p1.limbs-1), 0, b))
+	p2.BlockOrder = blockOrder
+}
+func (d *DeviceRing) INTTTagged(p1, p2 *DevPoly) {
+	b := C.int(0)
+	if p1.BlockOrder {
+		b = 1
+	}
+	d.must(C.rh_ring_ntt_layout(d.h, p1.ptr, C.int(p1.limbs), p2.ptr, C.int(p2.limbs), C.int(p1.npoly), C.int(p1.limbs-1), 1, b))
+	p2.BlockOrder = false
+}
+func (d *DeviceRing) ToReferenceOrder(p, tmp *DevPoly) {
+	if !p.BlockOrder {
+		return
+	}
+	d.must(C.rh_ring_ntt3n_reorder(d.h, p.ptr, tmp.ptr, C.int(p.npoly), C.int(p.limbs-1), 1))
+	d.must(C.rh_ring_copy_rows(d.h, p.ptr, C.int(p.limbs), tmp.ptr, C.int(p.limbs), C.int(p.npoly), C.int(p.limbs-1)))
+	p.BlockOrder = false
+}
+
+// ShardedKeySwitcher: rlwe.Evaluator.GadgetProduct with the limbs of Q ++ P dealt over the GPUs of one node, one process (or one
+// goroutine with its own device) per GPU.  The whole product -- ringQ.INTT, the exchange of the source limbs, the owned limbs' share of
+// gadgetProductMultiplePLazy, the exchange of the P parts, ModDown (core/rlwe/evaluator_gadget_product.go:16-30, 33-46, 122-188) -- is
+// ONE engine call (rh_kshard_gadget_product); the engine calls back for the two exchanges, and the callback below is RCCL's
+// ncclAllGather on the caller's communicator and the stream the engine names.  Build with -lrccl:
+//
+//	/*
+//	#cgo LDFLAGS: -lrccl
+//	#include <rccl/rccl.h>
+//	#include "ringhip.h"
+//	static int rh_go_allgather(void* ctx, const uint64_t* send, uint64_t* recv, size_t words, void* stream) {
+//	  return ncclAllGather(send, recv, words, ncclUint64, (ncclComm_t)ctx, (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+//	}
+//	static int rh_go_sharded_product(rh_kshard* ks, const uint64_t* cx, const uint64_t* kq, const uint64_t* kp, uint64_t* c0, uint64_t* c1,
+//	                                 int npoly, void* comm, int chunks) {
+//	  return rh_kshard_gadget_product(ks, cx, kq, kp, c0, c1, npoly, rh_go_allgather, comm, chunks);
+//	}
+//	*/
+//
+// (the callback is plain C, so no Go code runs under the engine's frames and no cgo export is needed).
+type ShardedKeySwitcher struct {
+	ks         *C.rh_kshard
+	q, p       *DeviceRing // rings over the OWNED moduli only
+	OwnQ, OwnP []int
+}
+
+// NewShardedKeySwitcher: allQ / allP are the full chains, rank r owns limb i of Q ++ P iff i % world == r (round robin, so every rank holds
+// a mix of Q and P limbs); qLoc / pLoc are device rings over exactly those moduli (pLoc nil when the rank owns no P limb).
+func NewShardedKeySwitcher(qLoc, pLoc *DeviceRing, allQ, allP []uint64, rank, world int) (*ShardedKeySwitcher, error) {
+	s := &ShardedKeySwitcher{q: qLoc, p: pLoc}
+	owner := make([]C.int, len(allQ)+len(allP))
+	var oq, op []C.int
+	for i := range owner {
+		owner[i] = C.int(i % world)
+		if i%world == rank {
+			if i < len(allQ) {
+				oq, s.OwnQ = append(oq, C.int(i)), append(s.OwnQ, i)
+			} else {
+				op, s.OwnP = append(op, C.int(i-len(allQ))), append(s.OwnP, i-len(allQ))
+			}
+		}
+	}
+	aq := make([]C.uint64_t, len(allQ))
+	ap := make([]C.uint64_t, len(allP))
+	for i, v := range allQ {
+		aq[i] = C.uint64_t(v)
+	}
+	for i, v := range allP {
+		ap[i] = C.uint64_t(v)
+	}
+	var ph *C.rh_ring
+	var opp *C.int
+	if pLoc != nil {
+		ph, opp = pLoc.h, &op[0]
+	}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if rc := C.rh_kshard_create(&s.ks, qLoc.h, ph, &aq[0], C.int(len(allQ)-1), &ap[0], C.int(len(allP)-1), &oq[0], C.int(len(oq)), opp, C.int(len(op))); rc != 0 {
+		return nil, fmt.Errorf("ringhip: %s", C.GoString(C.rh_last_error()))
+	}
+	if rc := C.rh_kshard_set_world(s.ks, C.int(world), C.int(rank), &owner[0]); rc != 0 {
+		return nil, fmt.Errorf("ringhip: %s", C.GoString(C.rh_last_error()))
+	}
+	return s, nil
+}
+
+// GadgetProduct: cx, ct0, ct1 hold the OWNED Q limbs of npoly polys, evkQ / evkP the owned slices of the key ([digit][component][owned
+// limb][N]); comm is the node's ncclComm_t (as unsafe.Pointer); chunks <= 0 picks the pipeline depth.  Outputs stay limb-sharded.
+// The body is the C helper of the comment above:
+//
+//	func (s *ShardedKeySwitcher) GadgetProduct(cx, evkQ, evkP, ct0, ct1 *DevPoly, comm unsafe.Pointer, chunks int) {
+//		var kp *C.uint64_t
+//		if evkP != nil { kp = evkP.ptr }
+//		s.q.must(C.rh_go_sharded_product(s.ks, cx.ptr, evkQ.ptr, kp, ct0.ptr, ct1.ptr, C.int(cx.npoly), comm, C.int(chunks)))
+//	}
+func (s *ShardedKeySwitcher) Close() { C.rh_kshard_destroy(s.ks) }

@@ -138,9 +138,12 @@ int rh_ring_ntt_many(rh_ring* r, const uint64_t* const* in_dev, uint64_t* const*
 /* The same on blocks that carry MORE limbs per poly than the level they are used at (in_rows / out_rows limbs per poly, each
  * >= level+1): ring.AtLevel(level) on max-level polys and buffers (ring/ring.go:192-213), the idiomatic use inside the reference's
  * evaluators.  Limbs 0..level of every poly are transformed, the others are untouched.  With rows == level+1 this IS rh_ring_ntt /
- * rh_ring_intt.  Otherwise, standard rings: the forward transform with in_rows == out_rows (N >= 4096) and the inverse transform
- * (N = 2^14 .. 2^16) run as one batched launch pair with the row strides inside the kernels; the remaining shapes (different strides
- * forward, small N, conjugate-invariant and 3N rings) run poly by poly -- correct, not the throughput path. */
+ * rh_ring_intt. */
+/* (round 3: every shape is ONE batched transform.  Standard rings with one row stride on both sides (forward, N >= 4096) and the inverse at
+ * N = 2^14 .. 2^16 stride inside the kernels; the other shapes -- different strides, small N, conjugate-invariant and 3N rings -- compact the
+ * leading limbs with one strided device copy on the way in and / or out.  rh_ring_stats(ring, "rows_direct" | "rows_compacted" |
+ * "rows_poly_by_poly", &n) counts how the calls of a handle were served.) */
+int rh_ring_stats(const rh_ring* r, const char* key, long* value);
 int rh_ring_ntt_rows(rh_ring* r, const uint64_t* in_dev, int in_rows, uint64_t* out_dev, int out_rows, int npoly, int level, int lazy);
 int rh_ring_intt_rows(rh_ring* r, const uint64_t* in_dev, int in_rows, uint64_t* out_dev, int out_rows, int npoly, int level, int lazy);
 
@@ -153,6 +156,15 @@ int rh_ring_intt_mul(rh_ring* r, const uint64_t* a_dev, const uint64_t* b_dev, u
 /* 3N rings: NTT-domain blocks between the reference's ascending-totative order and block order (see ntt3n_block_order):
  * to_reference = 1: block order -> reference order, 0: the reverse.  Out of place (in != out). */
 int rh_ring_ntt3n_reorder(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int to_reference);
+
+/* 3N rings, for hosts that TAG their device polys with the NTT-domain layout (matrix-fhe-lattigo_amd/ringhip.py DevicePoly.layout, the Go
+ * wrapper's DevicePoly.BlockOrder) instead of switching the whole handle with the tuning key: the layout of the NTT side of the call is an
+ * argument (block_order 1: block order, 0: the reference's order), so concurrent callers of one handle may differ.  rows as rh_ring_ntt_rows;
+ * canonical outputs.  rh_ring_ntt3n_block_order_supported: 1 for 3N rings with N = 3 * 2^k, k >= 13.  Other ring kinds ignore the argument. */
+int rh_ring_ntt3n_block_order_supported(const rh_ring* r);
+int rh_ring_ntt_layout(rh_ring* r, const uint64_t* in_dev, int in_rows, uint64_t* out_dev, int out_rows, int npoly, int level, int inverse, int block_order);
+int rh_ring_div_by_last_modulus_many_ntt_layout(rh_ring* r, int round, int level, int nb, const uint64_t* p0_dev, uint64_t* p1_dev, int p1_rows, int npoly,
+                                                int block_order);
 
 /* profiling aid: phase 0 = whole transform, 1 = column kernel only, 2 = tile kernel only (N >= 8192) */
 int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int inverse, int phase);

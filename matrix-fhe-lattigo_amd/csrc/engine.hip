@@ -30,6 +30,10 @@ static thread_local hipStream_t tl_stream = nullptr;
 static thread_local bool tl_has_stream = false;
 static thread_local u64* tl_ws = nullptr;
 static thread_local size_t tl_ws_words = 0;
+static thread_local int tl_layout3n = -1;          // -1: the handle's tuning value; 0 / 1: the layout the running entry point was told
+int rh_layout3n(const rh_ring* r) { return tl_layout3n >= 0 ? tl_layout3n : r->block_order3n; }
+RhLayoutScope::RhLayoutScope(int layout) : prev(tl_layout3n) { tl_layout3n = layout; }
+RhLayoutScope::~RhLayoutScope() { tl_layout3n = prev; }
 hipStream_t rh_stream(const rh_ring* r) { return tl_has_stream ? tl_stream : r->stream; }
 u64* rh_ws_override(size_t words) { return (tl_ws && tl_ws_words >= words) ? tl_ws : nullptr; }
 RhCallScope::RhCallScope(hipStream_t st, u64* ws, size_t ws_words) : prev_st(tl_stream), prev_has(tl_has_stream), prev_ws(tl_ws), prev_words(tl_ws_words) {
@@ -244,6 +248,7 @@ extern "C" void rh_ring_destroy(rh_ring* r) {
   rh_poly_slots_teardown(r);
   rh_rescale_teardown(r);
   for (int i = 0; i < 2; ++i) if (r->d_rs[i]) (void)hipFree(r->d_rs[i]);
+  if (r->d_rows) (void)hipFree(r->d_rows);
   rh_ring3n_teardown(r);
   delete r;
 }
@@ -754,7 +759,7 @@ static int ci_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
 int rh_ring_ntt_any(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse) {
   if (r->kind == RH_RING_3N) {
     std::lock_guard<std::recursive_mutex> lk(r->mu);
-    return rh_ring3n_ntt_launch(r, in, out, npoly, Lrows, limb0, inverse, r->block_order3n != 0);
+    return rh_ring3n_ntt_launch(r, in, out, npoly, Lrows, limb0, inverse, rh_layout3n(r) != 0);
   }
   if (r->kind == RH_RING_CI) return ci_ntt_launch(r, in, out, npoly, Lrows, limb0, inverse);
   return rh_std_ntt_launch(r, in, out, npoly, Lrows, limb0, inverse, false, 0);
@@ -767,7 +772,7 @@ static int ntt_batch(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, i
   (void)hipSetDevice(r->device);
   if (r->kind == RH_RING_3N) {
     std::lock_guard<std::recursive_mutex> lk(r->mu);          // the 3N workspace is shared and grows lazily
-    return rh_ring3n_ntt_launch(r, in, out, npoly, level + 1, 0, inverse, r->block_order3n != 0);
+    return rh_ring3n_ntt_launch(r, in, out, npoly, level + 1, 0, inverse, rh_layout3n(r) != 0);
   }
   if (r->kind == RH_RING_CI) return ci_ntt_launch(r, in, out, npoly, level + 1, 0, inverse);
   return rh_std_ntt_launch(r, in, out, npoly, level + 1, 0, inverse, lazy, phase);
@@ -809,20 +814,66 @@ static int ntt_rows(rh_ring* r, const uint64_t* in, int in_rows, uint64_t* out, 
   if (!in || !out) return rh_fail(RH_ERR_ARG, "ntt: null argument");
   if (npoly < 0) return rh_fail(RH_ERR_ARG, "ntt: npoly < 0");
   (void)hipSetDevice(r->device);
-  // batched: forward with one row stride on both sides (the kernels' Ls), inverse through the hand-scheduled bodies
-  if (r->kind == RH_RING_STANDARD && !inverse && in_rows == out_rows && r->logN >= LT)
+  // direct: forward with one row stride on both sides (the kernels' Ls), inverse through the hand-scheduled bodies
+  if (r->kind == RH_RING_STANDARD && !inverse && in_rows == out_rows && r->logN >= LT) {
+    ++r->stats_rows_direct;
     return std_ntt_launch_span(r, in, out, npoly, level + 1, 0, false, lazy, 0, in_rows);
-  if (r->kind == RH_RING_STANDARD && inverse && rh_can_intt_limb_strided(r))    // BackwardLazy is canonical for N >= 16 (ring/ntt.go:197-206)
+  }
+  if (r->kind == RH_RING_STANDARD && inverse && rh_can_intt_limb_strided(r)) {  // BackwardLazy is canonical for N >= 16 (ring/ntt.go:197-206)
+    ++r->stats_rows_direct;
     return rh_std_intt_rows(r, in, in_rows, out, out_rows, npoly, level + 1);
-  for (int k = 0; k < npoly; ++k)
-    if (int rc = ntt_batch(r, in + (size_t)k * in_rows * r->N, out + (size_t)k * out_rows * r->N, 1, level, inverse, lazy)) return rc;
-  return RH_OK;
+  }
+  // every other shape (different strides forward, small N, conjugate-invariant and 3N rings): still ONE batched transform -- the leading
+  // limbs are compacted with a strided copy on the way in and / or expanded on the way out (round 3; these shapes ran poly by poly before)
+  if (npoly == 0) return RH_OK;
+  ++r->stats_rows_compacted;
+  const size_t N = (size_t)r->N, Lr = (size_t)(level + 1);
+  hipStream_t st = rh_stream(r);
+  auto copy2d = [&](u64* dst, size_t drows, const u64* src, size_t srows) {
+    return hipMemcpy2DAsync(dst, drows * N * 8, src, srows * N * 8, Lr * N * 8, (size_t)npoly, hipMemcpyDeviceToDevice, st) == hipSuccess
+               ? RH_OK : rh_fail(RH_ERR_DEVICE, "ntt: strided copy of the leading limbs failed");
+  };
+  if ((size_t)out_rows == Lr) {                       // dense destination: gather into it, transform in place
+    if (int rc = copy2d(out, Lr, in, (size_t)in_rows)) return rc;
+    return ntt_batch(r, out, out, npoly, level, inverse, lazy);
+  }
+  std::lock_guard<std::recursive_mutex> lk(r->mu);   // the dense scratch is shared and grows lazily; its use is stream-ordered
+  const size_t words = (size_t)npoly * Lr * N;
+  if (r->rows_words < words) {
+    if (r->d_rows) (void)hipFree(r->d_rows);
+    r->d_rows = nullptr; r->rows_words = 0;
+    if (hipMalloc((void**)&r->d_rows, words * 8) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc(AtLevel scratch, %zu words) failed", words);
+    r->rows_words = words;
+  }
+  const u64* src = in;
+  if ((size_t)in_rows != Lr) { if (int rc = copy2d(r->d_rows, Lr, in, (size_t)in_rows)) return rc; src = r->d_rows; }
+  if (int rc = ntt_batch(r, src, r->d_rows, npoly, level, inverse, lazy)) return rc;
+  return copy2d(out, (size_t)out_rows, r->d_rows, Lr);
+}
+extern "C" int rh_ring_stats(const rh_ring* r, const char* key, long* value) {
+  if (!r || !key || !value) return rh_fail(RH_ERR_ARG, "rh_ring_stats: null argument");
+  if (!strcmp(key, "rows_direct")) { *value = r->stats_rows_direct; return RH_OK; }
+  if (!strcmp(key, "rows_compacted")) { *value = r->stats_rows_compacted; return RH_OK; }
+  if (!strcmp(key, "rows_poly_by_poly")) { *value = 0; return RH_OK; }   // no entry point loops over polys any more (kept so a regression has a name)
+  return rh_fail(RH_ERR_ARG, "rh_ring_stats: unknown key %s", key);
 }
 extern "C" int rh_ring_ntt_rows(rh_ring* r, const uint64_t* in, int in_rows, uint64_t* out, int out_rows, int npoly, int level, int lazy) {
   return ntt_rows(r, in, in_rows, out, out_rows, npoly, level, false, lazy != 0);
 }
 extern "C" int rh_ring_intt_rows(rh_ring* r, const uint64_t* in, int in_rows, uint64_t* out, int out_rows, int npoly, int level, int lazy) {
   return ntt_rows(r, in, in_rows, out, out_rows, npoly, level, true, lazy != 0);
+}
+// Explicit-layout forms for 3N rings (hosts that TAG their device polys with the NTT-domain layout instead of switching the whole handle with
+// the tuning key): block_order 1 = the NTT side of this call is in block order, 0 = the reference's ascending-totative order.  The layout is a
+// per-call argument (thread-local inside the call), so concurrent callers of one handle may use different layouts.  Other ring kinds: ignored.
+extern "C" int rh_ring_ntt3n_block_order_supported(const rh_ring* r) {
+  return r && r->kind == RH_RING_3N && rh_ring3n_block_order_ok(r) ? 1 : 0;
+}
+extern "C" int rh_ring_ntt_layout(rh_ring* r, const uint64_t* in, int in_rows, uint64_t* out, int out_rows, int npoly, int level, int inverse, int block_order) {
+  if (!r) return rh_fail(RH_ERR_ARG, "ntt: null argument");
+  if (block_order && !rh_ring_ntt3n_block_order_supported(r)) return rh_fail(RH_ERR_UNSUPPORTED, "block order needs a 3N ring with N = 3 * 2^k, k >= 13");
+  RhLayoutScope ls(r->kind == RH_RING_3N ? (block_order ? 1 : 0) : -1);
+  return ntt_rows(r, in, in_rows, out, out_rows, npoly, level, inverse != 0, false);
 }
 extern "C" int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, int inverse, int phase) {
   if (phase < 0 || phase > 2) return rh_fail(RH_ERR_ARG, "phase must be 0, 1 or 2");
@@ -890,6 +941,13 @@ extern "C" int rh_ring_reserve(rh_ring* r, int npoly) {
   (void)hipSetDevice(r->device);
   std::lock_guard<std::recursive_mutex> lk(r->mu);
   if (r->kind == RH_RING_3N) if (int rc = rh_ring3n_reserve(r, npoly)) return rc;
+  const size_t words = (size_t)npoly * r->L * r->N;            // the rows-per-poly transforms' dense scratch
+  if (r->rows_words < words) {
+    if (r->d_rows) (void)hipFree(r->d_rows);
+    r->d_rows = nullptr; r->rows_words = 0;
+    if (hipMalloc((void**)&r->d_rows, (words ? words : 1) * 8) != hipSuccess) return rh_fail(RH_ERR_NOMEM, "hipMalloc(AtLevel scratch) failed");
+    r->rows_words = words;
+  }
   return rh_rescale_reserve(r, npoly);
 }
 

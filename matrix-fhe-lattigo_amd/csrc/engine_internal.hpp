@@ -43,6 +43,8 @@ struct rh_ring {
   rh_ring3n_state* s3n = nullptr;
   std::vector<void*> rescale_tables;      // per level, rescale.hip
   u64* d_rs[2] = {nullptr, nullptr}; size_t rs_words[2] = {0, 0};
+  u64* d_rows = nullptr; size_t rows_words = 0;   // dense scratch of the rows-per-poly transforms that compact / expand (engine.hip: ntt_rows)
+  long stats_rows_direct = 0, stats_rows_compacted = 0;   // rh_ring_stats: how the rows-per-poly calls were served (diagnostic, not synchronised)
   int fuse_submul = 1;            // ModDown / rescale: subtract-multiply fused into the forward tile kernel's epilogue
   int fuse_ci = 1;                // conjugate-invariant ring: the fold inside the column stages (N = 2^14 .. 2^16)
   int digit_pipeline = 1;         // key switch: all digit blocks transformed by one pipelined stream of launches (N = 2^14 .. 2^16)
@@ -75,6 +77,9 @@ struct RhCallScope {                                         // installs (stream
   hipStream_t prev_st; bool prev_has; u64* prev_ws; size_t prev_words;
 };
 
+int rh_layout3n(const rh_ring* r);                          // 3N rings: the calling entry point's NTT-domain layout (1 block order, 0 reference), else the tuning value
+struct RhLayoutScope { explicit RhLayoutScope(int layout); ~RhLayoutScope(); RhLayoutScope(const RhLayoutScope&) = delete; RhLayoutScope& operator=(const RhLayoutScope&) = delete; private: int prev; };
+bool rh_ring3n_block_order_ok(const rh_ring* r);
 int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase = 0);
 int rh_ring_ntt_any(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse);
 int rh_std_ntt_fwd_strided(rh_ring* r, u64* data, int npoly, int Lrows, int limb0, int Ls);

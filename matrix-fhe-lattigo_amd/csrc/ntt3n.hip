@@ -518,6 +518,8 @@ static void launch_cols_post_inv(rh_ring* r, int S1sub, dim3 g, hipStream_t st, 
   else ntt3n_cols_post_inv<3><<<g, 256, 0, st>>>(in, out, N, r3, r3_stride, l3, c, Lrows, stw, log_n2);
 }
 
+bool rh_ring3n_block_order_ok(const rh_ring* r) { const rh_ring3n_state* s = r->s3n; return s && s->b == 1 && s->sub && s->log_n2 >= LT; }
+
 static int ntt3n_block_order_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse) {
   rh_ring3n_state* s = r->s3n;
   const int N = r->N, nb = s->nb;

@@ -206,6 +206,15 @@ extern "C" int rh_ring_div_by_last_modulus_many_ntt(rh_ring* r, int round, int l
   return launched("rescale many (NTT domain)");
 }
 
+// the same with the NTT-domain layout of a 3N ring's data as a per-call argument (see rh_ring_ntt_layout)
+extern "C" int rh_ring_div_by_last_modulus_many_ntt_layout(rh_ring* r, int round, int level, int nb, const uint64_t* p0, uint64_t* p1, int p1_rows, int npoly,
+                                                           int block_order) {
+  if (!r) return rh_fail(RH_ERR_ARG, "rescale: null ring");
+  if (block_order && !rh_ring_ntt3n_block_order_supported(r)) return rh_fail(RH_ERR_UNSUPPORTED, "block order needs a 3N ring with N = 3 * 2^k, k >= 13");
+  RhLayoutScope ls(r->kind == RH_RING_3N ? (block_order ? 1 : 0) : -1);
+  return rh_ring_div_by_last_modulus_many_ntt(r, round, level, nb, p0, p1, p1_rows, npoly);
+}
+
 // rh_ring_reserve: the rescale scratch for batches of up to npoly polys and the per-level constant tables, so
 // that no later call allocates (hipMalloc / hipFree synchronise the device and cannot be captured in a HIP graph)
 int rh_rescale_reserve(rh_ring* r, int npoly) {

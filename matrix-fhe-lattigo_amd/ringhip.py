@@ -37,6 +37,8 @@ def _opcodes():
 
 
 OPS = _opcodes()
+# opcodes that read their output operand as well (z = f(x, y, z)): its layout tag takes part like an input's
+_OPS_READ_Z = {v for k, v in OPS.items() if ("THEN_ADD" in k or "THEN_SUB" in k) and k != "MUL_SCALAR_MONT_THEN_ADD_SCALAR"}
 
 
 def _share_hip_runtime_with_torch():
@@ -96,6 +98,9 @@ def lib():
         "rh_host_alloc": (i, [sz, C.POINTER(vp)]), "rh_host_free": (i, [vp]), "rh_host_register": (i, [vp, sz]), "rh_host_unregister": (i, [vp]),
         "rh_ring_ntt": (i, [vp, vp, vp, i, i, i]), "rh_ring_intt": (i, [vp, vp, vp, i, i, i]),
         "rh_ring_ntt_phase": (i, [vp, vp, vp, i, i, i, i]),
+        "rh_ring_ntt3n_block_order_supported": (i, [vp]), "rh_ring_ntt_layout": (i, [vp, vp, i, vp, i, i, i, i, i]),
+        "rh_ring_div_by_last_modulus_many_ntt_layout": (i, [vp, i, i, i, vp, vp, i, i, i]),
+        "rh_ring_stats": (i, [vp, C.c_char_p, C.POINTER(C.c_long)]),
         "rh_ring_ntt_rows": (i, [vp, vp, i, vp, i, i, i, i]), "rh_ring_intt_rows": (i, [vp, vp, i, vp, i, i, i, i]),
         "rh_ring_vec_op_rows": (i, [vp, i, vp, i, vp, i, vp, i, i, i, U64P, U64P]),
         "rh_ring_intt_mul": (i, [vp, vp, vp, vp, i, i]),
@@ -158,6 +163,9 @@ class DevicePoly:
     """Device-resident block of `npoly` polynomials with `limbs` limbs of N words: replaces Poly.Coeffs [][]uint64
     (ring/poly.go:13-24).  Either owns hipMalloc'd memory or wraps an external device pointer (e.g. a torch tensor)."""
 
+    layout = None      # 3N rings: "block" when the block holds NTT-domain data in block order (Ring.ntt3n_layout); None: the reference's order
+                       # (or coefficient-domain data).  Set by the Ring methods that produce the block; the host only ever sees reference order.
+
     def __init__(self, ring, npoly, limbs, ptr=None, owner=None):
         self.ring, self.npoly, self.limbs = ring, int(npoly), int(limbs)
         self.words = self.npoly * self.limbs * ring.N
@@ -186,8 +194,13 @@ class DevicePoly:
         return cls(ring, t.shape[0], t.shape[1], ptr=t.data_ptr(), owner=t)
 
     def numpy(self):
+        """the block on the host -- always in the reference's order: a block-order NTT-domain block (3N rings) is converted on the way out"""
         out = np.empty((self.npoly, self.limbs, self.ring.N), dtype=np.uint64)
-        _check(lib().rh_dev_download(self.ring._h, _p(out), self.ptr, out.size))
+        src = self
+        if self.layout == "block":
+            src = DevicePoly(self.ring, self.npoly, self.limbs)
+            _check(lib().rh_ring_ntt3n_reorder(self.ring._h, self.ptr, src.ptr, self.npoly, self.limbs - 1, 1))
+        _check(lib().rh_dev_download(self.ring._h, _p(out), src.ptr, out.size))
         return out
 
     def free(self):
@@ -275,6 +288,7 @@ class Ring:
             _check(lib().rh_ring_create(C.byref(h), device, kind, self.N, self.L, _p(self.moduli), *[_p(a) for a in keep]))
         self._h = h
         self.level = self.L - 1
+        self._shared = {"ntt3n_layout": None}     # one dict for the handle and all its AtLevel views
         self.SubRings = [SubRing(self, i) for i in range(self.L)]
 
     # ---- construction helpers -------------------------------------------------------------------------------
@@ -315,6 +329,12 @@ class Ring:
     def ntt_phase(self, p1, p2, inverse=False, phase=0):
         _check(lib().rh_ring_ntt_phase(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, int(inverse), int(phase)))
 
+    def stats(self, key):
+        """rh_ring_stats: how the rows-per-poly (AtLevel) transforms of this handle were served: rows_direct / rows_compacted / rows_poly_by_poly"""
+        v = C.c_long()
+        _check(lib().rh_ring_stats(self._h, key.encode(), C.byref(v)))
+        return v.value
+
     def sync(self):
         _check(lib().rh_ring_sync(self._h))
 
@@ -352,14 +372,66 @@ class Ring:
                                        "blocks by level+1 rows, allocate the batch at that level" % (p.npoly, p.limbs, self.level))
         return more
 
+    # ---- 3N rings: the device NTT domain's layout, tagged per block ---------------------------------------------------------
+    @property
+    def ntt3n_layout(self):
+        """None (default): Ring.NTT writes the reference's ascending-totative order (ring/ntt_3n.go:82-109).  "block": Ring.NTT writes BLOCK
+        order (no permutation pass: 2 HBM passes per transform instead of 3) and tags its output (DevicePoly.layout); every later Ring call
+        reads the tags -- INTT takes either layout, the coefficient-wise calls keep it, a block-order operand that meets a reference-order
+        one is converted first, and DevicePoly.numpy() hands the host the reference's order.  Set on a ring or any of its views."""
+        return self._shared["ntt3n_layout"]
+
+    @ntt3n_layout.setter
+    def ntt3n_layout(self, value):
+        if value not in (None, "block"):
+            raise RingHipError("ntt3n_layout must be None or 'block'")
+        if value == "block" and not (self.kind == Matrix3N and lib().rh_ring_ntt3n_block_order_supported(self._h)):
+            raise RingHipError("block order needs a 3N ring with N = 3 * 2^k, k >= 13")
+        self._shared["ntt3n_layout"] = value
+
+    def ToReferenceOrder(self, p):
+        """a block-order NTT-domain block back into the reference's order, in place (through a temporary); no-op for any other block"""
+        if getattr(p, "layout", None) != "block":
+            return p
+        v = self.AtLevel(p.limbs - 1)
+        tmp = DevicePoly(v, p.npoly, p.limbs)
+        _check(lib().rh_ring_ntt3n_reorder(self._h, p.ptr, tmp.ptr, p.npoly, p.limbs - 1, 1))
+        _check(lib().rh_ring_copy_rows(self._h, p.ptr, p.limbs, tmp.ptr, p.limbs, p.npoly, p.limbs - 1))
+        p.layout = None
+        return p
+
+    def _lay(self, out, *ins):
+        """layout of a coefficient-wise call's output: its operands' common layout; mixed layouts are brought to the reference's first.
+        An output block that is also an operand keeps participating through its tag."""
+        if self.kind != Matrix3N:
+            return
+        tags = {getattr(p, "layout", None) for p in ins if p is not None}
+        if len(tags) > 1:
+            for p in ins:
+                if p is not None:
+                    self.ToReferenceOrder(p)
+            tags = {None}
+        lay = tags.pop() if tags else None
+        for o in (out if isinstance(out, (list, tuple)) else [out]):
+            o.layout = lay
+
     def _ntt(self, p1, p2, inverse, lazy):
         L = lib()
-        if self._chk(p1, p2, rows_ok=True):
+        more = self._chk(p1, p2, rows_ok=True)
+        if self.kind == Matrix3N and (self.ntt3n_layout == "block" or getattr(p1, "layout", None) == "block"):
+            # tagged path: forward writes the ring's layout, inverse reads the operand's (a forward transform's input is coefficient-domain data)
+            blk = (p1.layout == "block") if inverse else True
+            _check(L.rh_ring_ntt_layout(self._h, p1.ptr, p1.limbs, p2.ptr, p2.limbs, p1.npoly, self.level, 1 if inverse else 0, 1 if blk else 0))
+            p2.layout = None if inverse else "block"
+            return
+        if more:
             f = L.rh_ring_intt_rows if inverse else L.rh_ring_ntt_rows
             _check(f(self._h, p1.ptr, p1.limbs, p2.ptr, p2.limbs, p1.npoly, self.level, lazy))
         else:
             f = L.rh_ring_intt if inverse else L.rh_ring_ntt
             _check(f(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, lazy))
+        if self.kind == Matrix3N:
+            p2.layout = None
 
     def NTT(self, p1, p2): self._ntt(p1, p2, False, 0)
     def NTTLazy(self, p1, p2): self._ntt(p1, p2, False, 1)
@@ -387,12 +459,16 @@ class Ring:
     def NTT3NReorder(self, p1, p2, to_reference=True):
         """3N rings: NTT-domain block between block order (tuning ntt3n_block_order) and the Go transformer's order; out of place"""
         self._chk(p1, p2); _check(lib().rh_ring_ntt3n_reorder(self._h, p1.ptr, p2.ptr, p1.npoly, self.level, 1 if to_reference else 0))
+        if self.ntt3n_layout == "block":            # tagged use: the output carries its layout (the handle-wide tuning key leaves tags alone)
+            p2.layout = None if to_reference else "block"
 
     def CopyLvl(self, p1, p2):
         """p2 <- limbs 0..level of p1 (Poly.CopyLvl, ring/poly.go), blocks may carry more limbs per poly"""
         if p1.npoly != p2.npoly:
             raise RingHipError("CopyLvl: blocks differ in poly count")
         _check(lib().rh_ring_copy_rows(self._h, p2.ptr, p2.limbs, p1.ptr, p1.limbs, p1.npoly, self.level))
+        if self.kind == Matrix3N:
+            p2.layout = getattr(p1, "layout", None)
 
     def NTTMany(self, pairs):
         """Ring.NTT(p1, p2) for every (p1, p2) of `pairs` in one call (rh_ring_ntt_many): one software pipeline through all blocks"""
@@ -406,13 +482,18 @@ class Ring:
     def INTTMul(self, p1, p2, p3):
         """p3 = INTT(p1 . p2) for NTT-domain p1, p2: the values of MForm(p1, t); MulCoeffsMontgomery(t, p2, p3); INTT(p3, p3)
         (schemes/ckks/evaluator.go:821-834 + INTT), with the product formed on load inside the inverse transform"""
-        self._chk(p1, p2, p3); _check(lib().rh_ring_intt_mul(self._h, p1.ptr, p2.ptr, p3.ptr, p1.npoly, self.level))
+        self._chk(p1, p2, p3)
+        if self.kind == Matrix3N and (getattr(p1, "layout", None) or getattr(p2, "layout", None)):      # tagged operands: the three calls as they are
+            self.MForm(p1, p3); self.MulCoeffsMontgomery(p3, p2, p3); self.INTT(p3, p3)
+            return
+        _check(lib().rh_ring_intt_mul(self._h, p1.ptr, p2.ptr, p3.ptr, p1.npoly, self.level))
 
     # ---- automorphisms (ring/automorphism.go) ---------------------------------------------------------------
     def TensorDegree1(self, a0, a1, b0, b1, c0, c1, c2, mform_first=True):
         """degree-1 x degree-1 tensoring as one kernel: ckks mulRelin (schemes/ckks/evaluator.go:821-834) with mform_first,
         matrix_ckks.Evaluator.Mul (schemes/matrix_ckks/evaluator.go:166-173) without"""
         self._chk(a0, a1, b0, b1, c0, c1, c2)
+        self._lay([c0, c1, c2], a0, a1, b0, b1)
         _check(lib().rh_ring_tensor_degree1(self._h, a0.ptr, a1.ptr, b0.ptr, b1.ptr, c0.ptr, c1.ptr, c2.ptr, a0.npoly, self.level,
                                             1 if mform_first else 0))
 
@@ -460,11 +541,17 @@ class Ring:
     def DivFloorByLastModulus(self, p0, p1): self.DivFloorByLastModulusMany(1, p0, p1)
     def DivRoundByLastModulus(self, p0, p1): self.DivRoundByLastModulusMany(1, p0, p1)
 
-    def DivFloorByLastModulusManyNTT(self, nbRescales, p0, p1):
-        _check(lib().rh_ring_div_by_last_modulus_many_ntt(self._h, 0, self.level, nbRescales, p0.ptr, p1.ptr, p1.limbs, p0.npoly))
+    def _div_ntt(self, rnd, nbRescales, p0, p1):
+        if self.kind == Matrix3N and getattr(p0, "layout", None) == "block":       # the NTT-domain form on tagged data: the layout goes with the call
+            _check(lib().rh_ring_div_by_last_modulus_many_ntt_layout(self._h, rnd, self.level, nbRescales, p0.ptr, p1.ptr, p1.limbs, p0.npoly, 1))
+            p1.layout = "block"
+            return
+        _check(lib().rh_ring_div_by_last_modulus_many_ntt(self._h, rnd, self.level, nbRescales, p0.ptr, p1.ptr, p1.limbs, p0.npoly))
+        if self.kind == Matrix3N:
+            p1.layout = None
 
-    def DivRoundByLastModulusManyNTT(self, nbRescales, p0, p1):
-        _check(lib().rh_ring_div_by_last_modulus_many_ntt(self._h, 1, self.level, nbRescales, p0.ptr, p1.ptr, p1.limbs, p0.npoly))
+    def DivFloorByLastModulusManyNTT(self, nbRescales, p0, p1): self._div_ntt(0, nbRescales, p0, p1)
+    def DivRoundByLastModulusManyNTT(self, nbRescales, p0, p1): self._div_ntt(1, nbRescales, p0, p1)
 
     def DivFloorByLastModulusNTT(self, p0, p1): self.DivFloorByLastModulusManyNTT(1, p0, p1)
     def DivRoundByLastModulusNTT(self, p0, p1): self.DivRoundByLastModulusManyNTT(1, p0, p1)
@@ -473,6 +560,8 @@ class Ring:
     def vec_op(self, op, p1, p2, p3, s0=None, s1=None):
         code = OPS[op] if isinstance(op, str) else int(op)
         more = self._chk(p1, p2, p3, rows_ok=True)
+        if self.kind == Matrix3N:
+            self._lay(p3, p1, p2, p3 if code in _OPS_READ_Z else None)
         a = _u64(s0) if s0 is not None else None
         b = _u64(s1) if s1 is not None else None
         if more:
@@ -555,6 +644,9 @@ class Ring:
 
     def _halves(self, op, p1, s_lo, s_hi, p2):
         self._chk(p1, p2)
+        if getattr(p1, "layout", None) == "block":      # "the first / second N/2 coefficients" means positions of the reference's order
+            self.ToReferenceOrder(p1)
+        self._lay(p2, p1)
         a, b = _u64(s_lo), _u64(s_hi)
         _check(lib().rh_ring_vec_op_halves(self._h, OPS[op], p1.ptr, p2.ptr, p1.npoly, self.level, _p(a), _p(b)))
 
@@ -577,11 +669,13 @@ class Ring:
     def MulByVectorMontgomery(self, p1, vector, p2):
         """:366-370: every limb of every poly times the same N-word vector (a 1-poly, 1-limb DevicePoly)"""
         self._chk(p1, p2, rows_ok=True)
+        self._lay(p2, p1, vector)
         _check(lib().rh_ring_vec_op_bcast(self._h, OPS["MUL_MONT"], p1.ptr, p1.limbs, vector.ptr, p2.ptr, p2.limbs, p1.npoly, self.level))
 
     def MulByVectorMontgomeryThenAddLazy(self, p1, vector, p2):
         """:373-377"""
         self._chk(p1, p2, rows_ok=True)
+        self._lay(p2, p1, vector, p2)
         _check(lib().rh_ring_vec_op_bcast(self._h, OPS["MUL_MONT_THEN_ADD_LAZY"], p1.ptr, p1.limbs, vector.ptr, p2.ptr, p2.limbs, p1.npoly, self.level))
 
     def Shift(self, p1, k, p2):
@@ -612,6 +706,7 @@ class Ring:
             q = int(self.moduli[i])
             host[poly, i, :len(coeffs)] = np.array([c % q for c in coeffs], dtype=np.uint64)
         _check(lib().rh_dev_upload(self._h, p1.ptr, _p(host), host.size))
+        p1.layout = None                               # the block was read back (reference order) and rewritten whole
 
     def _crt(self):
         mods = [int(q) for q in self.moduli[:self.level + 1]]

@@ -105,6 +105,8 @@ class Evaluator:
         for p in polys:
             if p is None:
                 continue
+            if getattr(p, "layout", None) == "block":      # 3N rings: the key-switch kernels and the keys speak the reference's order
+                p.ring.ToReferenceOrder(p)
             if p.limbs < level + 1 or (p.limbs != level + 1 and p.npoly > 1):
                 raise RingHipError("batch of %d polys with %d limbs used at level %d: allocate it at that level" % (p.npoly, p.limbs, level))
 

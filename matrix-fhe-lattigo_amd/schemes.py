@@ -26,15 +26,20 @@ class Ciphertext:
 class MatrixCKKSEvaluator:
     """schemes/matrix_ckks/evaluator.go: Evaluator over the 3N ring Z_Q[X]/(X^N - X^{N/2} + 1)."""
 
-    def __init__(self, ringQ, block_order=False):
-        """block_order: keep the ring's device NTT domain in block order (rh_ring_set_tuning ntt3n_block_order): Mul is NTT ->
-        coefficient-wise products -> INTT, so its coefficient-domain output is bit-identical and every transform saves the
-        permutation pass.  It is a property of the RING handle: NTT-domain polys of this ring are then in block order for every
-        user of the handle (Ring.NTT3NReorder converts at the host boundary)."""
+    def __init__(self, ringQ, block_order=True):
+        """block_order (default): device-resident NTT-domain polys of the 3N ring are kept in BLOCK order (Ring.ntt3n_layout = "block"): a
+        transform is 2 HBM passes instead of 3, and since every NTT-domain operation of a ring is coefficient-wise, Mul / Add / Rescale chains
+        give bit-identical results.  The layout is a TAG on each device block (DevicePoly.layout), not a mode of the data a caller can see:
+        Ring.NTT tags what it writes, INTT and the coefficient-wise calls read the tags, a block-order operand that meets a reference-order
+        one (e.g. NTT-domain data uploaded from the host) is converted first, and DevicePoly.numpy() always hands out the reference's order
+        (ring/ntt_3n.go:82-109).  Rings too small for it (N < 3 * 2^13, or 3^b with b > 1) and block_order=False use the reference's order."""
         self.ringQ = ringQ
         self.fused_tensor = True
-        if block_order:
-            ringQ.set_tuning("ntt3n_block_order", 1)
+        from .ringhip import lib
+        if block_order and lib().rh_ring_ntt3n_block_order_supported(ringQ._h):
+            ringQ.ntt3n_layout = "block"
+        elif not block_order:
+            ringQ.ntt3n_layout = None
 
     def Mul(self, ct0, ct1, ctOut):
         """evaluator.go:114-192.  Reproduced as written, including its two side effects: inputs not yet in the NTT

@@ -195,7 +195,9 @@ class LimbShardedKeySwitch:
             if self.gather_override is not None:                           # dry runs (per-rank arithmetic without a fabric)
                 self.gather_override(s, r, words, stream)
                 return 0
-            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
+            # `stream` is NULL (None through ctypes) when the library runs a single chunk on the ring's own stream and that is torch's default
+            ts = torch.cuda.ExternalStream(stream, device=self.device) if stream else torch.cuda.default_stream(self.device)
+            with torch.cuda.stream(ts):
                 if self.dist.get_backend() == "nccl":
                     self.dist.all_gather_into_tensor(r, s)                 # RCCL over xGMI, ordered after / before the kernels of `stream`
                 else:                                                      # gloo (tests on one GPU): staged through the host

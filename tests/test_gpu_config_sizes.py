@@ -208,7 +208,7 @@ def test_config4_ring_all_24_limbs(rh, oracle):
         assert np.array_equal(oracle.ntt3n_backward(fx[i], mods[i], om[i]), x0[1, i])
     # Mul: NTT the four inputs, tensor without MForm (values carry the 2^-64 factor), INTT the three outputs
     dp = lambda a: rh.DevicePoly.from_numpy(ring, a)
-    ev = rh.MatrixCKKSEvaluator(ring)
+    ev = rh.MatrixCKKSEvaluator(ring, block_order=False)       # the reference's NTT-domain order throughout
     out = rh.Ciphertext([ring.NewPoly(B) for _ in range(3)])
     ev.Mul(rh.Ciphertext([dp(x0), dp(x1)]), rh.Ciphertext([dp(y0), dp(y1)]), out)
     got = [v.numpy() for v in out.Value]
@@ -222,12 +222,66 @@ def test_config4_ring_all_24_limbs(rh, oracle):
         c1 = oracle.vec_op(MULADD, A1, B0, oracle.vec_op(MUL, A0, B1, z, 0, 0, q), 0, 0, q)
         for c, e in ((0, c0), (1, c1), (2, c2)):
             assert np.array_equal(got[c][1, i], oracle.ntt3n_backward(e, q, w)), "Mul component %d limb %d" % (c, i)
-    # the same Mul with the ring's device NTT domain in block order (no permutation pass): identical coefficient-domain output
-    ev2 = rh.MatrixCKKSEvaluator(ring, block_order=True)
+    # the DEFAULT evaluator: device NTT domain in block order, tagged per block (no permutation pass): identical coefficient-domain output,
+    # and the NTT-domain inputs it left behind read back in the reference's order
+    ev2 = rh.MatrixCKKSEvaluator(ring)
+    assert ring.ntt3n_layout == "block"
     out2 = rh.Ciphertext([ring.NewPoly(B) for _ in range(3)])
-    ev2.Mul(rh.Ciphertext([dp(x0), dp(x1)]), rh.Ciphertext([dp(y0), dp(y1)]), out2)
+    cx = rh.Ciphertext([dp(x0), dp(x1)])
+    ev2.Mul(cx, rh.Ciphertext([dp(y0), dp(y1)]), out2)
+    assert cx.IsNTT and cx.Value[0].layout == "block" and out2.Value[0].layout is None
     for c in range(3):
         assert np.array_equal(out2.Value[c].numpy(), got[c]), "block-order Mul component %d" % c
+    assert np.array_equal(cx.Value[0].numpy()[1, 11], fx[11])
+    ring.close()
+
+
+def test_config4_per_gpu_share_128_ciphertext_pairs(rh, oracle):
+    """BASELINE config 4 at the share ONE GPU gets of its 1024 ciphertext pairs over 8 GPUs: 128 pairs, N = 3*2^16, 24 limbs (4.5 GiB per
+    128-poly component; 14 components live = 63 GiB of HBM).  matrix_ckks.Evaluator.Mul with the default (block-order, tagged) device NTT
+    domain: the WHOLE batch against the reference-order run on the device, and spot rows of spot ciphertexts against the oracle call sequence
+    (schemes/matrix_ckks/evaluator.go:114-192).  Any span / stride / size_t issue at this size shows as a mismatch on the last ciphertexts."""
+    import torch
+    from test_gpu_schemes import primes_3n, omega_for
+    N, L, B = 3 << 16, 24, 128
+    mods = primes_3n(oracle, N, L)
+    om = [omega_for(q, N) for q in mods]
+    ring = rh.Ring(N, mods, kind=rh.Matrix3N, omega3n=om)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(4128)
+    qs = torch.tensor(mods, dtype=torch.int64, device=dev).view(1, L, 1)
+
+    def draw():
+        t = torch.empty((B, L, N), dtype=torch.int64, device=dev)
+        for b0 in range(0, B, 16):
+            t[b0:b0 + 16] = torch.randint(0, 1 << 62, (16, L, N), dtype=torch.int64, device=dev, generator=g) % qs
+        return t
+    src = [draw() for _ in range(4)]                                   # x0, x1, y0, y1
+    spots_k, spots_i = (0, 77, B - 1), (0, 13, L - 1)
+    host = {(c, k, i): src[c][k, i].cpu().numpy().view(np.uint64).copy() for c in range(4) for k in spots_k for i in spots_i}
+    dp = lambda t: rh.DevicePoly.from_torch(ring, t)
+    res = {}
+    for name, blk in (("reference", False), ("block", True)):
+        ev = rh.MatrixCKKSEvaluator(ring, block_order=blk)
+        work = [t.clone() for t in src]                                # Mul transforms its inputs in place (:136-149)
+        outs = [torch.empty((B, L, N), dtype=torch.int64, device=dev) for _ in range(3)]
+        ev.Mul(rh.Ciphertext([dp(work[0]), dp(work[1])]), rh.Ciphertext([dp(work[2]), dp(work[3])]), rh.Ciphertext([dp(o) for o in outs]))
+        torch.cuda.synchronize()
+        res[name] = outs
+        del work
+    for c in range(3):
+        assert torch.equal(res["block"][c], res["reference"][c]), "component %d: block-order run differs from the reference-order run" % c
+    MUL, MULADD = rh.OPS["MUL_MONT"], rh.OPS["MUL_MONT_THEN_ADD"]
+    z = np.zeros(N, dtype=np.uint64)
+    for k in spots_k:
+        for i in spots_i:
+            q, w = mods[i], om[i]
+            A0, A1, B0, B1 = (oracle.ntt3n_forward(host[(c, k, i)], q, w) for c in range(4))
+            e = [oracle.vec_op(MUL, A0, B0, z, 0, 0, q),
+                 oracle.vec_op(MULADD, A1, B0, oracle.vec_op(MUL, A0, B1, z, 0, 0, q), 0, 0, q),
+                 oracle.vec_op(MUL, A1, B1, z, 0, 0, q)]
+            for c in range(3):
+                assert np.array_equal(res["block"][c][k, i].cpu().numpy().view(np.uint64), oracle.ntt3n_backward(e[c], q, w)), (c, k, i)
     ring.close()
 
 

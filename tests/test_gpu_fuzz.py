@@ -70,6 +70,9 @@ def test_fuzz_standard_ntt_family(rh, oracle, case):
     getattr(view, which)(pin, pout)
     got = pout.numpy()
     ctx = "case %d: %s N=2^%d L=%d level=%d B=%d limbs %d->%d inplace=%s" % (case, which, logN, L, level, B, limbs_in, limbs_out, inplace)
+    # every AtLevel shape is ONE batched transform (strides inside the kernels, or one strided copy in / out): never a loop over the polys
+    strided = limbs_in != level + 1 or limbs_out != level + 1
+    assert ring.stats("rows_direct") + ring.stats("rows_compacted") == (1 if strided else 0) and ring.stats("rows_poly_by_poly") == 0, ctx
     for (k, i) in _spots(rng, B, level):
         sr = oracle.SubRingConsts(N, mods[i])
         f = oracle.ntt if which.startswith("NTT") else oracle.intt
@@ -116,7 +119,7 @@ def test_fuzz_vec_ops_at_level(rh, oracle, case):
     ring.close()
 
 
-@pytest.mark.parametrize("case", range(12 * SCALE))
+@pytest.mark.parametrize("case", range(24 * SCALE))
 def test_fuzz_conjugate_invariant_and_3n(rh, oracle, case):
     """the other two ring types through the same batched entry points (ring/ntt.go:80-124, ring/ntt_3n.go:82-156)"""
     rng = np.random.default_rng(9000 + case)
@@ -148,15 +151,24 @@ def test_fuzz_conjugate_invariant_and_3n(rh, oracle, case):
         bwd = lambda v, i: oracle.ntt3n_backward(v, mods[i], oms[i])
         name = "3N N=%d" % N
     view = ring.AtLevel(level)
-    a = _block(rng, mods, B, level + 1, N, level)
+    # AtLevel views over polys with more limbs than the view (different row strides on the two sides), batched since round 3
+    limbs_in = level + 1 + int(rng.choice([0, 1, 2]))
+    limbs_out = limbs_in if inplace else level + 1 + int(rng.choice([0, 0, 3]))
+    a = _block(rng, mods, B, limbs_in, N, level)
     pin = rh.DevicePoly.from_numpy(ring, a)
-    pout = pin if inplace else view.NewPoly(B)
+    pout = pin if inplace else rh.DevicePoly.from_numpy(ring, np.full((B, limbs_out, N), SENTINEL, dtype=np.uint64))
     inverse = bool((case // 2) % 2)
     (view.INTT if inverse else view.NTT)(pin, pout)
     got = pout.numpy()
-    ctx = "case %d: %s %s L=%d level=%d B=%d inplace=%s" % (case, name, "INTT" if inverse else "NTT", L, level, B, inplace)
+    ctx = "case %d: %s %s L=%d level=%d B=%d limbs %d->%d inplace=%s" % (case, name, "INTT" if inverse else "NTT", L, level, B, limbs_in, limbs_out, inplace)
     for (k, i) in _spots(rng, B, level, n=2):
         assert np.array_equal(got[k, i], (bwd if inverse else fwd)(a[k, i], i)), ctx + " row (%d, %d)" % (k, i)
+    if limbs_out > level + 1:
+        assert (got[:, level + 1:] == SENTINEL).all(), ctx + ": rows above the level were written"
+    if not inplace:
+        assert np.array_equal(pin.numpy(), a), ctx + ": input modified"
+    strided = limbs_in != level + 1 or limbs_out != level + 1
+    assert ring.stats("rows_direct") + ring.stats("rows_compacted") == (1 if strided else 0) and ring.stats("rows_poly_by_poly") == 0, ctx
     ring.close()
 
 

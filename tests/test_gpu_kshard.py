@@ -119,7 +119,21 @@ def test_multi_rank_limb_shard_gloo(world, N, nq, np_):
     ps = [ctx.Process(target=_worker, args=(r, world, port, q, N, nq, np_)) for r in range(world)]
     for p in ps:
         p.start()
-    covered, ok0, ok1, pcounts = q.get(timeout=300)
+    import queue as _queue
+    import time as _time
+    res, t0 = None, _time.time()
+    while res is None and _time.time() - t0 < 300:                       # a rank that dies leaves the queue empty: do not wait the full time-out for it
+        try:
+            res = q.get(timeout=2)
+        except _queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in ps):
+                break
+    if res is None:
+        for p in ps:
+            if p.is_alive():
+                p.terminate()
+        raise AssertionError("a rank failed: exit codes %s" % [p.exitcode for p in ps])
+    covered, ok0, ok1, pcounts = res
     for p in ps:
         p.join(timeout=120)
         assert p.exitcode == 0

@@ -296,3 +296,63 @@ def test_matrix_ckks_new_forms_and_level_drop(rh, oracle):
     sub.INTT(r.Value[0], r.Value[0])
     assert np.array_equal(r.Value[0].numpy(), np.stack([oracle.div_by_last_modulus_many(a0[k], mods, 1, 1) for k in range(B)]))
     ring.close()
+
+
+def test_block_order_tags_follow_the_data(rh, oracle):
+    # block order is the DEFAULT for device-resident 3N chains, carried as a tag on each device block; the host boundary
+    # (numpy()) and any meeting with reference-order NTT-domain data convert lazily; key-switch callers get the reference's order
+    N, L, B = 3 << 13, 3, 2
+    mods = primes_3n(oracle, N, L)
+    om = [omega_for(q, N) for q in mods]
+    ring = rh.Ring(N, mods, kind=rh.Matrix3N, omega3n=om)
+    assert ring.ntt3n_layout is None
+    ev = rh.MatrixCKKSEvaluator(ring)
+    assert ring.ntt3n_layout == "block" and ring.AtLevel(1).ntt3n_layout == "block"            # views share the handle's setting
+    rng = np.random.default_rng(31)
+    mk = lambda: np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    a, b = mk(), mk()
+    fwd = lambda x: np.stack([np.stack([oracle.ntt3n_forward(x[k, i], mods[i], om[i]) for i in range(L)]) for k in range(B)])
+    fa, fb = fwd(a), fwd(b)
+    pa = rh.DevicePoly.from_numpy(ring, a)
+    assert pa.layout is None
+    ring.NTT(pa, pa)
+    assert pa.layout == "block"
+    assert np.array_equal(pa.numpy(), fa)                                  # the host sees the reference's order ...
+    raw = np.empty((B, L, N), dtype=np.uint64)
+    rh.ringhip._check(rh.lib().rh_dev_download(ring._h, raw.ctypes.data_as(rh.ringhip.U64P), pa.ptr, raw.size))
+    assert not np.array_equal(raw, fa) and np.array_equal(np.sort(raw, axis=2), np.sort(fa, axis=2))   # ... of data that really lies in another order
+    # a reference-order NTT-domain operand from the host meets a block-order one: converted first, result in the reference's order
+    pb_ref = rh.DevicePoly.from_numpy(ring, fb)
+    s = ring.NewPoly(B)
+    ring.Add(pa, pb_ref, s)
+    assert s.layout is None and pa.layout is None
+    exp = np.stack([(fa[:, i] + fb[:, i]) % np.uint64(q) for i, q in enumerate(mods)], axis=1)
+    assert np.array_equal(s.numpy(), exp)
+    # two block-order operands stay in block order; z-reading opcodes count their output as an operand
+    pa2, pb2 = rh.DevicePoly.from_numpy(ring, a), rh.DevicePoly.from_numpy(ring, b)
+    ring.NTT(pa2, pa2); ring.NTT(pb2, pb2)
+    t = ring.NewPoly(B)
+    ring.MulCoeffsMontgomery(pa2, pb2, t)
+    assert t.layout == "block"
+    ring.MulCoeffsMontgomeryThenAdd(pa2, pb2, s)                           # s is reference-order: everything comes back to it
+    assert s.layout is None and pa2.layout is None
+    MUL = rh.OPS["MUL_MONT"]
+    z = np.zeros(N, dtype=np.uint64)
+    prod = np.stack([np.stack([oracle.vec_op(MUL, fa[k, i], fb[k, i], z, 0, 0, mods[i]) for i in range(L)]) for k in range(B)])
+    assert np.array_equal(t.numpy(), prod)
+    assert np.array_equal(s.numpy(), np.stack([(exp[:, i] + prod[:, i]) % np.uint64(q) for i, q in enumerate(mods)], axis=1))
+    # INTT reads the operand's tag whatever the ring's setting; CopyLvl and a lower-level view carry it
+    low = ring.AtLevel(1)
+    c = rh.DevicePoly(low, B, 2)
+    low.CopyLvl(t, c)
+    assert c.layout == "block"
+    low.INTT(c, c)
+    assert c.layout is None
+    back = np.stack([np.stack([oracle.ntt3n_backward(prod[k, i], mods[i], om[i]) for i in range(2)]) for k in range(B)])
+    assert np.array_equal(c.numpy(), back)
+    ring.ntt3n_layout = None
+    ring.INTT(t, t)                                                        # still tagged: converted by the kernel choice, not by the setting
+    assert np.array_equal(t.numpy()[:, :2], back)
+    with pytest.raises(rh.RingHipError):
+        rh.Ring(3 << 6, primes_3n(oracle, 3 << 6, 1), kind=rh.Matrix3N).ntt3n_layout = "block"     # too small for block order
+    ring.close()
