@@ -418,10 +418,10 @@ class Ring:
     def _ntt(self, p1, p2, inverse, lazy):
         L = lib()
         more = self._chk(p1, p2, rows_ok=True)
-        if self.kind == Matrix3N and (self.ntt3n_layout == "block" or getattr(p1, "layout", None) == "block"):
-            # tagged path: forward writes the ring's layout, inverse reads the operand's (a forward transform's input is coefficient-domain data)
-            blk = (p1.layout == "block") if inverse else True
-            _check(L.rh_ring_ntt_layout(self._h, p1.ptr, p1.limbs, p2.ptr, p2.limbs, p1.npoly, self.level, 1 if inverse else 0, 1 if blk else 0))
+        # 3N rings, tagged path: a forward transform writes the RING's layout (its input is coefficient-domain data, whatever stale tag the
+        # block carries), an inverse transform reads the OPERAND's tag
+        if self.kind == Matrix3N and ((getattr(p1, "layout", None) == "block") if inverse else (self.ntt3n_layout == "block")):
+            _check(L.rh_ring_ntt_layout(self._h, p1.ptr, p1.limbs, p2.ptr, p2.limbs, p1.npoly, self.level, 1 if inverse else 0, 1))
             p2.layout = None if inverse else "block"
             return
         if more:

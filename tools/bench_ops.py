@@ -167,17 +167,17 @@ for N, L, B in ((3 << 13, 1, 1024), (3 << 16, 24, 16)):
         blocks = [rh.DevicePoly.from_torch(ring, rand_block(B, mods, N)) for _ in range(7)]
         ct0, ct1 = rh.Ciphertext(blocks[0:2]), rh.Ciphertext(blocks[2:4])
         out = rh.Ciphertext(blocks[4:7])
-        ev = rh.MatrixCKKSEvaluator(ring)
+        ev = rh.MatrixCKKSEvaluator(ring, block_order=False)
 
         def mul():
             ct0.IsNTT = ct1.IsNTT = False
             ev.Mul(ct0, ct1, out)
-        res.append(entry("config4 matrix_ckks Mul N=%d L=%d (4 NTT, 3 MulCoeffsMontgomery, 1 ThenAdd, 3 INTT)" % (N, L),
+        res.append(entry("config4 matrix_ckks Mul N=%d L=%d, reference-order NTT domain (block_order=False)" % (N, L),
                          timed(mul, reps=5), (7 * 16.0 + 3 * 24.0 + 32.0) * N * L * B, B, "ctmul"))
-        ring.set_tuning("ntt3n_block_order", 1)
-        res.append(entry("config4 matrix_ckks Mul N=%d L=%d, block-order NTT domain (same coefficient-domain output)" % (N, L),
+        ev = rh.MatrixCKKSEvaluator(ring)                    # the default since round 3: block order, carried as per-block tags
+        res.append(entry("config4 matrix_ckks Mul N=%d L=%d (4 NTT, tensoring, 3 INTT; DEFAULT evaluator: block-order device NTT domain, tagged per block)" % (N, L),
                          timed(mul, reps=5), (7 * 16.0 + 3 * 24.0 + 32.0) * N * L * B, B, "ctmul"))
-        ring.set_tuning("ntt3n_block_order", 0)
+        ring.ntt3n_layout = None
         del blocks, ct0, ct1, out
     del px, x
     ring.close(); torch.cuda.empty_cache()

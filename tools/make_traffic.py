@@ -4,7 +4,9 @@
 usage: make_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <batch> <launches_per_step>
 gfx950 corrections as in tools/pmc_summary.py (KiB units, FETCH_SIZE x2).  The step's traffic = launches_per_step x the
 average of the pipelined launch (ntt_fwd_fused_asm); Infinity-Cache hits are included in these counters."""
-import collections, csv, json, sys
+import collections, csv, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_tree_hash          # ties the counters to the kernel sources they were collected on (bench.py drops them when it differs)
 
 
 def per_kernel(path, counter):
@@ -34,6 +36,7 @@ out = {
                                       for n in f if "ntt" in n and n != k},
     "config": {"logn": 16, "limbs": 16, "batch": batch},
     "hbm_bytes_per_poly": (fetch_step + write_step) / batch,
+    "csrc_tree": csrc_tree_hash(),
 }
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -7,7 +7,9 @@ step.  The issue peak and the butterfly ceiling are the round-1 microbenchmarks 
 r01_micro_butterfly_rates.txt) at the kernel's occupancy of 4 waves/SIMD: v_mad_u64_u32-class instructions issue at 534 G wave-
 instructions/s chip-wide, v_add_u32-class at 997 G; the hand-scheduled butterfly is 16 + 2 of them, and the register-resident
 Shoup butterfly loop reaches 3.39 M (VGPR twiddles) .. 3.53 M (SGPR twiddles) limb-NTT(2^16)/s."""
-import collections, csv, json, sys
+import collections, csv, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_tree_hash          # ties the counters to the kernel sources they were collected on (bench.py drops them when it differs)
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
@@ -30,6 +32,7 @@ out = {
     "butterfly_ceiling_note": "register-resident Shoup butterfly loop at 4 workgroups/CU: 3.39 M (VGPR twiddles) .. 3.53 M (SGPR twiddles) limb-NTT(2^16)/s, half the stages each; profiles/r01_micro_butterfly_rates.txt",
     "other_counters_per_launch": {k: sum(v) / len(v) for k, v in c.items() if k != "SQ_INSTS_VALU"},
     "config": {"logn": 16, "limbs": 16, "batch": batch},
+    "csrc_tree": csrc_tree_hash(),
     "source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -- python3 bench.py --no-cpu",
 }
 json.dump(out, open(sys.argv[2], "w"), indent=1)

@@ -2,7 +2,7 @@
 # GPU box: regenerates everything under profiles/ that the bench line cites.  usage: tools/refresh_profiles.sh <tag>  (e.g. r02)
 # One rocprofv3 run per counter group; --pmc runs carry --kernel-trace only (gpurun rule).  rocprofv3 gets the program itself after `--`.
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
 echo "[1/9] bench"; python3 bench.py > $O/bench.log 2>$O/bench.err; tail -1 $O/bench.log > $O/${tag}_bench.json
