@@ -384,12 +384,12 @@ def run_ntt(args):
             dist.barrier()
         g_ms = (time.perf_counter() - t0) * 1e3 / reps
         # what arrived: this rank's slot is its own block; every other slot carries that rank's fingerprint (exchanged apart, tiny)
-        fp = block[0, 0, :8].cpu()
+        fp = block[0, 0, :8].clone() if args.dist_backend == "nccl" else block[0, 0, :8].cpu()     # RCCL moves device tensors, gloo host tensors
         fps = [fp]
         if dist is not None:
             fps = [torch.empty_like(fp) for _ in range(world)]
             dist.all_gather(fps, fp)
-        ok = bool(torch.equal(out[rank], block)) and all(bool(torch.equal(out[r, 0, 0, :8].cpu(), fps[r])) for r in range(world))
+        ok = bool(torch.equal(out[rank], block)) and all(bool(torch.equal(out[r, 0, 0, :8].cpu(), fps[r].cpu())) for r in range(world))
         recv = (world - 1) * gp * L * N * 8
         gather = {"ms": g_ms, "polys_per_rank": gp, "bytes_received_per_gpu": recv, "GBps_received_per_gpu": recv / (g_ms * 1e-3) / 1e9 if world > 1 else None,
                   "verified": all_ranks_ok(ok, args, dist, dev),
