@@ -7,7 +7,8 @@ LIB   := $(PKG)/lib/libringhip.so
 SRCS  := $(CSRC)/engine.hip $(CSRC)/ntt3n.hip $(CSRC)/bext.hip $(CSRC)/rescale.hip $(CSRC)/keyswitch.hip $(CSRC)/kshard.hip $(CSRC)/automorphism.hip
 HDRS  := $(wildcard $(CSRC)/*.hip.hpp) $(wildcard $(CSRC)/*.inc) $(wildcard $(CSRC)/*.hpp) $(wildcard include/*.h)
 
-all: $(LIB) oracle tests/cpp/test_ring_cpp
+ROCM ?= /opt/rocm
+all: $(LIB) oracle tests/cpp/test_ring_cpp tests/cpp/test_sharded_host
 
 $(CSRC)/ntt_tile_asm.inc: tools/gen_tile_asm.py
 	python3 tools/gen_tile_asm.py $@
@@ -18,6 +19,10 @@ $(LIB): $(SRCS) $(HDRS) $(CSRC)/ntt_tile_asm.inc
 
 tests/cpp/test_ring_cpp: tests/cpp/test_ring_cpp.cpp tests/cpp/golden_vectors.inc include/ringhip.hpp include/ringhip.h $(LIB)
 	g++ -O2 -std=c++17 -Iinclude $< -L$(PKG)/lib -lringhip -Wl,-rpath,'$$ORIGIN/../../$(PKG)/lib' -o $@
+
+# a compiled host with threads as ranks and a plain-C all-gather callback: the limb-sharded key switch through the C ABI alone
+tests/cpp/test_sharded_host: tests/cpp/test_sharded_host.cpp include/ringhip.h $(LIB)
+	g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -Iinclude -I$(ROCM)/include $< -L$(PKG)/lib -lringhip -L$(ROCM)/lib -lamdhip64 -lpthread -Wl,-rpath,'$$ORIGIN/../../$(PKG)/lib' -Wl,-rpath,$(ROCM)/lib -o $@
 
 oracle: oracle/libring_oracle.so
 oracle/libring_oracle.so: oracle/ring_oracle.c oracle/ring_oracle.h include/ringhip_ops.h

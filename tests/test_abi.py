@@ -56,3 +56,15 @@ def test_cpp_host_mirror_binary():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed" in out.stdout
+
+
+@pytest.mark.gpu
+def test_compiled_host_runs_the_sharded_key_switch_through_the_c_abi():
+    # tests/cpp/test_sharded_host.cpp: host threads as ranks, a plain-C all-gather callback in the place of ncclAllGather, no Python in the
+    # loop -- the cgo host of INTEGRATION.md 2b minus RCCL.  2-4 ranks, ranks without P limbs, 1-4 chunks, vs the unsharded product.
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "test_sharded_host")
+    assert os.path.exists(exe), "run `make` first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "all checks passed" in out.stdout and out.stdout.count(" ok") == 4
