@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <vector>
 #include <mutex>
+#include <atomic>
 #include <cstdint>
 #include "../../include/ringhip.h"
 #include "ring_types.hip.hpp"
@@ -44,7 +45,7 @@ struct rh_ring {
   std::vector<void*> rescale_tables;      // per level, rescale.hip
   u64* d_rs[2] = {nullptr, nullptr}; size_t rs_words[2] = {0, 0};
   u64* d_rows = nullptr; size_t rows_words = 0;   // dense scratch of the rows-per-poly transforms that compact / expand (engine.hip: ntt_rows)
-  long stats_rows_direct = 0, stats_rows_compacted = 0;   // rh_ring_stats: how the rows-per-poly calls were served (diagnostic, not synchronised)
+  std::atomic<long> stats_rows_direct{0}, stats_rows_compacted{0};   // rh_ring_stats: how the rows-per-poly calls were served
   int fuse_submul = 1;            // ModDown / rescale: subtract-multiply fused into the forward tile kernel's epilogue
   int fuse_ci = 1;                // conjugate-invariant ring: the fold inside the column stages (N = 2^14 .. 2^16)
   int digit_pipeline = 1;         // key switch: all digit blocks transformed by one pipelined stream of launches (N = 2^14 .. 2^16)

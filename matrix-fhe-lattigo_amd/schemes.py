@@ -80,6 +80,77 @@ class MatrixCKKSEvaluator:
         ctOut.IsNTT = False
 
 
+    # ---- MulByConst (evaluator.go:322-380): a ciphertext times a constant -------------------------------------------------------
+    @staticmethod
+    def _round_to_prec(x, prec):
+        """big.Float.SetPrec(prec).SetFloat64 / SetInt: the value rounded to `prec` significant bits, round-half-even (exact when it fits)"""
+        from fractions import Fraction
+        x = Fraction(x)
+        if x == 0:
+            return x
+        n, e = abs(x), 0
+        while n >= (1 << prec):
+            n /= 2; e += 1
+        while n < (1 << (prec - 1)):
+            n *= 2; e -= 1
+        fl = n.numerator // n.denominator
+        rem = n - fl
+        if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl & 1):
+            fl += 1
+        v = Fraction(fl) * (Fraction(2) ** e)
+        return v if x > 0 else -v
+
+    @staticmethod
+    def _scaled_int(x, scale):
+        """bigComplexToRNSScalar (:382-411): x * scale, plus / minus 0.5 by sign, truncated toward zero (exact: the 128-bit scale precision
+        holds the 53 + 61-bit product of a float64 constant and a modulus)"""
+        from fractions import Fraction
+        v = Fraction(x) * scale
+        if x > 0:
+            v += Fraction(1, 2)
+        elif x < 0:
+            v -= Fraction(1, 2)
+        return int(v)                                   # Python truncates toward zero like big.Float.Int
+
+    def MulByConst(self, ct, constant, ctOut, encoding_precision=53, roots_forward_1=None):
+        """evaluator.go:322-380: ctOut = ct * constant.  Integer constants multiply as they are (scale 1); other constants are scaled by the
+        moduli one rescaling consumes (q_level ...), rounded half away from zero, and the product's scale grows by that factor (returned; scale
+        bookkeeping is the reference Ciphertext's metadata).  The RNS scalars are formed on the host exactly as the reference forms them and
+        applied with ring.MulDoubleRNSScalar (the first N/2 coefficients times one scalar, the rest times the other).  A constant with an
+        imaginary part mixes in SubRing.RootsForward[1] of the FULL ring (:361-365): hand it over per limb (`roots_forward_1`, Montgomery form,
+        as the Go side holds it) -- this mirror does not regenerate the tables a Matrix ring carries for the wrong order."""
+        from fractions import Fraction
+        if ct.Level() != ctOut.Level():
+            raise RingHipError("ciphertexts must be at the same level for constant multiplication")
+        if ct.Degree() != ctOut.Degree():
+            raise RingHipError("MulByConst: ctOut must have the degree of ct")
+        level = ct.Level()
+        rq = self.ringQ.AtLevel(level)
+        mods = [int(q) for q in self.ringQ.moduli[:level + 1]]
+        re_, im_ = (constant.real, constant.imag) if isinstance(constant, complex) else (constant, 0)
+        rnd = lambda x: Fraction(x) if isinstance(x, int) else self._round_to_prec(x, encoding_precision)
+        re_, im_ = rnd(re_), rnd(im_)
+        if re_.denominator == 1 and im_.denominator == 1:          # cmplxBig.IsInt(): no scaling required
+            scale = 1
+        else:
+            scale = mods[level]
+            for i in range(1, self.levelsConsumedPerRescaling()):
+                scale *= mods[level - i]
+        real, imag = self._scaled_int(re_, scale), self._scaled_int(im_, scale)
+        rns_real = [real % q for q in mods]                         # NewRNSScalarFromBigint: the non-negative residue
+        rns_imag = [imag % q for q in mods]
+        if imag != 0:
+            if roots_forward_1 is None:
+                raise RingHipError("MulByConst: a constant with an imaginary part needs SubRing.RootsForward[1] of every limb (roots_forward_1)")
+            rinv = [pow(1 << 64, -1, q) for q in mods]
+            rns_imag = [(x * int(w) * ri) % q for x, w, ri, q in zip(rns_imag, roots_forward_1, rinv, mods)]       # ring.MRed(RNSImag[i], RootsForward[1])
+        s0 = [(a + b) % q for a, b, q in zip(rns_real, rns_imag, mods)]                                            # CRed(real + imag)
+        s1 = [(a + q - b) % q for a, b, q in zip(rns_real, rns_imag, mods)]                                        # CRed(real + q - imag)
+        for vin, vout in zip(ct.Value, ctOut.Value):
+            rq.MulDoubleRNSScalar(vin, s0, s1, vout)
+        ctOut.IsNTT = ct.IsNTT
+        return scale
+
     def levelsConsumedPerRescaling(self):
         """evaluator.go:313-319"""
         return 1

@@ -356,3 +356,47 @@ def test_block_order_tags_follow_the_data(rh, oracle):
     with pytest.raises(rh.RingHipError):
         rh.Ring(3 << 6, primes_3n(oracle, 3 << 6, 1), kind=rh.Matrix3N).ntt3n_layout = "block"     # too small for block order
     ring.close()
+
+
+def test_matrix_ckks_mul_by_const(rh, oracle):
+    # matrix_ckks.Evaluator.MulByConst (evaluator.go:322-380): integer constants as they are, float constants scaled by the level's modulus and
+    # rounded half away from zero; both halves of the double RNS scalar equal the constant when it is real.  Against Python integers.
+    N, L, B = 3 << 6, 3, 2
+    mods = primes_3n(oracle, N, L)
+    ring = rh.Ring(N, mods, kind=rh.Matrix3N)
+    ev = rh.MatrixCKKSEvaluator(ring)
+    rng = np.random.default_rng(77)
+    mk = lambda: np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    c0, c1 = mk(), mk()
+    ct = rh.Ciphertext([rh.DevicePoly.from_numpy(ring, c0), rh.DevicePoly.from_numpy(ring, c1)])
+    out = rh.Ciphertext([ring.NewPoly(B), ring.NewPoly(B)])
+    from fractions import Fraction
+    for const in (3, -7, 0, 2.5, -0.1, 1e-3, 12345.678):
+        scale = ev.MulByConst(ct, const, out)
+        if float(const).is_integer():
+            assert scale == 1
+            k = int(const)
+        else:
+            assert scale == mods[L - 1]
+            v = Fraction(const) * scale
+            k = int(v + Fraction(1, 2)) if const > 0 else int(v - Fraction(1, 2))
+        for src, got in ((c0, out.Value[0].numpy()), (c1, out.Value[1].numpy())):
+            for i, q in enumerate(mods):
+                want = (src[1, i].astype(object) * (k % q)) % q
+                assert [int(x) for x in got[1, i][:40]] == [int(x) for x in want[:40]], (const, i)
+                assert int(got[1, i][N - 1]) == int(want[N - 1])
+    # a complex constant: the two halves differ through RootsForward[1]; with the root w the scalars are real +- MRed(imag, w)
+    w = [int(rng.integers(1, int(q))) for q in mods]
+    scale = ev.MulByConst(ct, complex(2, 3), out, roots_forward_1=w)
+    assert scale == 1
+    got = out.Value[0].numpy()
+    for i, q in enumerate(mods):
+        im = (3 * w[i] * pow(1 << 64, -1, q)) % q
+        lo, hi = (2 + im) % q, (2 - im) % q
+        want = np.concatenate([(c0[0, i, :N // 2].astype(object) * lo) % q, (c0[0, i, N // 2:].astype(object) * hi) % q])
+        assert [int(x) for x in got[0, i]] == [int(x) for x in want]
+    with pytest.raises(rh.RingHipError):
+        ev.MulByConst(ct, complex(1, 1), out)                            # no RootsForward[1] handed over
+    with pytest.raises(rh.RingHipError):
+        ev.MulByConst(ct, 2, rh.Ciphertext([ring.AtLevel(0).NewPoly(B), ring.AtLevel(0).NewPoly(B)]))
+    ring.close()
