@@ -1065,10 +1065,12 @@ static int poly_slot_acquire(rh_ring* r, RhPolySlot** out) {
   return RH_OK;
 }
 static void poly_slot_release(rh_ring* r, RhPolySlot* sl) { std::lock_guard<std::mutex> lk(r->slot_mu); r->free_poly_slots.push_back(sl); }
-static bool host_ptr_is_pinned(const void* p) {
+// 1: page-locked host memory (DMA'd where it lies), 0: ordinary pageable memory (staged), -1: device memory (a caller's mistake: this is the HOST entry)
+static int host_ptr_kind(const void* p) {
   hipPointerAttribute_t a;
-  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // an ordinary (pageable) pointer is "invalid value" to the runtime
-  return a.type == hipMemoryTypeHost;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return 0; }   // an ordinary (pageable) pointer is "invalid value" to the runtime
+  if (a.type == hipMemoryTypeHost) return 1;
+  return (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeArray) ? -1 : 0;
 }
 static int ntt_host_poly(rh_ring* r, int level, const uint64_t* const* p1, uint64_t* const* p2, bool inverse, bool lazy) {
   if (!r) return rh_fail(RH_ERR_ARG, "null ring");
@@ -1081,8 +1083,13 @@ static int ntt_host_poly(rh_ring* r, int level, const uint64_t* const* p1, uint6
   if (int rc = poly_slot_acquire(r, &sl)) return rc;
   const size_t bytes = (size_t)N * 8;
   bool pin_in[RH_MAX_LIMBS], pin_out[RH_MAX_LIMBS], staged = false;
-  for (int i = 0; i < Lr; ++i) { pin_in[i] = host_ptr_is_pinned(p1[i]); pin_out[i] = host_ptr_is_pinned(p2[i]); staged |= !pin_in[i] || !pin_out[i]; }
   int rc = RH_OK;
+  for (int i = 0; i < Lr; ++i) {
+    const int ki = host_ptr_kind(p1[i]), ko = host_ptr_kind(p2[i]);
+    if (ki < 0 || ko < 0) { rc = rh_fail(RH_ERR_ARG, "cannot NTT: limb %d is a device pointer; device-resident polys go through rh_ring_ntt / rh_ring_intt", i); break; }
+    pin_in[i] = ki == 1; pin_out[i] = ko == 1; staged |= !pin_in[i] || !pin_out[i];
+  }
+  if (rc) { poly_slot_release(r, sl); return rc; }
   if (staged && !sl->hin) {
     sl->hwords = (size_t)N * r->L;
     if (hipHostMalloc((void**)&sl->hin, sl->hwords * 8, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void**)&sl->hout, sl->hwords * 8, hipHostMallocDefault) != hipSuccess) {

@@ -57,6 +57,11 @@ def test_config1_shape_host_pointers(rh, oracle):
         ring.NTTHost([a[:N - 1].copy()], p2)                                         # short slice: the reference panics (ring/ntt.go:212-214)
     with pytest.raises(rh.RingHipError):
         ring.NTTHost([], p2)
+    # a device pointer handed to the HOST entry is refused, not dereferenced on the CPU
+    import ctypes as C
+    dp = rh.DevicePoly.from_numpy(ring, a[None, None])
+    ins, outs = (C.c_void_p * 1)(dp.ptr), (C.c_void_p * 1)(p2[0].ctypes.data)
+    assert rh.lib().rh_ntt_poly_forward(ring._h, 0, ins, outs, 0) == -1 and b"device pointer" in rh.lib().rh_last_error()
     ring.close()
 
 
