@@ -196,3 +196,34 @@ def test_block_order_is_a_relayout_of_the_reference_order(rh, oracle, logn2, L, 
     with pytest.raises(rh.RingHipError):                                 # block order needs N = 3 * 2^k >= 24576
         small.NTT(small.NewPoly(1), small.NewPoly(1))
     small.close()
+
+
+from test_oracle_ntt3n import LARGE, large_input, check_against_large_fixture   # noqa: E402
+
+
+@pytest.mark.parametrize("vec", LARGE, ids=lambda v: "N=%d" % v["N"])
+def test_reference_python_vectors_at_config_sizes(rh, vec):
+    # the 3N kernels the configs really run (hand-scheduled layer + tile bodies, N = 3*2^13 .. 3*2^16; two radix-3 layers at 9*2^10) against
+    # outputs of the reference's own Python notes at those sizes (18-22-bit primes, omega handed over), through every route: the per-limb seam,
+    # the batched reference-order transform, and block order (tagged; numpy() converts at the host boundary)
+    N, p, w = vec["N"], vec["p"], vec["w"]
+    x = large_input(N, p)
+    ring = rh.Ring(N, [p], kind=rh.Matrix3N, omega3n=[w])
+    y = ring.SubRings[0].NTT(x)
+    check_against_large_fixture(vec, y)
+    assert np.array_equal(ring.SubRings[0].INTT(y), x)
+    B = 3
+    blk = rh.DevicePoly.from_numpy(ring, np.stack([x[None]] * B))
+    out = ring.NewPoly(B)
+    ring.NTT(blk, out)
+    got = out.numpy()
+    for k in range(B):
+        assert np.array_equal(got[k, 0], y)
+    if rh.lib().rh_ring_ntt3n_block_order_supported(ring._h):
+        ring.ntt3n_layout = "block"
+        ring.NTT(blk, out)
+        assert out.layout == "block"
+        assert np.array_equal(out.numpy()[B - 1, 0], y)
+        ring.INTT(out, out)
+        assert np.array_equal(out.numpy()[1, 0], x)
+    ring.close()
