@@ -400,3 +400,23 @@ def test_matrix_ckks_mul_by_const(rh, oracle):
     with pytest.raises(rh.RingHipError):
         ev.MulByConst(ct, 2, rh.Ciphertext([ring.AtLevel(0).NewPoly(B), ring.AtLevel(0).NewPoly(B)]))
     ring.close()
+
+
+from test_oracle_ntt3n import PRODUCT, product_inputs, check_mul_against_reference_product   # noqa: E402
+
+
+@pytest.mark.parametrize("vec", PRODUCT, ids=lambda v: "N=%d" % v["N"])
+def test_matrix_ckks_mul_against_reference_python_ring_product(rh, vec):
+    # the reference holds no vector for matrix_ckks.Evaluator.Mul.  Its Python notes do compute the ring product in
+    # Z_p[X]/(X^N - X^(N/2) + 1) (references/integer.py); the Go Mul is that product times 2^-64.  Degree 1 x degree 1, default evaluator
+    # (block-order device NTT domain where the ring allows it), sizes up to config 4's ring; the engine picks its OWN omega -- the product
+    # does not depend on which primitive 3N-th root the transform evaluates at.
+    N, p = vec["N"], vec["p"]
+    ring = rh.Ring(N, [p], kind=rh.Matrix3N)
+    a0, a1, b0, b1 = product_inputs(N, p)
+    dp = lambda v: rh.DevicePoly.from_numpy(ring, v[None, None])
+    ev = rh.MatrixCKKSEvaluator(ring)
+    out = rh.Ciphertext([ring.NewPoly(1) for _ in range(3)])
+    ev.Mul(rh.Ciphertext([dp(a0), dp(a1)]), rh.Ciphertext([dp(b0), dp(b1)]), out)
+    check_mul_against_reference_product(vec, [v.numpy()[0, 0] for v in out.Value])
+    ring.close()
