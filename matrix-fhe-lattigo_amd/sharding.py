@@ -109,13 +109,15 @@ def gather_limbs(local, own, base, st, ed, world, dist):
 class LimbShardedKeySwitch:
     """rlwe.Evaluator.GadgetProduct (core/rlwe/evaluator_gadget_product.go:16-30) with the limbs of Q ++ P dealt
     round-robin over the ranks of one node: rank r owns limbs {i : i mod world == r} and the matching slice of the
-    evaluation key.  All arithmetic is the HIP library's (rh_kshard_*, csrc/kshard.hip); this class only moves limbs:
+    evaluation key.  All arithmetic AND the orchestration are the HIP library's (rh_kshard_gadget_product, csrc/kshard.hip: INTT ->
+    exchange -> product -> exchange -> ModDown, chunks of the batch pipelined on two streams); this class supplies the one thing a
+    host must: the all-gather the library calls back for its two exchanges per chunk,
 
-      * one all-gather of every limb of INTT(cx) (8*N bytes per limb and poly; digit by digit with per_digit=True),
-      * before ModDown, one all-gather of the k+1 limbs of both P-part accumulators.
+      * every limb of INTT(cx) (8*N bytes per limb and poly),
+      * before ModDown, the k+1 limbs of both P-part accumulators.
 
-    Collectives run through torch.distributed on device tensors (backend "nccl" = RCCL over xGMI); with the "gloo"
-    backend (tests) the same blocks are staged through the host.  Outputs stay limb-sharded.
+    The callback runs torch.distributed on views of an exchange arena registered with the handle (backend "nccl" = RCCL over xGMI; with
+    "gloo", the tests' backend, the same blocks are staged through the host).  Outputs stay limb-sharded.
     Tensors are int64 views of the uint64 words, shape (npoly, owned limbs, N), on `device`."""
 
     def __init__(self, N, Q, P, rank, world, dist=None, device=0):
