@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--chunks", type=int, default=0, help="keyswitch --shard limb: chunks of the batch pipelined on two streams (0 = auto: 4 on more than one rank)")
     ap.add_argument("--gather", action="store_true", help="ntt workload: time the final device-tensor gather of result polys (outside `value`)")
     ap.add_argument("--gather-polys", type=int, default=64, help="polys per rank in the --gather leg (64 -> 512 MiB per rank at the default shape)")
+    ap.add_argument("--force-dist", action="store_true", help="pre-flight: with one rank, still create the process group and run every collective the N > 1 "
+                                                              "path makes (all-reduce, barrier, all-gather of clocks, AND of flags, the --gather leg) -- RCCL with a world of 1")
     ap.add_argument("--rank-timeout", type=float, default=1500.0, help="--gpus N without a launcher: the parent gives up (and stops its ranks) after this many seconds")
     return ap.parse_args()
 
@@ -140,9 +142,12 @@ def init_dist(args):
     dist, ranks_seen = None, 1
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:          # --force-dist without a launcher: a rendezvous of one
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -371,14 +376,14 @@ def run_ntt(args):
         gp = max(1, min(args.gather_polys, B))
         block = data[:gp]
         out = torch.empty((world, gp, L, N), dtype=torch.int64, device=dev)
-        sharding.gather_polys(block, dist, out=out)                                 # warm-up (RCCL builds its rings on first use)
+        sharding.gather_polys(block, dist, out=out, force=args.force_dist)          # warm-up (RCCL builds its rings on first use)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         reps = 3
         t0 = time.perf_counter()
         for _ in range(reps):
-            sharding.gather_polys(block, dist, out=out)
+            sharding.gather_polys(block, dist, out=out, force=args.force_dist)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -486,7 +491,7 @@ def run_ntt(args):
         "dtype": "u64", "data": "synthetic", "verified": verified,
         "config": {"workload": "Ring.NTT forward, N=2^%d, %d limbs (Qi60[0:%d]), batch %d polys/GPU, in place, device-resident" % (args.logn, L, L, B),
                    "parallelism": "batch-shard x%d, no data-path collective" % world, "limb_ntt_per_s": value * L,
-                   "dist_backend": args.dist_backend if world > 1 else None, "rccl_ranks" if args.dist_backend == "nccl" else "dist_ranks": ranks_seen,
+                   "dist_backend": args.dist_backend if (world > 1 or args.force_dist) else None, "rccl_ranks" if args.dist_backend == "nccl" else "dist_ranks": ranks_seen,
                    "per_rank_device_ms_per_step": per_rank, "verified_on": "every rank (its own batch, %d spot rows each)" % len(spots)},
         "roofline": roof,
     }

@@ -33,13 +33,14 @@ def gather_shards(local, dist):
     return out
 
 
-def gather_polys(block, dist=None, out=None):
+def gather_polys(block, dist=None, out=None, force=False):
     """The north star's one collective for the batch-sharded workloads (metric, configs 3 / 4): the final gather of the results.
     `block`: this rank's (B/G, L, N) device tensor (every rank the same shape: pad the last shard).  Returns the (G, B/G, L, N) tensor of
     every rank's block on every rank -- ONE all_gather_into_tensor on device memory (RCCL over xGMI with backend "nccl"); under "gloo"
-    (CPU rehearsal) the block is staged through the host.  `out` lets the caller supply the destination (no allocation when timing)."""
+    (CPU rehearsal) the block is staged through the host.  `out` lets the caller supply the destination (no allocation when timing);
+    `force` runs the collective even in a world of one (pre-flight of the RCCL call on a single GPU)."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         if out is None:
             return block.unsqueeze(0)
         out[0].copy_(block)

@@ -125,3 +125,50 @@ def test_bench_drops_stale_counters(tmp_path):
         assert r["traffic"] is not None and r["traffic_note"] is None
     else:
         assert r["traffic"] is None and "refresh" in r["traffic_note"]
+
+
+def test_bench_rccl_calls_with_a_world_of_one():
+    # every collective the N > 1 run makes -- all-reduce of ones, barriers, all-gather of the per-rank clocks, AND of the verification flags, the
+    # final gather as ONE all_gather_into_tensor on device memory -- through the REAL RCCL backend, with one rank on the box's one GPU
+    j = run_bench("--force-dist", "--dist-backend", "nccl", "--batch", "130", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-power", "--gather", "--gather-polys", "4")
+    assert j["n_gpus"] == 1 and j["config"]["dist_backend"] == "nccl" and j["config"]["rccl_ranks"] == 1 and j["verified"] is True
+    g = j["final_gather"]
+    assert g["verified"] is True and "RCCL" in g["what"] and g["bytes_received_per_gpu"] == 0
+
+
+def test_sharded_key_switch_callback_over_rccl_with_a_world_of_one(tmp_path):
+    # the all-gather thunk the library calls back (sharding.LimbShardedKeySwitch._allgather), with the nccl backend and a SIDE stream: a world of
+    # one makes RCCL copy the block onto itself, which is exactly the call a node makes (ExternalStream of the library's stream, views of the arena)
+    code = r'''
+import os, sys, socket
+sys.path.insert(0, %r)
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+import torch, torch.distributed as dist
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=dev)
+import matrix_fhe_lattigo_amd as rh
+from matrix_fhe_lattigo_amd import sharding
+from bench import QI60, PI60
+ks = sharding.LimbShardedKeySwitch(4096, QI60[:4], PI60[:2], 0, 1, dist=dist)
+words = 3 * 4096
+ks._arena = torch.zeros(4 * words, dtype=torch.int64, device=dev); ks._arena_words = 4 * words
+ks._arena[:words] = torch.arange(words, dtype=torch.int64, device=dev)
+side = torch.cuda.Stream(device=dev)
+torch.cuda.synchronize()
+base = ks._arena.data_ptr()
+rc = ks._allgather(None, base, base + 2 * words * 8, words, side.cuda_stream)
+side.synchronize()
+assert rc == 0, ks.cb_error
+assert torch.equal(ks._arena[2 * words:3 * words], ks._arena[:words]) and ks.exchanges == 1
+rc = ks._allgather(None, base, base + 3 * words * 8, words, None)          # the NULL stream: torch's default stream
+torch.cuda.synchronize()
+assert rc == 0 and torch.equal(ks._arena[3 * words:], ks._arena[:words])
+ks.close(); dist.destroy_process_group()
+print("RCCL_CALLBACK_OK")
+''' % ROOT
+    f = tmp_path / "cb.py"
+    f.write_text(code)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(f)], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and "RCCL_CALLBACK_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
