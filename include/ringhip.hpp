@@ -123,6 +123,22 @@ class Ring {
   void NTTLazy(const Poly& p1, Poly& p2) const { check(rh_ring_ntt_rows(h_.get(), p1.data(), p1.limbs(), p2.data(), p2.limbs(), p1.npoly(), level_, 1)); }
   void INTT(const Poly& p1, Poly& p2) const { check(rh_ring_intt_rows(h_.get(), p1.data(), p1.limbs(), p2.data(), p2.limbs(), p1.npoly(), level_, 0)); }
   void INTTLazy(const Poly& p1, Poly& p2) const { check(rh_ring_intt_rows(h_.get(), p1.data(), p1.limbs(), p2.data(), p2.limbs(), p1.npoly(), level_, 1)); }
+  // Ring.NTT / NTTLazy / INTT / INTTLazy on a whole HOST poly in one call (ring/ntt.go:127-152: the loop over Poly.Coeffs [][]uint64):
+  // coeffs[i] = limb i's slice (>= N words; pageable, or page-locked memory from rh_host_alloc / rh_host_register), limbs 0..level of this view
+  void NTT(const std::vector<const uint64_t*>& p1, const std::vector<uint64_t*>& p2) const { hostPoly(rh_ntt_poly_forward, p1, p2, 0); }
+  void NTTLazy(const std::vector<const uint64_t*>& p1, const std::vector<uint64_t*>& p2) const { hostPoly(rh_ntt_poly_forward, p1, p2, 1); }
+  void INTT(const std::vector<const uint64_t*>& p1, const std::vector<uint64_t*>& p2) const { hostPoly(rh_ntt_poly_backward, p1, p2, 0); }
+  void INTTLazy(const std::vector<const uint64_t*>& p1, const std::vector<uint64_t*>& p2) const { hostPoly(rh_ntt_poly_backward, p1, p2, 1); }
+  // 3N rings: the NTT-domain layout as an argument of the call (the host tags its blocks: DevicePoly.layout in Python, DevPoly.BlockOrder in Go)
+  bool BlockOrderSupported() const { return rh_ring_ntt3n_block_order_supported(h_.get()) != 0; }
+  void NTTLayout(const Poly& p1, Poly& p2, bool blockOrder) const {
+    check(rh_ring_ntt_layout(h_.get(), p1.data(), p1.limbs(), p2.data(), p2.limbs(), p1.npoly(), level_, 0, blockOrder ? 1 : 0));
+  }
+  void INTTLayout(const Poly& p1, Poly& p2, bool blockOrder) const {
+    check(rh_ring_ntt_layout(h_.get(), p1.data(), p1.limbs(), p2.data(), p2.limbs(), p1.npoly(), level_, 1, blockOrder ? 1 : 0));
+  }
+  void NTT3NReorder(const Poly& p1, Poly& p2, bool toReference) const { check(rh_ring_ntt3n_reorder(h_.get(), p1.data(), p2.data(), p1.npoly(), level_, toReference ? 1 : 0)); }
+  long Stats(const char* key) const { long v = 0; check(rh_ring_stats(h_.get(), key, &v)); return v; }
   // Ring.NTT on several blocks in one call (rh_ring_ntt_many): every poly of a block at this view's level (limbs() == level + 1)
   void NTTMany(const std::vector<std::pair<const Poly*, Poly*>>& blocks) const {
     std::vector<const uint64_t*> in; std::vector<uint64_t*> out; std::vector<int> cnt;
@@ -189,6 +205,11 @@ class Ring {
 
   std::vector<SubRing> SubRings;
  private:
+  template <class F> void hostPoly(F f, const std::vector<const uint64_t*>& p1, const std::vector<uint64_t*>& p2, int lazy) const {
+    if ((int)p1.size() < level_ + 1 || (int)p2.size() < level_ + 1)
+      throw Panic("cannot NTT: poly has " + std::to_string(p1.size()) + " / " + std::to_string(p2.size()) + " limbs, ring level needs " + std::to_string(level_ + 1));
+    check(f(h_.get(), level_, p1.data(), p2.data(), lazy));
+  }
   void adopt(rh_ring* h) {
     h_.reset(h, rh_ring_destroy);
     for (int i = 0; i < (int)moduli_.size(); ++i) SubRings.emplace_back(h, i, N_, moduli_[i]);
@@ -282,6 +303,13 @@ class KeySwitchShard {
   }
   void ModDown(const uint64_t* srcPGathered, const Poly& ctIn, Poly& ctOut) const {
     check(rh_kshard_moddown(h_.get(), srcPGathered, ctIn.data(), ctOut.data(), ctIn.npoly()));
+  }
+  // the whole product in one call (rlwe.Evaluator.GadgetProduct on the owned limbs): the host supplies the all-gather -- ncclAllGather on a node
+  // (tests/cpp/test_sharded_host.cpp runs it with threads as ranks).  owner[i]: the rank of limb i of Q ++ P.
+  void SetWorld(int world, int rank, const std::vector<int>& owner) const { check(rh_kshard_set_world(h_.get(), world, rank, owner.data())); }
+  void GadgetProduct(const Poly& cxLoc, const uint64_t* evkQLoc, const uint64_t* evkPLoc, Poly& ct0, Poly& ct1, rh_allgather_fn allgather, void* ctx,
+                     int chunks = 0) const {
+    check(rh_kshard_gadget_product(h_.get(), cxLoc.data(), evkQLoc, evkPLoc, ct0.data(), ct1.data(), cxLoc.npoly(), allgather, ctx, chunks));
   }
  private:
   std::shared_ptr<rh_kshard> h_;

@@ -195,6 +195,27 @@ int main() {
     }
     EXPECT(s0.download() == d0.download());
     EXPECT(s1.download() == d1.download());
+    // the whole sharded product in ONE call (round 3): a handle that owns every limb needs no map and no all-gather
+    Poly w0 = rq.NewPoly(np), w1 = rq.NewPoly(np);
+    ks.GadgetProduct(cx, kq.data(), kp.data(), w0, w1, nullptr, nullptr, 2);      // two chunks on the side streams
+    rq.Sync();
+    EXPECT(w0.download() == d0.download());
+    EXPECT(w1.download() == d1.download());
+  }
+
+  // round 3: Ring.NTT(p1, p2 Poly) on a whole host poly in one call, the KAT again (ring/ntt_test.go:10-89, N = 16, both limbs)
+  {
+    std::vector<uint64_t> o0(16), o1(16);
+    r.NTT(std::vector<const uint64_t*>{KAT16_POLY_0.data(), KAT16_POLY_1.data()}, std::vector<uint64_t*>{o0.data(), o1.data()});
+    EXPECT(o0 == KAT16_NTT_0);
+    EXPECT(o1 == KAT16_NTT_1);
+    r.INTT(std::vector<const uint64_t*>{o0.data(), o1.data()}, std::vector<uint64_t*>{o0.data(), o1.data()});      // in place
+    EXPECT(o0 == KAT16_POLY_0);
+    EXPECT(o1 == KAT16_POLY_1);
+    bool short_poly = false;
+    try { r.NTT(std::vector<const uint64_t*>{KAT16_POLY_0.data()}, std::vector<uint64_t*>{o0.data()}); } catch (const Panic&) { short_poly = true; }
+    EXPECT(short_poly);
+    EXPECT(r.Stats("rows_poly_by_poly") == 0);
   }
 
   // error behaviour
