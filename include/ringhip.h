@@ -153,6 +153,14 @@ int rh_ring_intt_rows(rh_ring* r, const uint64_t* in_dev, int in_rows, uint64_t*
  * than the three calls.  a, b: npoly polys of level+1 limbs, canonical or lazy (< 2q); out may alias either.  Standard rings. */
 int rh_ring_intt_mul(rh_ring* r, const uint64_t* a_dev, const uint64_t* b_dev, uint64_t* out_dev, int npoly, int level);
 
+/* The whole of BASELINE config 3 from COEFFICIENT-domain operands: out = INTT(NTT(a) . NTT(b)), the values of ring.NTT(a); ring.NTT(b);
+ * ring.MForm; ring.MulCoeffsMontgomery; ring.INTT (schemes/ckks/evaluator.go:821-834 around a fresh product) -- canonical, hence bit-identical.
+ * The forward tile stages of both operands, their product and the inverse tile stages run as ONE kernel per 4096-coefficient tile: NTT(a), NTT(b)
+ * and the product never reach memory (72 instead of 104 bytes per coefficient).  a and b are CONSUMED: they are transformed in place as far as
+ * their column stages and do not hold NTT(a) / NTT(b) afterwards (a caller that needs those keeps rh_ring_ntt_many + rh_ring_intt_mul).  out may
+ * alias a or b; a != b.  Standard rings, 2^13 <= N <= 2^17 (otherwise RH_ERR_UNSUPPORTED). */
+int rh_ring_polymul(rh_ring* r, uint64_t* a_dev, uint64_t* b_dev, uint64_t* out_dev, int npoly, int level);
+
 /* 3N rings: NTT-domain blocks between the reference's ascending-totative order and block order (see ntt3n_block_order):
  * to_reference = 1: block order -> reference order, 0: the reverse.  Out of place (in != out). */
 int rh_ring_ntt3n_reorder(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int npoly, int level, int to_reference);

@@ -925,6 +925,39 @@ extern "C" int rh_ring_intt_mul(rh_ring* r, const uint64_t* a, const uint64_t* b
   return std_intt_mul_launch(r, a, b, out, npoly, level + 1);
 }
 
+// c = INTT(NTT(a) . NTT(b)) with a and b given in the COEFFICIENT domain (BASELINE config 3: ring.NTT(a), ring.NTT(b), ring.MForm,
+// ring.MulCoeffsMontgomery, ring.INTT -- schemes/ckks/evaluator.go:821-834 around a fresh product): forward column stages of a and of b in
+// place, then ONE kernel for the forward tile stages of both, their product and the inverse tile stages (ntt_polymul_tile_asm), then the inverse
+// column stages.  Same canonical values as the five ring calls; a and b are CONSUMED (they hold their column-stage intermediates afterwards,
+// not NTT(a) / NTT(b)); out may alias either.  Standard rings, 2^13 <= N <= 2^17, hand-scheduled tile bodies; other shapes: RH_ERR_UNSUPPORTED
+// (the caller falls back to rh_ring_ntt_many + rh_ring_intt_mul).
+extern "C" int rh_ring_polymul(rh_ring* r, uint64_t* a, uint64_t* b, uint64_t* out, int npoly, int level) {
+  if (!r || !a || !b || !out) return rh_fail(RH_ERR_ARG, "polymul: null argument");
+  if (level < 0 || level >= r->L) return rh_fail(RH_ERR_ARG, "polymul: level %d out of range [0,%d)", level, r->L);
+  if (npoly < 0) return rh_fail(RH_ERR_ARG, "polymul: npoly < 0");
+  if (a == b) return rh_fail(RH_ERR_ARG, "polymul: a and b must be different blocks (both are transformed in place)");
+  const int S1 = r->logN - LT;
+  if (r->kind != RH_RING_STANDARD || S1 < 1 || S1 > 5 || !r->asm_tile) return rh_fail(RH_ERR_UNSUPPORTED, "polymul: standard rings with 2^13 <= N <= 2^17 and the hand-scheduled tile bodies");
+  const int Lrows = level + 1;
+  const unsigned rows = (unsigned)npoly * (unsigned)Lrows;
+  if (rows == 0) return RH_OK;
+  (void)hipSetDevice(r->device);
+  if (int rc = std_ntt_launch_span(r, a, a, npoly, Lrows, 0, false, false, 1)) return rc;       // column stages only (phase 1), in place
+  if (int rc = std_ntt_launch_span(r, b, b, npoly, Lrows, 0, false, false, 1)) return rc;
+  (void)hipGetLastError();
+  hipStream_t st = rh_stream(r);
+  if (rh_streams_beyond_cache(r, rows)) ntt_polymul_tile_asm<true><<<rows << S1, 256, 0, st>>>(a, b, out, r->d_twk_fwd, r->d_twk_inv, r->d_consts_r, Lrows, r->logN, npoly);
+  else ntt_polymul_tile_asm<false><<<rows << S1, 256, 0, st>>>(a, b, out, r->d_twk_fwd, r->d_twk_inv, r->d_consts_r, Lrows, r->logN, npoly);
+  const bool nt = rh_streams_beyond_cache(r, rows);
+  if (S1 >= 2 && S1 <= 4 && r->asm_cols) {
+#define RH_PM_COLS(S) do { if (nt) ntt_inv_cols_asm<S, true><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows, 0); \
+                           else ntt_inv_cols_asm<S, false><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows, 0); } while (0)
+    if (S1 == 4) RH_PM_COLS(4); else if (S1 == 3) RH_PM_COLS(3); else RH_PM_COLS(2);
+#undef RH_PM_COLS
+  } else launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows, r->logN, 1);
+  return check_launch("polymul");
+}
+
 extern "C" int rh_ring_ntt3n_reorder(rh_ring* r, const uint64_t* in, uint64_t* out, int npoly, int level, int to_reference) {
   if (!r || !in || !out) return rh_fail(RH_ERR_ARG, "ntt3n_reorder: null argument");
   if (r->kind != RH_RING_3N) return rh_fail(RH_ERR_ARG, "ntt3n_reorder: not a 3N ring");

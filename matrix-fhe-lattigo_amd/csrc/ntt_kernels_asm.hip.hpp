@@ -275,6 +275,40 @@ ntt_inv_tile_mul_asm(const u64* in, const u64* in2, u64* out, const tw2* __restr
   __shared__ u64 lds[LDS_WORDS];
   inv_tile_asm_body<true>(lds, blockIdx.x, in, in2, out, twk, consts, L, logN, npoly);
 }
+// ---- c = INTT(NTT(a) . NTT(b)), the tile-stage middle in ONE kernel (BASELINE config 3; tools/gen_tile_asm.py: gen_polymul): forward tile
+// stages of a's and of b's column-stage outputs, MRedLazy product, inverse tile stages -- NTT(a), NTT(b) and their product never reach memory
+// (72 instead of 104 bytes per coefficient of a poly-mul).  The forward body leaves thread tid with coefficients 16 tid + k, where the inverse
+// body's first round starts, so two LDS transposes drop out too.  156 VGPRs: 3 workgroups per CU.  out may alias a or b (a tile is read whole
+// before it is written).  consts: qinv for the product; the factor 2^64 is restored by the inverse column stages' constants (d_consts_r).
+template <bool NT = false>
+__global__ void __launch_bounds__(256)
+ntt_polymul_tile_asm(const u64* a, const u64* b2, u64* out, const tw2* __restrict__ twk_fwd, const tw2* __restrict__ twk_inv,
+                     const LimbConsts* __restrict__ consts, int L, int logN, int npoly) {
+  __shared__ u64 lds[LDS_WORDS];
+  const u32 b = blockIdx.x;
+  const u32 limb = b % (u32)L;
+  const u32 r = b / (u32)L;
+  const u32 poly = r % (u32)npoly;
+  const u32 tile = r / (u32)npoly;
+  const size_t base = (((size_t)poly * L + limb) << logN) + ((size_t)tile << LT);
+  const size_t toff = ((size_t)limb << logN) + ((size_t)tile << LT);
+  const u64 pin = uni64((u64)(size_t)(a + base)), pin2 = uni64((u64)(size_t)(b2 + base)), pout = uni64((u64)(size_t)(out + base));
+  const u64 tw = uni64((u64)(size_t)(twk_fwd + toff)), twi = uni64((u64)(size_t)(twk_inv + toff));
+  const u64 q = uni64(consts[limb].q), qinv = uni64(consts[limb].qinv);
+  const u64 nq = (u64)0 - q, nq2 = (u64)0 - 2 * q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
+  const u32 lds_off = uni32((u32)(size_t)lds);
+  const u32 tid = threadIdx.x;
+#define RH_TILE_POLYMUL_ASM(BODY)                                                                                                          \
+  asm volatile(BODY : : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pin2] "s"(pin2), [pout] "s"(pout), [tw] "s"(tw),               \
+               [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)), [twi] "s"(twi), [twilo] "s"((u32)(size_t)twi),            \
+               [twihi] "s"((u32)((size_t)twi >> 32)), [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)), [nq] "s"(nq), [nq2] "s"(nq2),       \
+               [nq4] "s"(nq4), [q4] "s"(q4), [q] "s"(q), [q0] "s"((u32)q), [q1] "s"((u32)(q >> 32)), [qi0] "s"((u32)qinv),                 \
+               [qi1] "s"((u32)(qinv >> 32)) : NTT_TILE_POLYMUL_ASM_CLOBBERS)
+  if constexpr (NT) RH_TILE_POLYMUL_ASM(NTT_TILE_POLYMUL_ASM_BODY_NT);
+  else RH_TILE_POLYMUL_ASM(NTT_TILE_POLYMUL_ASM_BODY);
+#undef RH_TILE_POLYMUL_ASM
+}
+
 // software-pipelined inverse: tile stages of span j (in -> out), then column stages + N^-1 of span j-1 (in place)
 template <int S1, bool ASMCOLS = false, bool MUL = false, bool NT = true>
 __global__ void __launch_bounds__(256)

@@ -104,6 +104,7 @@ def lib():
         "rh_ring_ntt_rows": (i, [vp, vp, i, vp, i, i, i, i]), "rh_ring_intt_rows": (i, [vp, vp, i, vp, i, i, i, i]),
         "rh_ring_vec_op_rows": (i, [vp, i, vp, i, vp, i, vp, i, i, i, U64P, U64P]),
         "rh_ring_intt_mul": (i, [vp, vp, vp, vp, i, i]),
+        "rh_ring_polymul": (i, [vp, vp, vp, vp, i, i]),
         "rh_ring_ntt_many": (i, [vp, vp, vp, vp, i, i]),
         "rh_ring_ntt3n_reorder": (i, [vp, vp, vp, i, i, i]),
         "rh_ring_set_tuning": (i, [vp, C.c_char_p, C.c_long]),
@@ -487,6 +488,12 @@ class Ring:
             self.MForm(p1, p3); self.MulCoeffsMontgomery(p3, p2, p3); self.INTT(p3, p3)
             return
         _check(lib().rh_ring_intt_mul(self._h, p1.ptr, p2.ptr, p3.ptr, p1.npoly, self.level))
+
+    def PolyMul(self, p1, p2, p3):
+        """p3 = INTT(NTT(p1) . NTT(p2)) for COEFFICIENT-domain p1, p2 (BASELINE config 3): the canonical values of NTT; NTT; MForm;
+        MulCoeffsMontgomery; INTT with the tile-stage middle of all three transforms as one kernel (rh_ring_polymul).  p1 and p2 are consumed
+        (they hold column-stage intermediates afterwards).  Raises RingHipError for shapes the fused kernel does not cover."""
+        self._chk(p1, p2, p3); _check(lib().rh_ring_polymul(self._h, p1.ptr, p2.ptr, p3.ptr, p1.npoly, self.level))
 
     # ---- automorphisms (ring/automorphism.go) ---------------------------------------------------------------
     def TensorDegree1(self, a0, a1, b0, b1, c0, c1, c2, mform_first=True):

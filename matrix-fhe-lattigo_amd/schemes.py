@@ -247,7 +247,12 @@ def ckks_polymul(ringQ, a, b, c, tmp=None, fused=True):
     """BASELINE config 3: c = INTT(NTT(a) . NTT(b)) with MForm + MulCoeffsMontgomery as mulRelin sequences it
     (schemes/ckks/evaluator.go:821-834).  a and b are transformed in place (they end in the NTT domain).
     fused (default): MForm, MulCoeffsMontgomery and the inverse transform as ONE call (Ring.INTTMul: the product is formed on
-    load by the inverse transform's first kernel) -- same canonical values; fused=False: the five ring calls as written."""
+    load by the inverse transform's first kernel) -- same canonical values; fused=False: the five ring calls as written;
+    fused="tile": Ring.PolyMul -- the forward tile stages of both operands, the product and the inverse tile stages as one kernel
+    (a and b are CONSUMED: they do not end as NTT(a), NTT(b); same c)."""
+    if fused == "tile":
+        ringQ.PolyMul(a, b, c)
+        return
     if fused:
         ringQ.NTTMany([(a, a), (b, b)])
     else:

@@ -420,3 +420,45 @@ def test_matrix_ckks_mul_against_reference_python_ring_product(rh, vec):
     ev.Mul(rh.Ciphertext([dp(a0), dp(a1)]), rh.Ciphertext([dp(b0), dp(b1)]), out)
     check_mul_against_reference_product(vec, [v.numpy()[0, 0] for v in out.Value])
     ring.close()
+
+
+@pytest.mark.parametrize("logN,L,B", [(13, 2, 3), (14, 5, 2), (15, 16, 3), (16, 3, 5), (17, 2, 1), (15, 16, 130)])
+def test_polymul_one_tile_kernel_equals_the_five_ring_calls(rh, oracle, logN, L, B):
+    # Ring.PolyMul (rh_ring_polymul): forward tile stages of both operands + product + inverse tile stages as ONE kernel per 4096-tile (config 3
+    # without NTT(a), NTT(b) or the product in memory) -- the canonical values of NTT, NTT, MForm, MulCoeffsMontgomery, INTT, bit for bit; the
+    # last case (1 GiB per operand) takes the non-temporal bodies
+    N, mods = 1 << logN, QI60[:L]
+    ring = rh.Ring(N, mods)
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(logN * 1000 + L * 10 + B)
+    qs = torch.tensor(mods, dtype=torch.int64, device=dev).view(1, L, 1)
+    ta = torch.randint(0, 1 << 62, (B, L, N), dtype=torch.int64, device=dev, generator=g) % qs
+    tb = torch.randint(0, 1 << 62, (B, L, N), dtype=torch.int64, device=dev, generator=g) % qs
+    ta[0, :, :3] = torch.tensor([0, 1, 2], device=dev)
+    tb[B - 1, :, N - 1] = qs.view(L) - 1
+    keep_a, keep_b = ta.clone(), tb.clone()
+    dp = lambda t: rh.DevicePoly.from_torch(ring, t)
+    ref = torch.empty_like(ta)
+    ra, rb = keep_a.clone(), keep_b.clone()
+    rh.ckks_polymul(ring, dp(ra), dp(rb), dp(ref), dp(torch.empty_like(ta)), fused=False)     # the five ring calls as written
+    out = torch.empty_like(ta)
+    rh.ckks_polymul(ring, dp(ta), dp(tb), dp(out), fused="tile")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    # output aliasing an operand
+    ta2, tb2 = keep_a.clone(), keep_b.clone()
+    ring.PolyMul(dp(ta2), dp(tb2), dp(tb2))
+    torch.cuda.synchronize()
+    assert torch.equal(tb2, ref)
+    # one row against the oracle's own sequence
+    k, i = B - 1, L - 1
+    sr = oracle.SubRingConsts(N, mods[i])
+    h = lambda t: t[k, i].cpu().numpy().view(np.uint64)
+    A, Bn = oracle.ntt(h(keep_a), sr), oracle.ntt(h(keep_b), sr)
+    prod = oracle.vec_op(rh.OPS["MUL_MONT"], oracle.vec_op(rh.OPS["MFORM"], A, A, A, 0, 0, mods[i]), Bn, Bn, 0, 0, mods[i])
+    assert np.array_equal(h(out), oracle.intt(prod, sr))
+    with pytest.raises(rh.RingHipError):
+        small = rh.Ring(4096, mods)
+        small.PolyMul(small.NewPoly(1), small.NewPoly(1), small.NewPoly(1))                     # N = 4096: not covered by the fused kernel
+    ring.close()

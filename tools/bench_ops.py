@@ -82,6 +82,18 @@ ms = timed(polymul_fused, reps=5)
 e = entry("config3 poly-mul N=2^15 L=16, MForm + MulCoeffsMontgomery formed on load by the inverse transform (Ring.INTTMul)", ms, 88.0 * N * L * B, B, "polymul")
 e["frac_vs_fused_lower_bound_24NL"] = round(24.0 * N * L * B / (ms * 1e-3) / 1e9 / PEAK, 3)
 res.append(e)
+def polymul_many():
+    ring.NTTMany([(pa, pa), (pb, pb)]); ring.INTTMul(pa, pb, pa)
+ms = timed(polymul_many, reps=5)
+e = entry("config3 poly-mul N=2^15 L=16, one pipeline through both forward transforms (Ring.NTTMany) + Ring.INTTMul", ms, 88.0 * N * L * B, B, "polymul")
+e["frac_vs_fused_lower_bound_24NL"] = round(24.0 * N * L * B / (ms * 1e-3) / 1e9 / PEAK, 3)
+res.append(e)
+def polymul_tile():
+    ring.PolyMul(pa, pb, pa)
+ms = timed(polymul_tile, reps=5)
+e = entry("config3 poly-mul N=2^15 L=16, Ring.PolyMul: forward tile stages of both operands + product + inverse tile stages as ONE kernel (72 B per coefficient)", ms, 88.0 * N * L * B, B, "polymul")
+e["frac_vs_fused_lower_bound_24NL"] = round(24.0 * N * L * B / (ms * 1e-3) / 1e9 / PEAK, 3)
+res.append(e)
 del pa, pb, a, b
 ring.close(); torch.cuda.empty_cache()
 

@@ -1,0 +1,25 @@
+import sys, json
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import torch
+import matrix_fhe_lattigo_amd as rh
+from conftest import QI60
+dev = torch.device("cuda", 0); stream = torch.cuda.current_stream()
+def timed(fn, reps=8, warm=2):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps): fn()
+    e1.record(stream); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+for logn, B in ((15, 512), (16, 256), (14, 1024), (13, 2048)):
+    N, L = 1 << logn, 16
+    ring = rh.Ring(N, QI60[:L]); ring.set_stream(stream.cuda_stream)
+    qs = torch.tensor(QI60[:L], dtype=torch.int64, device=dev).view(1, L, 1)
+    a = torch.randint(0, 1 << 62, (B, L, N), dtype=torch.int64, device=dev) % qs
+    b = torch.randint(0, 1 << 62, (B, L, N), dtype=torch.int64, device=dev) % qs
+    pa, pb = rh.DevicePoly.from_torch(ring, a), rh.DevicePoly.from_torch(ring, b)
+    t1 = timed(lambda: (ring.NTTMany([(pa, pa), (pb, pb)]), ring.INTTMul(pa, pb, pa)))
+    t2 = timed(lambda: ring.PolyMul(pa, pb, pa))
+    print("N=2^%d B=%d: NTTMany+INTTMul %.3f ms (%.1f k/s) | PolyMul %.3f ms (%.1f k/s)  x%.3f" % (logn, B, t1, B / t1, t2, B / t2, t1 / t2), flush=True)
+    del pa, pb, a, b; ring.close(); torch.cuda.empty_cache()

@@ -246,7 +246,7 @@ INV_SLOT_ORDER = list(range(7, 15)) + list(range(3, 7)) + [1, 2] + [0]      # co
 INV_NEED = {3: 8, 2: 12, 1: 14, 0: 15}                                      # twiddle quads needed before stage u
 
 
-def gen_inverse(mul=False):
+def gen_inverse(mul=False, from_registers=False):
     """first 12 stages (t = 1..2048) of the inverse transform on a 4096-tile; values leave < 4q (no scaling):
     mirror image of gen(); same LDS layout and kernel-order twiddle table (built from RootsBackward).
     mul: the input is the pointwise Montgomery product of two blocks (pin, pin2), formed on load (rh_ring_intt_mul); the second
@@ -261,6 +261,8 @@ def gen_inverse(mul=False):
     for j in range(4):
         emit("v_add_u32 v%d, %d, v%d" % (SCR + j, 8192 * j + 4096, A0))
     for k in range(16):
+        if from_registers:                                    # gen_polymul: x[k] already holds coefficient 16 tid + k (the layout of round C')
+            break
         j, rem = divmod(k, 4)
         emit("global_load_dwordx2 %s, v%d, %%[pin] offset:%d" % (pair(X(k)), SCR + j, rem * 2048 - 4096))
     if mul:
@@ -283,14 +285,15 @@ def gen_inverse(mul=False):
     emit("v_add_u32 v%d, %%[lds], v%d" % (A3, A3))            # addrA
     emit("v_mul_u32_u24 v%d, 136, %%[tid]" % A0)
     emit("v_add_u32 v%d, %%[lds], v%d" % (A0, A0))            # addrC
-    emit("s_waitcnt vmcnt(15)")                               # the 16 data loads
-    for k in range(16):
-        emit("ds_write_b64 v%d, %s offset:%d" % (A3, pair(X(k)), 2176 * k))
-    emit("s_waitcnt lgkmcnt(0)")
-    emit("s_barrier")
-    for k in range(16):
-        emit("ds_read_b64 %s, v%d offset:%d" % (pair(X(k)), A0, 8 * k))
-    emit("s_waitcnt lgkmcnt(0)")
+    if not from_registers:
+        emit("s_waitcnt vmcnt(15)")                           # the 16 data loads
+        for k in range(16):
+            emit("ds_write_b64 v%d, %s offset:%d" % (A3, pair(X(k)), 2176 * k))
+        emit("s_waitcnt lgkmcnt(0)")
+        emit("s_barrier")
+        for k in range(16):
+            emit("ds_read_b64 %s, v%d offset:%d" % (pair(X(k)), A0, 8 * k))
+        emit("s_waitcnt lgkmcnt(0)")
     emit("; ---- round C' (t = 1, 2, 4, 8)")
     round16_inv(lambda slot: (TW0 + 4 * slot, None), stage_hook=lambda u: emit("s_waitcnt vmcnt(%d)" % (15 - INV_NEED[u])))
     # round B' twiddles: tw[16 + slot*16 + hi4]
@@ -329,6 +332,34 @@ def gen_inverse(mul=False):
     emit("s_waitcnt vmcnt(0)")
 
 
+SAVE0 = 124          # gen_polymul: the first operand's 16 transformed coefficients wait in v124..v155 while the second is transformed
+NVGPR_POLYMUL = 156
+
+
+def gen_polymul():
+    """One workgroup, one 4096-tile: forward tile stages of a (pin) and of b (pin2), their pointwise Montgomery product, the inverse
+    tile stages, store (pout) -- the middle of c = INTT(NTT(a) . NTT(b)) (BASELINE config 3) without NTT(a), NTT(b) or their product
+    ever reaching memory.  The forward body ends with thread tid holding coefficients 16 tid + k, which is where the inverse body's
+    first round starts: the forward transpose + store and the inverse load + transpose drop out with the memory passes.
+    Operands: the forward body's, plus pin2, twi / twilo / twihi (kernel-order inverse table) and qi0 / qi1 / q0 / q1 / q (MRedLazy)."""
+    gen(stop_after_reduce=True)
+    for k in range(16):
+        emit("v_mov_b32 v%d, v%d" % (SAVE0 + 2 * k, X(k)))
+        emit("v_mov_b32 v%d, v%d" % (SAVE0 + 2 * k + 1, X(k) + 1))
+    mark = len(out)
+    gen(stop_after_reduce=True, barrier_before_lds=True)
+    for i in range(mark, len(out)):
+        out[i] = out[i].replace("%[pin]", "%[pin2]")
+    emit("; ---- x[k] = MRedLazy(NTT(b)[k], NTT(a)[k]) < 2q")
+    for k in range(0, 16, 2):
+        for ins in interleave(mred_lazy_steps(X(k), SAVE0 + 2 * k, T0), mred_lazy_steps(X(k + 1), SAVE0 + 2 * (k + 1), T1)):
+            emit(ins)
+    mark = len(out)
+    gen_inverse(from_registers=True)
+    for i in range(mark, len(out)):
+        out[i] = out[i].replace("%[tw]", "%[twi]").replace("%[twlo]", "%[twilo]").replace("%[twhi]", "%[twihi]")
+
+
 def round16(tw_of_slot, stage_hook=None, pair_hook=None, stages=4):
     """`stages` stages over x[0 .. 2^stages - 1] (4 -> the radix-16 round); tw_of_slot(slot) -> (vgpr_quad_index or None,
     sgpr tuple or None).  stage_hook(u) / pair_hook(u, i) emit waits just before the first consumer (guide G15)"""
@@ -364,7 +395,7 @@ def csub_all(const_name):
             emit("v_bfi_b32 v%d, v%d, v%d, v%d" % (X(kk) + 1, t.M, X(kk) + 1, t.T + 1))
 
 
-def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True, epilogue=None, lazy_out=False):
+def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True, epilogue=None, lazy_out=False, stop_after_reduce=False, barrier_before_lds=False):
     A0, A1, A2, A3 = ADDR, ADDR + 1, ADDR + 2, ADDR + 3
     emit("; ---- prologue: zero halves of the zero-extended pairs, addresses")
     if PRIO in (1, 2):
@@ -408,6 +439,8 @@ def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True, epilogue
             emit("s_waitcnt vmcnt(%d)" % (31 - (2 * i + 4)))
     round16(lambda slot: (None, ("s%d" % (36 + 4 * slot), "s%d" % (37 + 4 * slot), "s%d" % (38 + 4 * slot), "s%d" % (39 + 4 * slot))),
             pair_hook=a_pair_hook)
+    if barrier_before_lds:                                    # a second transform in the same workgroup (gen_polymul): every wave must have
+        emit("s_barrier")                                     # finished the previous transform's LDS reads before the tile is written again
     for k in range(16):
         emit("ds_write_b64 v%d, %s offset:%d" % (A3, pair(X(k)), 2176 * k))
     # addrB
@@ -453,6 +486,8 @@ def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True, epilogue
         csub_all("nq4")                                       # multiply-accumulate of the gadget product takes any 64-bit operand)
         csub_all("nq2")
         csub_all("nq")
+    if stop_after_reduce:                                     # gen_polymul: thread tid now holds the canonical NTT values of coefficients
+        return                                                # 16 tid + k in x[k] -- the layout the inverse tile's first round starts from
     for k in range(16):
         emit("ds_write_b64 v%d, %s offset:%d" % (A1, pair(X(k)), 8 * k))
     emit("s_waitcnt lgkmcnt(0)")
@@ -1115,6 +1150,10 @@ for _suffix, _flags in (("", ""), ("_NT", " nt")):
     del out[:]
     gen_inverse(mul=True)
     inv_mul = list(out)
+    del out[:]
+    gen_polymul()
+    polymul = list(out)
+    bodies_text += render("NTT_TILE_POLYMUL_ASM_BODY" + _suffix, polymul)
     bodies_text += (render("NTT_TILE_ASM_BODY" + _suffix, fwd) + render("NTT_TILE_LAZY_ASM_BODY" + _suffix, fwd_lazy) + render("NTT_TILE_SUBMUL_ASM_BODY" + _suffix, fwd_sm)
                     + render("NTT_TILE_SUBMUL_ADD_ASM_BODY" + _suffix, fwd_sma)
                     + "".join(render("NTT_COLS%d_ASM_BODY%s" % (1 << k, _suffix), cols[k]) + render("NTT_COLS%d_INV_ASM_BODY%s" % (1 << k, _suffix), cols_inv[k])
@@ -1126,6 +1165,7 @@ clob_s = ", ".join('"s%d"' % i for i in range(36, 100))
 text = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  forward: %d instructions, inverse: %d; NAME_NT = the same body with non-temporal data streams.\n" % (len(fwd), len(inv))
 text += bodies_text
 text += "#define NTT_TILE_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (clob_v, clob_s)
+text += "#define NTT_TILE_POLYMUL_ASM_CLOBBERS %s, %s, \"vcc\", \"scc\", \"memory\"\n" % (", ".join('"v%d"' % i for i in range(NVGPR_POLYMUL)), clob_s)
 path = sys.argv[1] if len(sys.argv) > 1 else "ntt_tile_asm.inc"
 open(path, "w").write(text)
 text3 = "// GENERATED by tools/gen_tile_asm.py -- do not edit.  3N transform: column stages fused with the radix-3 layer and the split / merge, both directions.\n"
