@@ -942,10 +942,34 @@ extern "C" int rh_ring_polymul(rh_ring* r, uint64_t* a, uint64_t* b, uint64_t* o
   const unsigned rows = (unsigned)npoly * (unsigned)Lrows;
   if (rows == 0) return RH_OK;
   (void)hipSetDevice(r->device);
+  hipStream_t st = rh_stream(r);
+  int chunk = r->chunk_polys;
+  if (chunk < 0) { const int c = r->auto_span_rows / Lrows > 0 ? r->auto_span_rows / Lrows : 1; chunk = npoly > c ? c : 0; }
+  if (chunk > 0 && npoly > chunk) {
+    // large batches: ONE stream of launches, launch j = column stages of span j + tile middle of span j-1 + inverse column stages of span j-2
+    (void)hipGetLastError();
+    const int nspans = (npoly + chunk - 1) / chunk;
+    const size_t stride = (size_t)Lrows * r->N;
+    const bool nt = r->nt_streams;                         // a pipelined batch is always far beyond the Infinity Cache (three blocks of >= 2048 rows)
+    auto span = [&](int j, int* n) { const int p0 = j * chunk; *n = (j < 0 || j >= nspans) ? 0 : (npoly - p0 < chunk ? npoly - p0 : chunk); return (size_t)(j < 0 ? 0 : p0) * stride; };
+    for (int j = 0; j < nspans + 2; ++j) {
+      int p1, p2, p3;
+      const size_t o1 = span(j, &p1), o2 = span(j - 1, &p2), o3 = span(j - 2, &p3);
+      const unsigned n1 = (unsigned)p1 * Lrows * 16, n2 = ((unsigned)p2 * Lrows) << S1, n3 = (unsigned)p3 * Lrows * 16;
+      const unsigned grid = n1 > n2 ? (n1 > n3 ? n1 : n3) : (n2 > n3 ? n2 : n3);
+      if (!grid) continue;
+#define RH_PM_FUSED(S) do { if (nt) ntt_polymul_fused_asm<S, true><<<grid, 256, 0, st>>>(a + o1, b + o1, n1, a + o2, b + o2, out + o2, n2, p2, out + o3, n3, r->d_tw_fwd, r->d_twk_fwd, \
+                                                                                          r->d_twk_inv, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows, r->logN);                          \
+                            else ntt_polymul_fused_asm<S, false><<<grid, 256, 0, st>>>(a + o1, b + o1, n1, a + o2, b + o2, out + o2, n2, p2, out + o3, n3, r->d_tw_fwd, r->d_twk_fwd,      \
+                                                                                       r->d_twk_inv, r->d_tw_inv, r->d_lastw_r, r->d_consts_r, Lrows, r->logN); } while (0)
+      switch (S1) { case 1: RH_PM_FUSED(1); break; case 2: RH_PM_FUSED(2); break; case 3: RH_PM_FUSED(3); break; case 4: RH_PM_FUSED(4); break; default: RH_PM_FUSED(5); break; }
+#undef RH_PM_FUSED
+    }
+    return check_launch("polymul (pipelined)");
+  }
   if (int rc = std_ntt_launch_span(r, a, a, npoly, Lrows, 0, false, false, 1)) return rc;       // column stages only (phase 1), in place
   if (int rc = std_ntt_launch_span(r, b, b, npoly, Lrows, 0, false, false, 1)) return rc;
   (void)hipGetLastError();
-  hipStream_t st = rh_stream(r);
   if (rh_streams_beyond_cache(r, rows)) ntt_polymul_tile_asm<true><<<rows << S1, 256, 0, st>>>(a, b, out, r->d_twk_fwd, r->d_twk_inv, r->d_consts_r, Lrows, r->logN, npoly);
   else ntt_polymul_tile_asm<false><<<rows << S1, 256, 0, st>>>(a, b, out, r->d_twk_fwd, r->d_twk_inv, r->d_consts_r, Lrows, r->logN, npoly);
   const bool nt = rh_streams_beyond_cache(r, rows);

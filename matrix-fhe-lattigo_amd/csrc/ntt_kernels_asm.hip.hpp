@@ -281,11 +281,8 @@ ntt_inv_tile_mul_asm(const u64* in, const u64* in2, u64* out, const tw2* __restr
 // body's first round starts, so two LDS transposes drop out too.  156 VGPRs: 3 workgroups per CU.  out may alias a or b (a tile is read whole
 // before it is written).  consts: qinv for the product; the factor 2^64 is restored by the inverse column stages' constants (d_consts_r).
 template <bool NT = false>
-__global__ void __launch_bounds__(256)
-ntt_polymul_tile_asm(const u64* a, const u64* b2, u64* out, const tw2* __restrict__ twk_fwd, const tw2* __restrict__ twk_inv,
-                     const LimbConsts* __restrict__ consts, int L, int logN, int npoly) {
-  __shared__ u64 lds[LDS_WORDS];
-  const u32 b = blockIdx.x;
+RH_DEV void polymul_tile_asm_body(u64* lds, const u32 b, const u64* a, const u64* b2, u64* out, const tw2* __restrict__ twk_fwd,
+                                  const tw2* __restrict__ twk_inv, const LimbConsts* __restrict__ consts, int L, int logN, int npoly) {
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
   const u32 poly = r % (u32)npoly;
@@ -307,6 +304,34 @@ ntt_polymul_tile_asm(const u64* a, const u64* b2, u64* out, const tw2* __restric
   if constexpr (NT) RH_TILE_POLYMUL_ASM(NTT_TILE_POLYMUL_ASM_BODY_NT);
   else RH_TILE_POLYMUL_ASM(NTT_TILE_POLYMUL_ASM_BODY);
 #undef RH_TILE_POLYMUL_ASM
+}
+template <bool NT = false>
+__global__ void __launch_bounds__(256)
+ntt_polymul_tile_asm(const u64* a, const u64* b2, u64* out, const tw2* __restrict__ twk_fwd, const tw2* __restrict__ twk_inv,
+                     const LimbConsts* __restrict__ consts, int L, int logN, int npoly) {
+  __shared__ u64 lds[LDS_WORDS];
+  polymul_tile_asm_body<NT>(lds, blockIdx.x, a, b2, out, twk_fwd, twk_inv, consts, L, logN, npoly);
+}
+// The software pipeline of a large poly-mul batch (rh_ring_polymul, spans of ~2048 rows): launch j runs the forward column stages of span j
+// (both operands, in place: the memory-bound work), the one-kernel tile middle of span j-1 (the VALU-bound work) and the inverse column stages of
+// span j-2, so the column passes run under the tile passes like in ntt_fwd_fused_asm.  n1: column blocks per operand of span j, n2: tiles of span
+// j-1, n3: column blocks of span j-2 (0: that part is absent in this launch).
+template <int S1, bool NT>
+__global__ void __launch_bounds__(256)
+ntt_polymul_fused_asm(u64* a1, u64* b1, unsigned n1, const u64* a2, const u64* b2, u64* out2, unsigned n2, int npoly2, u64* out3, unsigned n3,
+                      const tw2* __restrict__ twn_f, const tw2* __restrict__ twk_f, const tw2* __restrict__ twk_i, const tw2* __restrict__ twn_i,
+                      const tw2* __restrict__ lastw_r, const LimbConsts* __restrict__ consts_r, int L, int logN) {
+  __shared__ u64 lds[LDS_WORDS];
+  const u32 b = blockIdx.x;
+  if (b < n1) {
+    fwd_cols_best<S1, true, NT>(b, a1, a1, twn_f, consts_r, L, logN);               // (the column stages read q only: either constant block does)
+    fwd_cols_best<S1, true, NT>(b, b1, b1, twn_f, consts_r, L, logN);
+  }
+  if (b < n2) polymul_tile_asm_body<NT>(lds, b, a2, b2, out2, twk_f, twk_i, consts_r, L, logN, npoly2);
+  if (b < n3) {
+    if constexpr (has_asm_cols(S1)) inv_cols_asm_body<S1, NT>(b, out3, twn_i, lastw_r, consts_r, L);
+    else inv_cols_body<S1>(b, out3, twn_i, lastw_r, consts_r, L, logN, 1);
+  }
 }
 
 // software-pipelined inverse: tile stages of span j (in -> out), then column stages + N^-1 of span j-1 (in place)

@@ -422,11 +422,12 @@ def test_matrix_ckks_mul_against_reference_python_ring_product(rh, vec):
     ring.close()
 
 
-@pytest.mark.parametrize("logN,L,B", [(13, 2, 3), (14, 5, 2), (15, 16, 3), (16, 3, 5), (17, 2, 1), (15, 16, 130)])
+@pytest.mark.parametrize("logN,L,B", [(13, 2, 3), (14, 5, 2), (15, 16, 3), (16, 3, 5), (17, 2, 1), (15, 16, 130), (14, 8, 600), (13, 2, 3000), (17, 2, 1100), (16, 16, 300)])
 def test_polymul_one_tile_kernel_equals_the_five_ring_calls(rh, oracle, logN, L, B):
     # Ring.PolyMul (rh_ring_polymul): forward tile stages of both operands + product + inverse tile stages as ONE kernel per 4096-tile (config 3
-    # without NTT(a), NTT(b) or the product in memory) -- the canonical values of NTT, NTT, MForm, MulCoeffsMontgomery, INTT, bit for bit; the
-    # last case (1 GiB per operand) takes the non-temporal bodies
+    # without NTT(a), NTT(b) or the product in memory) -- the canonical values of NTT, NTT, MForm, MulCoeffsMontgomery, INTT, bit for bit.  Batches
+    # of more than ~2048 rows run the software pipeline (column stages of span j + tile middle of span j-1 + inverse column stages of span j-2 in one
+    # launch): two spans with a short tail, three spans, and the compiled column stages of N = 2^13 / 2^17 inside the fused launch
     N, mods = 1 << logN, QI60[:L]
     ring = rh.Ring(N, mods)
     import torch

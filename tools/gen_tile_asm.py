@@ -342,15 +342,15 @@ def gen_polymul():
     ever reaching memory.  The forward body ends with thread tid holding coefficients 16 tid + k, which is where the inverse body's
     first round starts: the forward transpose + store and the inverse load + transpose drop out with the memory passes.
     Operands: the forward body's, plus pin2, twi / twilo / twihi (kernel-order inverse table) and qi0 / qi1 / q0 / q1 / q (MRedLazy)."""
-    gen(stop_after_reduce=True)
+    gen(stop_after_reduce=True, reduce_below_2q=True)
     for k in range(16):
         emit("v_mov_b32 v%d, v%d" % (SAVE0 + 2 * k, X(k)))
         emit("v_mov_b32 v%d, v%d" % (SAVE0 + 2 * k + 1, X(k) + 1))
     mark = len(out)
-    gen(stop_after_reduce=True, barrier_before_lds=True)
+    gen(stop_after_reduce=True, barrier_before_lds=True, reduce_below_2q=True)
     for i in range(mark, len(out)):
         out[i] = out[i].replace("%[pin]", "%[pin2]")
-    emit("; ---- x[k] = MRedLazy(NTT(b)[k], NTT(a)[k]) < 2q")
+    emit("; ---- x[k] = MRedLazy(NTT(b)[k], NTT(a)[k]) < 2q  (both operands < 2q, congruent to the canonical values)")
     for k in range(0, 16, 2):
         for ins in interleave(mred_lazy_steps(X(k), SAVE0 + 2 * k, T0), mred_lazy_steps(X(k + 1), SAVE0 + 2 * (k + 1), T1)):
             emit(ins)
@@ -395,7 +395,7 @@ def csub_all(const_name):
             emit("v_bfi_b32 v%d, v%d, v%d, v%d" % (X(kk) + 1, t.M, X(kk) + 1, t.T + 1))
 
 
-def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True, epilogue=None, lazy_out=False, stop_after_reduce=False, barrier_before_lds=False):
+def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True, epilogue=None, lazy_out=False, stop_after_reduce=False, barrier_before_lds=False, reduce_below_2q=False):
     A0, A1, A2, A3 = ADDR, ADDR + 1, ADDR + 2, ADDR + 3
     emit("; ---- prologue: zero halves of the zero-extended pairs, addresses")
     if PRIO in (1, 2):
@@ -485,7 +485,8 @@ def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True, epilogue
     if not lazy_out:                                          # lazy_out: values leave < 8q (consumers that reduce anyway: the key
         csub_all("nq4")                                       # multiply-accumulate of the gadget product takes any 64-bit operand)
         csub_all("nq2")
-        csub_all("nq")
+        if not reduce_below_2q:                               # gen_polymul: MRedLazy takes operands < 2q (4 q^2 < q 2^64), the last step is not needed
+            csub_all("nq")
     if stop_after_reduce:                                     # gen_polymul: thread tid now holds the canonical NTT values of coefficients
         return                                                # 16 tid + k in x[k] -- the layout the inverse tile's first round starts from
     for k in range(16):
