@@ -390,6 +390,12 @@ func (d *DeviceRing) INTTMul(a, b, out *DevPoly) {
 	d.must(C.rh_ring_intt_mul(d.h, a.ptr, b.ptr, out.ptr, C.int(a.npoly), C.int(a.limbs-1)))
 }
 
+// PolyMul: c = INTT(NTT(a) . NTT(b)) for coefficient-domain a, b -- the values of NTT, NTT, MForm, MulCoeffsMontgomery, INTT (schemes/ckks/evaluator.go:821-834
+// around a fresh product; BASELINE config 3) with the tile stages of all three transforms as one kernel.  a and b are CONSUMED.
+func (d *DeviceRing) PolyMul(a, b, c *DevPoly) {
+	d.must(C.rh_ring_polymul(d.h, a.ptr, b.ptr, c.ptr, C.int(a.npoly), C.int(a.limbs-1)))
+}
+
 // KeySwitcher pairs the Q and P device rings (ring.BasisExtender + the gadget product of rlwe.Evaluator).
 type KeySwitcher struct {
 	be   *C.rh_bext

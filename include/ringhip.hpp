@@ -139,6 +139,9 @@ class Ring {
   }
   void NTT3NReorder(const Poly& p1, Poly& p2, bool toReference) const { check(rh_ring_ntt3n_reorder(h_.get(), p1.data(), p2.data(), p1.npoly(), level_, toReference ? 1 : 0)); }
   long Stats(const char* key) const { long v = 0; check(rh_ring_stats(h_.get(), key, &v)); return v; }
+  // c = INTT(NTT(a) . NTT(b)) from coefficient-domain operands (BASELINE config 3) with the tile stages of all three transforms as one kernel;
+  // a and b are consumed (rh_ring_polymul)
+  void PolyMul(Poly& a, Poly& b, Poly& c) const { check(rh_ring_polymul(h_.get(), a.data(), b.data(), c.data(), a.npoly(), level_)); }
   // Ring.NTT on several blocks in one call (rh_ring_ntt_many): every poly of a block at this view's level (limbs() == level + 1)
   void NTTMany(const std::vector<std::pair<const Poly*, Poly*>>& blocks) const {
     std::vector<const uint64_t*> in; std::vector<uint64_t*> out; std::vector<int> cnt;

@@ -132,6 +132,13 @@ int main() {
   std::vector<uint64_t> c = pa.download();
   for (int l = 0; l < 2; ++l)
     for (int j = 0; j < N; ++j) EXPECT(c[l * N + j] == (j == 1 ? mods[l] - 15 : 0));
+  // the same product through Ring.PolyMul (the tile stages of all three transforms as one kernel; operands consumed)
+  {
+    Poly qa = R.NewPoly(), qb = R.NewPoly(), qc = R.NewPoly();
+    qa.upload(a); qb.upload(b);
+    R.PolyMul(qa, qb, qc);
+    EXPECT(qc.download() == c);
+  }
 
   // Ring.AtLevel(l) on polys allocated at the top level (ring/ring.go:192-213): limbs 0..l transformed, the rest untouched
   {
