@@ -550,7 +550,7 @@ func FreePinnedPoly(base *C.uint64_t) { C.rh_host_free(base) }
 // Layout tag of a 3N ring's NTT-domain device block (DevPoly.BlockOrder): set by NTTTagged, read by INTTTagged and
 // DivRoundByLastModulusManyNTTTagged; coefficient-wise calls keep it (both operands must carry the same tag, else convert one with
 // ToReferenceOrder first).  Block order saves the permutation pass of every transform (2 HBM passes instead of 3); a block that crosses
-// the host boundary is converted back (Download of a tagged block calls ToReferenceOrder on a copy).
+// the host boundary must be converted back first (ToReferenceOrder before Download; the Python mirror does it inside DevicePoly.numpy()).
 func (d *DeviceRing) BlockOrderSupported() bool { return C.rh_ring_ntt3n_block_order_supported(d.h) != 0 }
 func (d *DeviceRing) NTTTagged(p1, p2 *DevPoly, blockOrder bool) {
 	b := C.int(0)

@@ -5,7 +5,6 @@ set -e
 tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
-echo "[1/9] bench"; python3 bench.py > $O/bench.log 2>$O/bench.err; tail -1 $O/bench.log > $O/${tag}_bench.json
 echo "[2/9] kernel trace"; rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 bench.py --no-cpu --no-verify --no-power > $O/kt.log 2>&1
 cp $O/kt/kt_kernel_stats.csv $O/${tag}_kernel_stats.csv
 echo "[3/9] pmc fetch"; rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pf -o f --output-format csv -- python3 bench.py --no-cpu --no-verify --no-power --steps 3 --warmup 1 > $O/pf.log 2>&1
@@ -15,6 +14,9 @@ for x in f w; do d=$([ $x = f ] && echo pf || echo pw); n=$([ $x = f ] && echo f
 echo "[5/9] pmc sq"; rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -d $O/ps -o s --output-format csv -- python3 bench.py --no-cpu --no-verify --no-power --steps 3 --warmup 1 > $O/ps.log 2>&1
 python3 tools/make_valu.py $O/ps/s_counter_collection.csv $O/latest_valu.json 1024 9 > /dev/null
 python3 tools/pmc_table.py $O/ps > $O/${tag}_pmc_sq_counters.txt
+# the bench line LAST of the headline group: it reads profiles/latest_*.json, which must be the counters of THIS tree (csrc_tree stamp)
+cp $O/latest_traffic.json $O/latest_valu.json profiles/
+echo "[1/9] bench"; python3 bench.py > $O/bench.log 2>$O/bench.err; tail -1 $O/bench.log > $O/${tag}_bench.json
 echo "[6/9] 3N kernels (config 4 ring, reference order and block order)"
 for bo in 0 1; do
   rocprofv3 --kernel-trace --stats -d $O/k3_$bo -o k --output-format csv -- python3 tools/bench_3n.py 16 24 16 $bo > $O/k3_$bo.log 2>&1
