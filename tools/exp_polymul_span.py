@@ -1,0 +1,25 @@
+import sys
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import torch
+import matrix_fhe_lattigo_amd as rh
+from conftest import QI60
+dev = torch.device("cuda", 0); stream = torch.cuda.current_stream()
+def timed(fn, reps=10, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps): fn()
+    e1.record(stream); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+N, L, B = 1 << 15, 16, 512
+ring = rh.Ring(N, QI60[:L]); ring.set_stream(stream.cuda_stream)
+qs = torch.tensor(QI60[:L], dtype=torch.int64, device=dev).view(1, L, 1)
+a = torch.randint(0, 1 << 62, (B, L, N), dtype=torch.int64, device=dev) % qs
+b = torch.randint(0, 1 << 62, (B, L, N), dtype=torch.int64, device=dev) % qs
+pa, pb = rh.DevicePoly.from_torch(ring, a), rh.DevicePoly.from_torch(ring, b)
+for span in (512, 1024, 2048, 3072, 4096, 8192):
+    ring.set_tuning("auto_span_rows", span)
+    print("span rows", span, "PolyMul %.3f ms" % timed(lambda: ring.PolyMul(pa, pb, pa)), flush=True)
+ring.set_tuning("auto_span_rows", 2048); ring.set_tuning("chunk_polys", 0)
+print("unpipelined %.3f ms" % timed(lambda: ring.PolyMul(pa, pb, pa)))
