@@ -140,3 +140,40 @@ def test_multi_rank_limb_shard_gloo(world, N, nq, np_):
     assert covered and ok0 and ok1
     if world == 4:
         assert 0 in pcounts                                             # a rank that owns no P limb took part
+
+
+def test_orchestrated_entry_error_behaviour(rh):
+    # rh_kshard_gadget_product: a handle that owns a subset of the limbs needs the owner map; more than one rank needs the caller's all-gather;
+    # a failing all-gather surfaces as a status with its code in the message (never an abort across the ABI); a wrong owner map is refused
+    import ctypes as C
+    import torch
+    from matrix_fhe_lattigo_amd import sharding
+    N, nq, np_ = 4096, 5, 2
+    Q, P = QI60[:nq], PI60[:np_]
+    L = rh.lib()
+    ks = sharding.LimbShardedKeySwitch(N, Q, P, 0, 2, dist=None)               # rank 0 of 2: limbs 0, 2, 4 of Q and P1
+    dev = torch.device("cuda", 0)
+    nQ, nP = len(ks.ownQ), len(ks.ownP)
+    cx = torch.zeros((2, nQ, N), dtype=torch.int64, device=dev)
+    kq = torch.zeros((ks.beta, 2, nQ, N), dtype=torch.int64, device=dev)
+    kp = torch.zeros((ks.beta, 2, nP, N), dtype=torch.int64, device=dev)
+    c0, c1 = torch.empty_like(cx), torch.empty_like(cx)
+    args = (ks._h, cx.data_ptr(), kq.data_ptr(), kp.data_ptr(), c0.data_ptr(), c1.data_ptr(), 2)
+    assert L.rh_kshard_gadget_product(*args, rh.ringhip.ALLGATHER_FN(), None, 1) == -1 and b"all-gather" in L.rh_last_error()
+    failing = rh.ringhip.ALLGATHER_FN(lambda ctx, s, r, w, st: 7)
+    assert L.rh_kshard_gadget_product(*args, failing, None, 1) == -3 and b"returned 7" in L.rh_last_error()
+    torch.cuda.synchronize()
+    bad = (C.c_int * (nq + np_))(*([1] * (nq + np_)))                           # every limb owned by rank 1: not what rank 0 was created with
+    assert L.rh_kshard_set_world(ks._h, 2, 0, bad) == -1 and b"owner map" in L.rh_last_error()
+    w = C.c_size_t()
+    assert L.rh_kshard_exchange_words(ks._h, 64, 4, C.byref(w)) == 0 and w.value > 0
+    ks.close()
+    # a fresh partial handle without set_world
+    rq = rh.Ring(N, [Q[0], Q[2]])
+    h = C.c_void_p()
+    allQ, allP = rh.ringhip._u64(Q), rh.ringhip._u64(P)
+    oq = (C.c_int * 2)(0, 2)
+    rh.ringhip._check(L.rh_kshard_create(C.byref(h), rq._h, None, rh.ringhip._p(allQ), nq - 1, rh.ringhip._p(allP), np_ - 1, oq, 2, oq, 0))
+    assert L.rh_kshard_gadget_product(h, cx.data_ptr(), kq.data_ptr(), None, c0.data_ptr(), c1.data_ptr(), 1, rh.ringhip.ALLGATHER_FN(), None, 1) == -1
+    assert b"rh_kshard_set_world" in L.rh_last_error()
+    L.rh_kshard_destroy(h); rq.close()
