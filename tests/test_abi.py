@@ -68,3 +68,17 @@ def test_compiled_host_runs_the_sharded_key_switch_through_the_c_abi():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "all checks passed" in out.stdout and out.stdout.count(" ok") == 4
+
+
+def test_generated_asm_bodies_are_what_the_generator_writes(tmp_path):
+    # csrc/ntt_tile_asm.inc, ntt3n_asm.inc and ntt_ci_asm.inc are GENERATED (tools/gen_tile_asm.py) and committed so that the library builds
+    # without running Python: the committed text must be exactly what the committed generator produces
+    import subprocess
+    import sys
+    out = tmp_path / "ntt_tile_asm.inc"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_tile_asm.py"), str(out)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    for name in ("ntt_tile_asm.inc", "ntt3n_asm.inc", "ntt_ci_asm.inc"):
+        want = open(os.path.join(ROOT, "matrix-fhe-lattigo_amd", "csrc", name)).read()
+        got = open(os.path.join(str(tmp_path), name)).read()
+        assert got == want, "%s is stale: run `python3 tools/gen_tile_asm.py matrix-fhe-lattigo_amd/csrc/ntt_tile_asm.inc`" % name
