@@ -1,5 +1,7 @@
-import sys
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+"""Config 3 experiment (round 3): Ring.PolyMul (the tile stages of all three transforms as one kernel) against Ring.NTTMany + Ring.INTTMul; see DESIGN.md 6."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 import matrix_fhe_lattigo_amd as rh
 from conftest import QI60
