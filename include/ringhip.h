@@ -139,9 +139,8 @@ int rh_ring_ntt_many(rh_ring* r, const uint64_t* const* in_dev, uint64_t* const*
  * >= level+1): ring.AtLevel(level) on max-level polys and buffers (ring/ring.go:192-213), the idiomatic use inside the reference's
  * evaluators.  Limbs 0..level of every poly are transformed, the others are untouched.  With rows == level+1 this IS rh_ring_ntt /
  * rh_ring_intt. */
-/* (round 3: every shape is ONE batched transform.  Standard rings with one row stride on both sides (forward, N >= 4096) and the inverse at
- * N = 2^14 .. 2^16 stride inside the kernels; the other shapes -- different strides, small N, conjugate-invariant and 3N rings -- compact the
- * leading limbs with one strided device copy on the way in and / or out.  rh_ring_stats(ring, "rows_direct" | "rows_compacted" |
+/* (round 3: every shape is ONE batched transform.  Standard rings take both row strides inside the kernels (every N, forward and inverse);
+ * conjugate-invariant and 3N rings compact the leading limbs with one strided device copy on the way in and / or out.  rh_ring_stats(ring, "rows_direct" | "rows_compacted" |
  * "rows_poly_by_poly", &n) counts how the calls of a handle were served.) */
 int rh_ring_stats(const rh_ring* r, const char* key, long* value);
 int rh_ring_ntt_rows(rh_ring* r, const uint64_t* in_dev, int in_rows, uint64_t* out_dev, int out_rows, int npoly, int level, int lazy);

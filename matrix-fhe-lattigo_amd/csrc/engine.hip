@@ -319,31 +319,33 @@ static int check_launch(const char* what) {
 
 template <class P>
 static void launch_fwd_cols(int S1, dim3 grid, hipStream_t st, const u64* in, u64* out, const typename P::tw_t* tw,
-                            const LimbConsts* c, int L, int logN, int Ls = 0) {
+                            const LimbConsts* c, int L, int logN, int Ls = 0, int Lso = 0) {
   switch (S1) {
-    case 1: ntt_fwd_cols<P, 1><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN, Ls); break;
-    case 2: ntt_fwd_cols<P, 2><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN, Ls); break;
-    case 3: ntt_fwd_cols<P, 3><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN, Ls); break;
-    case 4: ntt_fwd_cols<P, 4><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN, Ls); break;
-    case 5: ntt_fwd_cols<P, 5><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN, Ls); break;
+    case 1: ntt_fwd_cols<P, 1><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN, Ls, Lso); break;
+    case 2: ntt_fwd_cols<P, 2><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN, Ls, Lso); break;
+    case 3: ntt_fwd_cols<P, 3><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN, Ls, Lso); break;
+    case 4: ntt_fwd_cols<P, 4><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN, Ls, Lso); break;
+    case 5: ntt_fwd_cols<P, 5><<<grid, 256, 0, st>>>(in, out, tw, c, L, logN, Ls, Lso); break;
   }
 }
 static void launch_inv_cols(int S1, dim3 grid, hipStream_t st, u64* data, const tw2* tw, const tw2* lastw,
-                            const LimbConsts* c, int L, int logN, int scale) {
+                            const LimbConsts* c, int L, int logN, int scale, int Ls = 0) {
   switch (S1) {
-    case 1: ntt_inv_cols<1><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN, scale); break;
-    case 2: ntt_inv_cols<2><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN, scale); break;
-    case 3: ntt_inv_cols<3><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN, scale); break;
-    case 4: ntt_inv_cols<4><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN, scale); break;
-    case 5: ntt_inv_cols<5><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN, scale); break;
+    case 1: ntt_inv_cols<1><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN, scale, Ls); break;
+    case 2: ntt_inv_cols<2><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN, scale, Ls); break;
+    case 3: ntt_inv_cols<3><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN, scale, Ls); break;
+    case 4: ntt_inv_cols<4><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN, scale, Ls); break;
+    case 5: ntt_inv_cols<5><<<grid, 256, 0, st>>>(data, tw, lastw, c, L, logN, scale, Ls); break;
   }
 }
 
 // limb0: first limb of the table set to use (host-pointer single-limb path); rows = npoly * Lrows.
 // phase: 0 = whole transform, 1 = column kernel only, 2 = tile kernel only (profiling aid, rh_ring_ntt_phase).
 static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase,
-                               int Ls = 0) {          // Ls: rows per poly of the block when > Lrows (forward, N >= 4096 only)
+                               int Ls = 0, int Lso = 0) {   // Ls / Lso: rows per poly of the input / output block when > Lrows (0: Lrows / Ls): AtLevel views
   (void)hipGetLastError();                       // drop any stale error of an unrelated earlier call
+  if (Ls && !Lso) Lso = Ls;                      // one stride given: both sides
+  if (Lso && !Ls) Ls = Lrows;
   const int logN = r->logN, N = r->N;
   const size_t toff = (size_t)limb0 * N;
   const LimbConsts* c = r->d_consts + limb0;
@@ -352,12 +354,13 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
   if (rows == 0) return RH_OK;
   if (logN < LT) {
     if (!inverse) {
-      if (lazy) ntt_fwd_small<MontPolicy><<<rows, 256, 0, st>>>(in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN, 0);
-      else      ntt_fwd_small<ShoupPolicy><<<rows, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, logN, 1);
+      if (lazy) ntt_fwd_small<MontPolicy><<<rows, 256, 0, st>>>(in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN, 0, Ls, Lso);
+      else      ntt_fwd_small<ShoupPolicy><<<rows, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, logN, 1, Ls, Lso);
     } else if (lazy && logN < 4 && r->d_tw_inv_mont && r->kind == RH_RING_STANDARD) {
+      if (Ls || Lso) return rh_fail(RH_ERR_UNSUPPORTED, "strided non-canonical BackwardLazy of N = 8");          // (ntt_rows compacts this one shape)
       ntt_inv_small_lazy_mont<<<rows, 64, 0, st>>>(in, out, r->d_tw_inv_mont + toff, c, Lrows, logN);   // N = 8: BackwardLazy is not canonical
     } else {
-      ntt_inv_small<<<rows, 256, 0, st>>>(in, out, r->d_tw_inv + toff, c, Lrows, logN, r->inv_scale ? 1 : 0);
+      ntt_inv_small<<<rows, 256, 0, st>>>(in, out, r->d_tw_inv + toff, c, Lrows, logN, r->inv_scale ? 1 : 0, Ls, Lso);
     }
     return check_launch("ntt_small");
   }
@@ -369,40 +372,42 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
     if (S1 > 0) {
       dim3 g1(rows * 16);
       if (phase != 2) {
-        if (lazy) launch_fwd_cols<MontPolicy>(S1, g1, st, in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN, Ls);
-        else if (S1 == 4 && r->asm_cols && r->asm_tile && nt) ntt_fwd_cols_asm<4, true><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
-        else if (S1 == 3 && r->asm_cols && r->asm_tile && nt) ntt_fwd_cols_asm<3, true><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
-        else if (S1 == 2 && r->asm_cols && r->asm_tile && nt) ntt_fwd_cols_asm<2, true><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
-        else if (S1 == 4 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<4><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
-        else if (S1 == 3 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<3><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
-        else if (S1 == 2 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<2><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls);
-      else      launch_fwd_cols<ShoupPolicy>(S1, g1, st, in, out, r->d_tw_fwd + toff, c, Lrows, logN, Ls);
+        if (lazy) launch_fwd_cols<MontPolicy>(S1, g1, st, in, out, r->d_tw_fwd_mont + toff, c, Lrows, logN, Ls, Lso);
+        else if (S1 == 4 && r->asm_cols && r->asm_tile && nt) ntt_fwd_cols_asm<4, true><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls, Lso);
+        else if (S1 == 3 && r->asm_cols && r->asm_tile && nt) ntt_fwd_cols_asm<3, true><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls, Lso);
+        else if (S1 == 2 && r->asm_cols && r->asm_tile && nt) ntt_fwd_cols_asm<2, true><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls, Lso);
+        else if (S1 == 4 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<4><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls, Lso);
+        else if (S1 == 3 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<3><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls, Lso);
+        else if (S1 == 2 && r->asm_cols && r->asm_tile) ntt_fwd_cols_asm<2><<<g1, 256, 0, st>>>(in, out, r->d_tw_fwd + toff, c, Lrows, Ls, Lso);
+      else      launch_fwd_cols<ShoupPolicy>(S1, g1, st, in, out, r->d_tw_fwd + toff, c, Lrows, logN, Ls, Lso);
       }
       if (phase != 2) src = out;                   // phase 2 (tile stages only): the caller's `in` holds the column stages' output
     }
     if (phase != 1) {
-      const int ls = Ls ? Ls : Lrows;
-      if (lazy) ntt_fwd_tile<MontPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd_mont + toff, c, Lrows, logN, 0, npoly, ls);
-      else if (r->asm_tile && nt) ntt_fwd_tile_asm<true><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, npoly, ls);
-      else if (r->asm_tile) ntt_fwd_tile_asm<false><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, npoly, ls);
-      else      ntt_fwd_tile<ShoupPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, 1, npoly, ls);
+      // the tile stages read what the column stages wrote (the OUTPUT block, its stride on both sides); without column stages (N = 4096) they go in -> out
+      const int lso = Lso ? Lso : (Ls ? Ls : Lrows);
+      const int ls = (src == out) ? lso : (Ls ? Ls : Lrows);
+      if (lazy) ntt_fwd_tile<MontPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd_mont + toff, c, Lrows, logN, 0, npoly, ls, lso);
+      else if (r->asm_tile && nt) ntt_fwd_tile_asm<true><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, npoly, ls, lso);
+      else if (r->asm_tile) ntt_fwd_tile_asm<false><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, npoly, ls, lso);
+      else      ntt_fwd_tile<ShoupPolicy><<<tiles, 256, 0, st>>>(src, out, r->d_twk_fwd + toff, c, Lrows, logN, 1, npoly, ls, lso);
     }
   } else {
     if (phase != 1) {
       // the hand-scheduled body leaves values < 4q unscaled: right whenever column stages follow, and for N = 4096
       // sub-rings of the 3N transform (inv_scale = false), which scale in their own last layer
-      if (r->asm_tile && (S1 > 0 || !r->inv_scale) && nt) ntt_inv_tile_asm<true><<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly, 0, 0);
-      else if (r->asm_tile && (S1 > 0 || !r->inv_scale)) ntt_inv_tile_asm<false><<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly, 0, 0);
-      else ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, (S1 == 0 && r->inv_scale) ? 1 : 0, npoly);
+      if (r->asm_tile && (S1 > 0 || !r->inv_scale) && nt) ntt_inv_tile_asm<true><<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly, Ls, Lso);
+      else if (r->asm_tile && (S1 > 0 || !r->inv_scale)) ntt_inv_tile_asm<false><<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly, Ls, Lso);
+      else ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, (S1 == 0 && r->inv_scale) ? 1 : 0, npoly, Ls, Lso);
     }
     const bool acols = phase != 2 && r->asm_cols && r->asm_tile && r->inv_scale;
-    if (S1 == 4 && acols && nt) ntt_inv_cols_asm<4, true><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, 0);
-    else if (S1 == 3 && acols && nt) ntt_inv_cols_asm<3, true><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, 0);
-    else if (S1 == 2 && acols && nt) ntt_inv_cols_asm<2, true><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, 0);
-    else if (S1 == 4 && acols) ntt_inv_cols_asm<4><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, 0);
-    else if (S1 == 3 && acols) ntt_inv_cols_asm<3><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, 0);
-    else if (S1 == 2 && acols) ntt_inv_cols_asm<2><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, 0);
-    else if (S1 > 0 && phase != 2) launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, logN, r->inv_scale ? 1 : 0);
+    if (S1 == 4 && acols && nt) ntt_inv_cols_asm<4, true><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Lso);
+    else if (S1 == 3 && acols && nt) ntt_inv_cols_asm<3, true><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Lso);
+    else if (S1 == 2 && acols && nt) ntt_inv_cols_asm<2, true><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Lso);
+    else if (S1 == 4 && acols) ntt_inv_cols_asm<4><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Lso);
+    else if (S1 == 3 && acols) ntt_inv_cols_asm<3><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Lso);
+    else if (S1 == 2 && acols) ntt_inv_cols_asm<2><<<dim3(rows * 16), 256, 0, st>>>(out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Lso);
+    else if (S1 > 0 && phase != 2) launch_inv_cols(S1, dim3(rows * 16), st, out, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, logN, r->inv_scale ? 1 : 0, Lso);
   }
   return check_launch("ntt");
 }
@@ -814,17 +819,14 @@ static int ntt_rows(rh_ring* r, const uint64_t* in, int in_rows, uint64_t* out, 
   if (!in || !out) return rh_fail(RH_ERR_ARG, "ntt: null argument");
   if (npoly < 0) return rh_fail(RH_ERR_ARG, "ntt: npoly < 0");
   (void)hipSetDevice(r->device);
-  // direct: forward with one row stride on both sides (the kernels' Ls), inverse through the hand-scheduled bodies
-  if (r->kind == RH_RING_STANDARD && !inverse && in_rows == out_rows && r->logN >= LT) {
+  // standard rings: the row strides of the two blocks go into the kernels (every N, forward and inverse, exact-lazy forward included); the one
+  // exception is the non-canonical BackwardLazy of N = 8, which compacts like the other ring types
+  if (r->kind == RH_RING_STANDARD && !(inverse && lazy && r->logN < 4)) {
     ++r->stats_rows_direct;
-    return std_ntt_launch_span(r, in, out, npoly, level + 1, 0, false, lazy, 0, in_rows);
+    return std_ntt_launch_span(r, in, out, npoly, level + 1, 0, inverse, lazy, 0, in_rows, out_rows);
   }
-  if (r->kind == RH_RING_STANDARD && inverse && rh_can_intt_limb_strided(r)) {  // BackwardLazy is canonical for N >= 16 (ring/ntt.go:197-206)
-    ++r->stats_rows_direct;
-    return rh_std_intt_rows(r, in, in_rows, out, out_rows, npoly, level + 1);
-  }
-  // every other shape (different strides forward, small N, conjugate-invariant and 3N rings): still ONE batched transform -- the leading
-  // limbs are compacted with a strided copy on the way in and / or expanded on the way out (round 3; these shapes ran poly by poly before)
+  // conjugate-invariant and 3N rings: still ONE batched transform -- the leading limbs are compacted with a strided copy on the way in and / or
+  // expanded on the way out (round 3; these shapes ran poly by poly before)
   if (npoly == 0) return RH_OK;
   ++r->stats_rows_compacted;
   const size_t N = (size_t)r->N, Lr = (size_t)(level + 1);

@@ -118,7 +118,8 @@ RH_DEV void round16_inv(const P& p, u64 (&x)[16], TWF TW) {
 // ---------------------------------------------------------------------------------------------------------------
 template <class P>
 RH_DEV void fwd_tile_body(u64* lds, const u32 b, const u64* in, u64* out, const typename P::tw_t* __restrict__ twk,
-                          const LimbConsts* __restrict__ consts, int L, int logN, int canonical, int npoly, int Ls) {
+                          const LimbConsts* __restrict__ consts, int L, int logN, int canonical, int npoly, int Ls, int Lso = 0) {
+  if (Lso == 0) Lso = Ls;                  // rows per poly of the OUTPUT block when it differs from the input's (AtLevel views with two strides)
   const int tid = threadIdx.x;
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
@@ -128,6 +129,7 @@ RH_DEV void fwd_tile_body(u64* lds, const u32 b, const u64* in, u64* out, const 
   const u32 poly = r % (u32)npoly;
   const u32 tile = r / (u32)npoly;
   const size_t base = (((size_t)poly * Ls + limb) << logN) + ((size_t)tile << LT);   // Ls = rows per poly of the block (>= L)
+  const size_t obase = (((size_t)poly * Lso + limb) << logN) + ((size_t)tile << LT);
   const typename P::tw_t* tw = twk + ((size_t)limb << logN) + ((size_t)tile << LT);
   P p; p.init(consts[limb]);
 
@@ -155,14 +157,14 @@ RH_DEV void fwd_tile_body(u64* lds, const u32 b, const u64* in, u64* out, const 
   for (int k = 0; k < 16; ++k) lds[LDS_PAD(tid * 16 + k)] = p.fwd_final(x[k], canonical != 0);
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 16; ++k) out[base + tid + 256 * k] = lds[LDS_PAD(tid + 256 * k)];
+  for (int k = 0; k < 16; ++k) out[obase + tid + 256 * k] = lds[LDS_PAD(tid + 256 * k)];
 }
 template <class P>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // LDS allows 4 workgroups per CU: keep the registers within that
 ntt_fwd_tile(const u64* in, u64* out, const typename P::tw_t* __restrict__ twk,
-             const LimbConsts* __restrict__ consts, int L, int logN, int canonical, int npoly, int Ls) {
+             const LimbConsts* __restrict__ consts, int L, int logN, int canonical, int npoly, int Ls, int Lso) {
   __shared__ u64 lds[LDS_WORDS];
-  fwd_tile_body<P>(lds, blockIdx.x, in, out, twk, consts, L, logN, canonical, npoly, Ls);
+  fwd_tile_body<P>(lds, blockIdx.x, in, out, twk, consts, L, logN, canonical, npoly, Ls, Lso);
 }
 
 // Forward tile stages with a fused epilogue: out = MRed(2q - y + NTT(in), s_limb) -- the subtract-multiply that follows a
@@ -228,7 +230,7 @@ ntt_fwd_tile_submul(const u64* in, const tw2* __restrict__ twk, const LimbConsts
 // 2^64-scaled constant sets: consts here when `last`, else to the column kernel), so the canonical result is the same residue.
 template <bool MUL>
 RH_DEV void inv_tile_body(u64* lds, const u32 b, const u64* in, const u64* in2, u64* out, const tw2* __restrict__ twk,
-                          const LimbConsts* __restrict__ consts, int L, int logN, int last, int npoly) {
+                          const LimbConsts* __restrict__ consts, int L, int logN, int last, int npoly, int in_Ls = 0, int out_Ls = 0) {
   const int tid = threadIdx.x;
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
@@ -236,7 +238,8 @@ RH_DEV void inv_tile_body(u64* lds, const u32 b, const u64* in, const u64* in2, 
   // tile's twiddles (64 KiB per limb) are served by the XCD's L2 instead of being re-fetched per poly
   const u32 poly = r % (u32)npoly;
   const u32 tile = r / (u32)npoly;
-  const size_t base = (((size_t)poly * L + limb) << logN) + ((size_t)tile << LT);
+  const size_t base = (((size_t)poly * (in_Ls ? in_Ls : L) + limb) << logN) + ((size_t)tile << LT);      // in_Ls / out_Ls: rows per poly of the blocks (0: L)
+  const size_t obase = (((size_t)poly * (out_Ls ? out_Ls : L) + limb) << logN) + ((size_t)tile << LT);
   const tw2* tw = twk + ((size_t)limb << logN) + ((size_t)tile << LT);
   const LimbConsts c = consts[limb];
   ShoupPolicy p; p.init(c);
@@ -270,13 +273,13 @@ RH_DEV void inv_tile_body(u64* lds, const u32 b, const u64* in, const u64* in2, 
     for (int k = 0; k < 16; ++k) x[k] = canon4(shoup_mul(x[k], c.ninv_w, c.ninv_wp, c.nq), c.q);
   }
 #pragma unroll
-  for (int k = 0; k < 16; ++k) out[base + tid + 256 * k] = x[k];
+  for (int k = 0; k < 16; ++k) out[obase + tid + 256 * k] = x[k];
 }
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 ntt_inv_tile(const u64* in, u64* out, const tw2* __restrict__ twk,
-             const LimbConsts* __restrict__ consts, int L, int logN, int last, int npoly) {
+             const LimbConsts* __restrict__ consts, int L, int logN, int last, int npoly, int in_Ls = 0, int out_Ls = 0) {
   __shared__ u64 lds[LDS_WORDS];
-  inv_tile_body<false>(lds, blockIdx.x, in, nullptr, out, twk, consts, L, logN, last, npoly);
+  inv_tile_body<false>(lds, blockIdx.x, in, nullptr, out, twk, consts, L, logN, last, npoly, in_Ls, out_Ls);
 }
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 ntt_inv_tile_mul(const u64* in, const u64* in2, u64* out, const tw2* __restrict__ twk,
@@ -291,14 +294,16 @@ ntt_inv_tile_mul(const u64* in, const u64* in2, u64* out, const tw2* __restrict_
 // ---------------------------------------------------------------------------------------------------------------
 template <class P, int S1>
 RH_DEV void fwd_cols_body(const u32 b, const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
-                          const LimbConsts* __restrict__ consts, int L, int logN, int Ls = 0) {
+                          const LimbConsts* __restrict__ consts, int L, int logN, int Ls = 0, int Lso = 0) {
   if (Ls == 0) Ls = L;                     // rows per poly of the block (>= L)
+  if (Lso == 0) Lso = Ls;                  // ... of the output block, when it differs
   constexpr int R = 1 << S1;
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
   const u32 cb = r & 15;            // 16 blocks of 256 columns per limb
   const u32 poly = r >> 4;
   const size_t base = (((size_t)poly * Ls + limb) << logN) + cb * 256 + threadIdx.x;
+  const size_t obase = (((size_t)poly * Lso + limb) << logN) + cb * 256 + threadIdx.x;
   const typename P::tw_t* tw = twn + ((size_t)limb << logN);
   P p; p.init(consts[limb]);
   u64 x[R];
@@ -316,13 +321,13 @@ RH_DEV void fwd_cols_body(const u32 b, const u64* in, u64* out, const typename P
     }
   }
 #pragma unroll
-  for (int k = 0; k < R; ++k) out[base + ((size_t)k << LT)] = x[k];
+  for (int k = 0; k < R; ++k) out[obase + ((size_t)k << LT)] = x[k];
 }
 template <class P, int S1>
 __global__ void __launch_bounds__(256)
 ntt_fwd_cols(const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
-             const LimbConsts* __restrict__ consts, int L, int logN, int Ls) {
-  fwd_cols_body<P, S1>(blockIdx.x, in, out, twn, consts, L, logN, Ls);
+             const LimbConsts* __restrict__ consts, int L, int logN, int Ls, int Lso) {
+  fwd_cols_body<P, S1>(blockIdx.x, in, out, twn, consts, L, logN, Ls, Lso);
 }
 // Column stages fed by the re-expansion of a rescale step (ring/scaling.go:97-118): x = (t [+ h, recentred]) mod q_limb is
 // computed on the fly from the coefficient-domain last limb t (one row per poly, L2-resident across the limbs) instead of
@@ -381,13 +386,13 @@ ntt_fwd_fused(const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n2, i
 // lastw = Shoup pair of psi_bwd[1]*N^-1.
 template <int S1>
 RH_DEV void inv_cols_body(const u32 b, u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
-                          const LimbConsts* __restrict__ consts, int L, int logN, int scale) {
+                          const LimbConsts* __restrict__ consts, int L, int logN, int scale, int Ls = 0) {
   constexpr int R = 1 << S1;
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
   const u32 cb = r & 15;
   const u32 poly = r >> 4;
-  const size_t base = (((size_t)poly * L + limb) << logN) + cb * 256 + threadIdx.x;
+  const size_t base = (((size_t)poly * (Ls ? Ls : L) + limb) << logN) + cb * 256 + threadIdx.x;          // Ls: rows per poly of the block (0: L)
   const tw2* tw = twn + ((size_t)limb << logN);
   const LimbConsts c = consts[limb];
   ShoupPolicy p; p.init(c);
@@ -426,8 +431,8 @@ RH_DEV void inv_cols_body(const u32 b, u64* data, const tw2* __restrict__ twn, c
 template <int S1>
 __global__ void __launch_bounds__(256)
 ntt_inv_cols(u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
-             const LimbConsts* __restrict__ consts, int L, int logN, int scale) {
-  inv_cols_body<S1>(blockIdx.x, data, twn, lastw, consts, L, logN, scale);
+             const LimbConsts* __restrict__ consts, int L, int logN, int scale, int Ls = 0) {
+  inv_cols_body<S1>(blockIdx.x, data, twn, lastw, consts, L, logN, scale, Ls);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -438,11 +443,11 @@ ntt_inv_cols(u64* data, const tw2* __restrict__ twn, const tw2* __restrict__ las
 template <class P>
 __global__ void __launch_bounds__(256)
 ntt_fwd_small(const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
-              const LimbConsts* __restrict__ consts, int L, int logN, int canonical) {
+              const LimbConsts* __restrict__ consts, int L, int logN, int canonical, int Ls = 0, int Lso = 0) {   // Ls / Lso: rows per poly of the input / output block (0: L)
   __shared__ u64 lds[TILE];
   const int N = 1 << logN;
-  const u32 limb = blockIdx.x % (u32)L;
-  const size_t base = (size_t)blockIdx.x << logN;
+  const u32 limb = blockIdx.x % (u32)L, poly = blockIdx.x / (u32)L;
+  const size_t base = ((size_t)poly * (Ls ? Ls : L) + limb) << logN, obase = ((size_t)poly * (Lso ? Lso : (Ls ? Ls : L)) + limb) << logN;
   const typename P::tw_t* tw = twn + ((size_t)limb << logN);
   P p; p.init(consts[limb]);
   for (int j = threadIdx.x; j < N; j += blockDim.x) lds[j] = in[base + j];
@@ -459,16 +464,16 @@ ntt_fwd_small(const u64* in, u64* out, const typename P::tw_t* __restrict__ twn,
     }
     __syncthreads();
   }
-  for (int j = threadIdx.x; j < N; j += blockDim.x) out[base + j] = p.fwd_final(lds[j], canonical != 0);
+  for (int j = threadIdx.x; j < N; j += blockDim.x) out[obase + j] = p.fwd_final(lds[j], canonical != 0);
 }
 
 __global__ void __launch_bounds__(256)
 ntt_inv_small(const u64* in, u64* out, const tw2* __restrict__ twn,
-              const LimbConsts* __restrict__ consts, int L, int logN, int scale) {
+              const LimbConsts* __restrict__ consts, int L, int logN, int scale, int Ls = 0, int Lso = 0) {   // Ls / Lso: rows per poly of the input / output block (0: L)
   __shared__ u64 lds[TILE];
   const int N = 1 << logN;
-  const u32 limb = blockIdx.x % (u32)L;
-  const size_t base = (size_t)blockIdx.x << logN;
+  const u32 limb = blockIdx.x % (u32)L, poly = blockIdx.x / (u32)L;
+  const size_t base = ((size_t)poly * (Ls ? Ls : L) + limb) << logN, obase = ((size_t)poly * (Lso ? Lso : (Ls ? Ls : L)) + limb) << logN;
   const tw2* tw = twn + ((size_t)limb << logN);
   const LimbConsts c = consts[limb];
   ShoupPolicy p; p.init(c);
@@ -486,7 +491,7 @@ ntt_inv_small(const u64* in, u64* out, const tw2* __restrict__ twn,
     __syncthreads();
   }
   for (int j = threadIdx.x; j < N; j += blockDim.x)
-    out[base + j] = scale ? canon4(shoup_mul(lds[j], c.ninv_w, c.ninv_wp, c.nq), c.q) : lds[j];
+    out[obase + j] = scale ? canon4(shoup_mul(lds[j], c.ninv_w, c.ninv_wp, c.nq), c.q) : lds[j];
 }
 
 // N < 16 (the reference accepts N = 8, ring/ring.go:318): BackwardLazy is NOT canonical there -- inttCoreLazy followed by

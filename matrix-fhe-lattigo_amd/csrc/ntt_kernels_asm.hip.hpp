@@ -17,8 +17,9 @@
 // NT: the body with non-temporal data streams (tools/gen_tile_asm.py: for working sets far beyond the Infinity Cache -- the pipelined launches)
 template <bool LAZY = false, bool NT = false>
 RH_DEV void fwd_tile_asm_body(u64* lds, const u32 b, const u64* in, u64* out, const tw2* __restrict__ twk,
-                              const LimbConsts* __restrict__ consts, int L, int logN, int npoly, int Ls = 0, u32 gap0 = 0, u32 gap_len = 0) {
+                              const LimbConsts* __restrict__ consts, int L, int logN, int npoly, int Ls = 0, u32 gap0 = 0, u32 gap_len = 0, int Lso = 0) {
   if (Ls == 0) Ls = L;                     // rows per poly of the block (>= L)
+  if (Lso == 0) Lso = Ls;                  // ... of the output block, when it differs (AtLevel views with two strides)
   const u32 lrow = b % (u32)L;
   const u32 limb = lrow + (lrow >= gap0 ? gap_len : 0u);
   const u32 r = b / (u32)L;
@@ -26,7 +27,7 @@ RH_DEV void fwd_tile_asm_body(u64* lds, const u32 b, const u64* in, u64* out, co
   const u32 tile = r / (u32)npoly;
   const size_t base = (((size_t)poly * Ls + limb) << logN) + ((size_t)tile << LT);
   const u64 pin = uni64((u64)(size_t)(in + base));
-  const u64 pout = uni64((u64)(size_t)(out + base));
+  const u64 pout = uni64((u64)(size_t)(out + (((size_t)poly * Lso + limb) << logN) + ((size_t)tile << LT)));
   const u64 tw = uni64((u64)(size_t)(twk + ((size_t)limb << logN) + ((size_t)tile << LT)));
   const u64 q = uni64(consts[limb].q);
   const u64 nq = (u64)0 - q, nq2 = (u64)0 - 2 * q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
@@ -51,8 +52,9 @@ constexpr bool has_asm_cols(int S1) { return S1 >= 2 && S1 <= 4; }
                [nq1] "s"((u32)(nq >> 32)), [nq4] "s"(nq4), [q4] "s"(q4) : NTT_TILE_ASM_CLOBBERS)
 template <int S1, bool NT = false>
 RH_DEV void fwd_cols_asm_body(const u32 b, const u64* in, u64* out, const tw2* __restrict__ twn,
-                              const LimbConsts* __restrict__ consts, int L, int Ls = 0, u32 gap0 = 0, u32 gap_len = 0) {
+                              const LimbConsts* __restrict__ consts, int L, int Ls = 0, u32 gap0 = 0, u32 gap_len = 0, int Lso = 0) {
   if (Ls == 0) Ls = L;                     // rows per poly of the block (>= L)
+  if (Lso == 0) Lso = Ls;                  // ... of the output block, when it differs
   static_assert(has_asm_cols(S1), "asm column stages exist for S1 = 2..4");
   constexpr int logN = LT + S1;
   const u32 lrow = b % (u32)L;
@@ -60,7 +62,7 @@ RH_DEV void fwd_cols_asm_body(const u32 b, const u64* in, u64* out, const tw2* _
   const u32 r = b / (u32)L;
   const size_t base = (((size_t)(r >> 4) * Ls + limb) << logN) + (r & 15) * 256;
   const u64 pin = uni64((u64)(size_t)(in + base));
-  const u64 pout = uni64((u64)(size_t)(out + base));
+  const u64 pout = uni64((u64)(size_t)(out + (((size_t)(r >> 4) * Lso + limb) << logN) + (r & 15) * 256));
   const u64 tw = uni64((u64)(size_t)(twn + ((size_t)limb << logN)));
   const u64 q = uni64(consts[limb].q);
   const u64 nq = (u64)0 - q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
@@ -110,16 +112,16 @@ RH_DEV void fwd_cols_best(const u32 b, const u64* in, u64* out, const tw2* __res
 }
 template <int S1, bool NT = false>
 __global__ void __launch_bounds__(256)
-ntt_fwd_cols_asm(const u64* in, u64* out, const tw2* __restrict__ twn, const LimbConsts* __restrict__ consts, int L, int Ls) {
-  fwd_cols_asm_body<S1, NT>(blockIdx.x, in, out, twn, consts, L, Ls);
+ntt_fwd_cols_asm(const u64* in, u64* out, const tw2* __restrict__ twn, const LimbConsts* __restrict__ consts, int L, int Ls, int Lso = 0) {
+  fwd_cols_asm_body<S1, NT>(blockIdx.x, in, out, twn, consts, L, Ls, 0, 0, Lso);
 }
 
 template <bool NT = false>
 __global__ void __launch_bounds__(256)
 ntt_fwd_tile_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts,
-                 int L, int logN, int npoly, int Ls) {
+                 int L, int logN, int npoly, int Ls, int Lso = 0) {
   __shared__ u64 lds[LDS_WORDS];
-  fwd_tile_asm_body<false, NT>(lds, blockIdx.x, in, out, twk, consts, L, logN, npoly, Ls);
+  fwd_tile_asm_body<false, NT>(lds, blockIdx.x, in, out, twk, consts, L, logN, npoly, Ls, 0, 0, Lso);
 }
 
 // Forward tile stages with the subtract-multiply epilogue, hand-scheduled: same contract as ntt_fwd_tile_submul (ntt_kernels.hip.hpp),
