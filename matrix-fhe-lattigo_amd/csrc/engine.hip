@@ -736,6 +736,37 @@ static int ci_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lro
     const size_t toff = (size_t)limb0 * r->N;
     const CiFoldTw* cf = reinterpret_cast<const CiFoldTw*>(r->d_cifold + limb0);
     const LimbConsts* c = r->d_consts + limb0;
+    // large batches: the software pipeline of the standard ring's fused launches (spans of ~2048 rows): forward launch j = fold + column stages of
+    // span j with the tile stages of span j-1; inverse launch j = tile stages of span j with the column stages + fold of span j-1 (round 3)
+    int chunk = r->chunk_polys;
+    if (chunk < 0) { const int c0 = r->auto_span_rows / Lrows > 0 ? r->auto_span_rows / Lrows : 1; chunk = npoly > c0 ? c0 : 0; }
+    if (chunk > 0 && npoly > chunk && r->inv_scale) {
+      const int nspans = (npoly + chunk - 1) / chunk;
+      const size_t stride = (size_t)Lrows * r->N;
+      const bool ntp = r->nt_streams;
+      auto span = [&](int j, int* n) { const int p0 = j * chunk; *n = (j < 0 || j >= nspans) ? 0 : (npoly - p0 < chunk ? npoly - p0 : chunk); return (size_t)(j < 0 ? 0 : p0) * stride; };
+      for (int j = 0; j <= nspans; ++j) {
+        int p1, p2;
+        const size_t o1 = span(j, &p1), o2 = span(j - 1, &p2);
+        const unsigned rows1 = (unsigned)p1 * Lrows, rows2 = (unsigned)p2 * Lrows;
+        if (!inverse) {
+          const unsigned n1 = rows1 * 8, n2 = rows2 << S1, grid = n1 > n2 ? n1 : n2;
+#define RH_CIF(S) do { if (rows1) ci_col0_kernel<S, false><<<(rows1 + 63) / 64, 64, 0, st>>>(in + o1, out + o1, r->d_tw_fwd + toff, nullptr, cf, c, Lrows, rows1);                 \
+                       if (ntp) ntt_ci_fwd_fused_asm<S, true><<<grid, 256, 0, st>>>(in + o1, out + o1, n1, out + o2, n2, p2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, cf, c, Lrows);   \
+                       else ntt_ci_fwd_fused_asm<S, false><<<grid, 256, 0, st>>>(in + o1, out + o1, n1, out + o2, n2, p2, r->d_tw_fwd + toff, r->d_twk_fwd + toff, cf, c, Lrows); } while (0)
+          if (S1 == 4) RH_CIF(4); else if (S1 == 3) RH_CIF(3); else RH_CIF(2);
+#undef RH_CIF
+        } else {
+          const unsigned n1 = rows1 << S1, n2 = rows2 * 8, grid = n1 > n2 ? n1 : n2;
+#define RH_CII(S) do { if (ntp) ntt_ci_inv_fused_asm<S, true><<<grid, 256, 0, st>>>(in + o1, out + o1, n1, p1, out + o2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff, r->d_lastw + limb0, cf, c, Lrows);  \
+                       else ntt_ci_inv_fused_asm<S, false><<<grid, 256, 0, st>>>(in + o1, out + o1, n1, p1, out + o2, n2, r->d_twk_inv + toff, r->d_tw_inv + toff, r->d_lastw + limb0, cf, c, Lrows); \
+                       if (rows2) ci_col0_kernel<S, true><<<(rows2 + 63) / 64, 64, 0, st>>>(out + o2, out + o2, r->d_tw_inv + toff, r->d_lastw + limb0, cf, c, Lrows, rows2); } while (0)
+          if (S1 == 4) RH_CII(4); else if (S1 == 3) RH_CII(3); else RH_CII(2);
+#undef RH_CII
+        }
+      }
+      return check_launch("conjugate-invariant transform (pipelined)");
+    }
     const unsigned g8 = rows * 8, g0 = (rows + 63) / 64;
 #define RH_CI(S, INV, SRC, TW, LW) do { ntt_cols_ci_asm<S, INV><<<g8, 256, 0, st>>>(SRC, out, TW, LW, cf, c, Lrows);  \
                                         ci_col0_kernel<S, INV><<<g0, 64, 0, st>>>(SRC, out, TW, LW, cf, c, Lrows, rows); } while (0)

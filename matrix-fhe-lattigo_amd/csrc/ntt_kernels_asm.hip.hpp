@@ -355,12 +355,10 @@ ntt_inv_fused_asm(const u64* in1, const u64* in1b, u64* out1, unsigned n1, int n
 // Column 0 (its own mirror image, with the two special coefficients 0 and N/2) is ci_col0_kernel.
 struct CiFoldTw { tw2 f, b; };            // = CiFold (engine_internal.hpp): fold twiddles roots_fwd[1] / roots_bwd[1]
 template <int S1, bool INV>
-__global__ void __launch_bounds__(256)
-ntt_cols_ci_asm(const u64* in, u64* out, const tw2* __restrict__ twn, const tw2* __restrict__ lastw, const CiFoldTw* __restrict__ fold,
-                const LimbConsts* __restrict__ consts, int L) {
+RH_DEV void cols_ci_asm_body(const u32 b, const u64* in, u64* out, const tw2* __restrict__ twn, const tw2* __restrict__ lastw,
+                             const CiFoldTw* __restrict__ fold, const LimbConsts* __restrict__ consts, int L) {
   static_assert(has_asm_cols(S1), "asm column stages exist for S1 = 2..4");
   constexpr int logN = LT + S1;
-  const u32 b = blockIdx.x;
   const u32 limb = b % (u32)L, rr = b / (u32)L, g = rr & 7;
   const size_t row = ((size_t)(rr >> 3) * L + limb) << logN;
   const size_t offa = row + 256 * g + 1, offb = row + 256 * (15 - g);
@@ -395,6 +393,32 @@ ntt_cols_ci_asm(const u64* in, u64* out, const tw2* __restrict__ twn, const tw2*
     else RH_CI_FWD_ASM(NTT_CI_COLS4_FWD_ASM_BODY);
 #undef RH_CI_FWD_ASM
   }
+}
+template <int S1, bool INV>
+__global__ void __launch_bounds__(256)
+ntt_cols_ci_asm(const u64* in, u64* out, const tw2* __restrict__ twn, const tw2* __restrict__ lastw, const CiFoldTw* __restrict__ fold,
+                const LimbConsts* __restrict__ consts, int L) {
+  cols_ci_asm_body<S1, INV>(blockIdx.x, in, out, twn, lastw, fold, consts, L);
+}
+// The software pipeline of large conjugate-invariant batches (round 3), as ntt_fwd_fused_asm / ntt_inv_fused_asm for the standard ring:
+// forward launch j = fold + column stages of span j (n1 = rows * 8 units) + tile stages of span j-1; inverse launch j = tile stages of span j
+// + column stages + fold of span j-1.  Column 0 of a span is ci_col0_kernel, launched beside it (a one-thread-per-row kernel).
+template <int S1, bool NT>
+__global__ void __launch_bounds__(256)
+ntt_ci_fwd_fused_asm(const u64* in1, u64* out1, unsigned n1, u64* data2, unsigned n2, int npoly2, const tw2* __restrict__ twn,
+                     const tw2* __restrict__ twk, const CiFoldTw* __restrict__ fold, const LimbConsts* __restrict__ consts, int L) {
+  __shared__ u64 lds[LDS_WORDS];
+  if (blockIdx.x < n1) cols_ci_asm_body<S1, false>(blockIdx.x, in1, out1, twn, nullptr, fold, consts, L);
+  if (blockIdx.x < n2) fwd_tile_asm_body<false, NT>(lds, blockIdx.x, data2, data2, twk, consts, L, LT + S1, npoly2);
+}
+template <int S1, bool NT>
+__global__ void __launch_bounds__(256)
+ntt_ci_inv_fused_asm(const u64* in1, u64* out1, unsigned n1, int npoly1, u64* data2, unsigned n2, const tw2* __restrict__ twk,
+                     const tw2* __restrict__ twn, const tw2* __restrict__ lastw, const CiFoldTw* __restrict__ fold,
+                     const LimbConsts* __restrict__ consts, int L) {
+  __shared__ u64 lds[LDS_WORDS];
+  if (blockIdx.x < n2) cols_ci_asm_body<S1, true>(blockIdx.x, data2, data2, twn, lastw, fold, consts, L);
+  if (blockIdx.x < n1) inv_tile_asm_body<false, NT>(lds, blockIdx.x, in1, nullptr, out1, twk, consts, L, LT + S1, npoly1);
 }
 // column 0 of every (poly, limb) row: coefficients 4096 k, k < R.  Coefficient 0 is not folded (forward) / doubled (inverse), N/2 folds
 // with itself, k folds with R - k; column stages as fwd_cols_body<ShoupPolicy> / inv_cols_body(scale = 1).  One thread per row.

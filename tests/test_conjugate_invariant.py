@@ -67,3 +67,42 @@ def test_gpu_ci_vs_oracle(rh, oracle, logN):
     assert np.array_equal(ring.SubRings[1].NTT(a[0, 1]), exp[0, 1])
     assert np.array_equal(ring.SubRings[2].INTT(exp[1, 2]), a[1, 2])
     ring.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("logN,L,B", [(14, 3, 700), (15, 2, 2100), (16, 16, 140)])
+def test_gpu_ci_large_batches_run_the_fused_pipeline(rh, oracle, logN, L, B):
+    # batches of more than ~2048 rows: forward launch j = fold + column stages of span j with the tile stages of span j-1, inverse launch j = tile
+    # stages of span j with the column stages + fold of span j-1 (round 3) -- bit-identical to the two-launch path (chunk_polys = 0) and, on
+    # spot rows of the first, a middle and the last span, to the oracle; in place and out of place
+    import torch
+    N = 1 << logN
+    mods = [q for q in QI60 if (q - 1) % (4 * N) == 0][:L]
+    ring = rh.Ring(N, mods, kind=rh.ConjugateInvariant)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(logN * 7 + B)
+    qs = torch.tensor(mods, dtype=torch.int64, device=dev).view(1, L, 1)
+    x = torch.randint(0, 1 << 62, (B, L, N), dtype=torch.int64, device=dev, generator=g) % qs
+    dp = lambda t: rh.DevicePoly.from_torch(ring, t)
+    y, y0 = torch.empty_like(x), torch.empty_like(x)
+    ring.NTT(dp(x), dp(y))                                         # pipelined, out of place
+    ring.set_tuning("chunk_polys", 0)
+    ring.NTT(dp(x), dp(y0))                                        # two launches over the whole batch
+    ring.set_tuning("chunk_polys", -1)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0)
+    srs = [oracle.SubRingConsts(N, q, nthroot=4 * N) for q in mods]
+    h = lambda t, k, i: t[k, i].cpu().numpy().view(np.uint64)
+    for k in (0, B // 2 + 1, B - 1):
+        i = k % L
+        assert np.array_equal(h(y, k, i), oracle.ntt_ci(h(x, k, i), srs[i])), (k, i)
+    z = y.clone()
+    ring.INTT(dp(z), dp(z))                                        # pipelined, in place
+    torch.cuda.synchronize()
+    assert torch.equal(z, x)
+    z2 = torch.empty_like(x)
+    ring.set_tuning("chunk_polys", 0)
+    ring.INTT(dp(y), dp(z2))
+    torch.cuda.synchronize()
+    assert torch.equal(z2, x)
+    ring.close()

@@ -13,10 +13,13 @@ ring = rh.Ring(N, QI60[:L], kind=rh.ConjugateInvariant); ring.set_stream(stream.
 qs = torch.tensor(QI60[:L], dtype=torch.int64, device=dev).view(1, L, 1)
 x = torch.randint(0, 1 << 62, (B, L, N), dtype=torch.int64, device=dev) % qs
 p = rh.DevicePoly.from_torch(ring, x)
-for name, f in (("NTT", lambda: ring.NTT(p, p)), ("INTT", lambda: ring.INTT(p, p))):
-    f(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(5): f()
-    e1.record(stream); torch.cuda.synchronize()
-    print("CI", name, "B", B, "ms", round(e0.elapsed_time(e1) / 5, 4))
+for chunk in ([int(v) for v in sys.argv[2:]] or [-1]):          # chunk_polys values to compare on the same box: -1 auto (pipelined), 0 two launches
+  ring.set_tuning("chunk_polys", chunk)
+  print("chunk_polys", chunk)
+  for name, f in (("NTT", lambda: ring.NTT(p, p)), ("INTT", lambda: ring.INTT(p, p))):
+      f(); torch.cuda.synchronize()
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record(stream)
+      for _ in range(5): f()
+      e1.record(stream); torch.cuda.synchronize()
+      print("CI", name, "B", B, "ms", round(e0.elapsed_time(e1) / 5, 4))
