@@ -86,7 +86,7 @@ def test_bench_parent_fails_fast_when_a_rank_dies():
     import time
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--single-device", "--dist-backend", "gloo", "--batch", "64", "--steps",
-                          "200000", "--warmup", "1", "--no-cpu", "--no-verify", "--logn", "14", "--rank-timeout", "600"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          "2000000", "--warmup", "1", "--no-cpu", "--no-verify", "--logn", "14", "--rank-timeout", "600"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, env=env)
     victim, deadline = None, time.time() + 240
     while victim is None and time.time() < deadline:                     # a direct child of the parent that is a rank (its command line is bench.py's)
