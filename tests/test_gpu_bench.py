@@ -100,16 +100,35 @@ def test_bench_parent_fails_fast_when_a_rank_dies():
                     victim = int(d)
             except (OSError, IndexError, ValueError):
                 continue
-    assert victim is not None, "no rank process found"
-    time.sleep(20.0)                                                       # let the ranks get into their timed loop
-    os.kill(victim, signal.SIGKILL)                                        # the exact PID of one rank
-    t0 = time.time()
+    def rank_pids():
+        out = []
+        for d in os.listdir("/proc"):
+            if d.isdigit():
+                try:
+                    st = open("/proc/%s/stat" % d).read().rsplit(")", 1)[1].split()
+                    if int(st[1]) == p.pid and "bench.py" in open("/proc/%s/cmdline" % d).read():
+                        out.append(int(d))
+                except (OSError, IndexError, ValueError):
+                    pass
+        return out
     try:
-        _out, err = p.communicate(timeout=120)
-    except subprocess.TimeoutExpired:
-        p.kill()
-        raise AssertionError("parent still waiting 120 s after a rank died")
-    assert p.returncode != 0 and "rank exit codes" in err and time.time() - t0 < 120
+        assert victim is not None, "no rank process found"
+        time.sleep(20.0)                                                   # let the ranks get into their timed loop
+        os.kill(victim, signal.SIGKILL)                                    # the exact PID of one rank
+        t0 = time.time()
+        try:
+            _out, err = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            raise AssertionError("parent still waiting 120 s after a rank died")
+        assert p.returncode != 0 and "rank exit codes" in err and time.time() - t0 < 120
+    finally:                                                               # whatever happened: no rank of this test outlives it (exact PIDs, never a pattern)
+        for pid in rank_pids():
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except OSError:
+                pass
+        if p.poll() is None:
+            p.kill()
 
 
 def test_bench_drops_stale_counters(tmp_path):
