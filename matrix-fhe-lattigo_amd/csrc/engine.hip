@@ -339,6 +339,24 @@ static void launch_inv_cols(int S1, dim3 grid, hipStream_t st, u64* data, const 
   }
 }
 
+// One-pass launches (N = 2^13, 2^14; ntt_kernels_asm.hip.hpp): 68 / 136 KiB of dynamic LDS per workgroup, beyond the 64 KiB default limit.
+static bool one_pass_ok(rh_ring* r) {
+  const int S1 = r->logN - LT;
+  if (!(r->one_pass && r->asm_tile && (S1 == 1 || S1 == 2))) return false;
+  if (!r->one_pass_ready) {
+    const int b1 = 2 * LDS_WORDS * 8, b2 = 4 * LDS_WORDS * 8;
+    hipError_t e = hipSuccess;
+    auto raise = [&](const void* f, int bytes) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
+    raise((const void*)ntt_fwd_onepass_asm<1, false>, b1); raise((const void*)ntt_fwd_onepass_asm<1, true>, b1);
+    raise((const void*)ntt_fwd_onepass_asm<2, false>, b2); raise((const void*)ntt_fwd_onepass_asm<2, true>, b2);
+    raise((const void*)ntt_inv_onepass_asm<1, false>, b1); raise((const void*)ntt_inv_onepass_asm<1, true>, b1);
+    raise((const void*)ntt_inv_onepass_asm<2, false>, b2); raise((const void*)ntt_inv_onepass_asm<2, true>, b2);
+    if (e != hipSuccess) { (void)hipGetLastError(); r->one_pass = false; return false; }     // (a device without that much LDS: the two-pass launches)
+    r->one_pass_ready = true;
+  }
+  return true;
+}
+
 // limb0: first limb of the table set to use (host-pointer single-limb path); rows = npoly * Lrows.
 // phase: 0 = whole transform, 1 = column kernel only, 2 = tile kernel only (profiling aid, rh_ring_ntt_phase).
 static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse, bool lazy, int phase,
@@ -367,6 +385,23 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
   const int S1 = logN - LT;
   const unsigned tiles = rows << S1;
   const bool nt = r->nt_streams && (size_t)rows * (size_t)r->N * 8 >= ((size_t)512 << 20);   // non-temporal data streams beyond the Infinity Cache (see rh_streams_beyond_cache)
+  if (phase == 0 && !(lazy && !inverse) && one_pass_ok(r)) {          // (the forward lazy form keeps the reference's representatives: Montgomery bodies, two passes)
+    const size_t lds = ((size_t)LDS_WORDS * 8) << S1;
+    const dim3 wg(256u << S1);
+    const int sc = r->inv_scale ? 1 : 0;
+    if (!inverse) {
+      if (S1 == 1 && nt) ntt_fwd_onepass_asm<1, true><<<rows, wg, lds, st>>>(in, out, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, Ls, Lso);
+      else if (S1 == 1) ntt_fwd_onepass_asm<1, false><<<rows, wg, lds, st>>>(in, out, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, Ls, Lso);
+      else if (nt) ntt_fwd_onepass_asm<2, true><<<rows, wg, lds, st>>>(in, out, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, Ls, Lso);
+      else ntt_fwd_onepass_asm<2, false><<<rows, wg, lds, st>>>(in, out, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, Ls, Lso);
+    } else {
+      if (S1 == 1 && nt) ntt_inv_onepass_asm<1, true><<<rows, wg, lds, st>>>(in, out, r->d_twk_inv + toff, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Ls, Lso, sc);
+      else if (S1 == 1) ntt_inv_onepass_asm<1, false><<<rows, wg, lds, st>>>(in, out, r->d_twk_inv + toff, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Ls, Lso, sc);
+      else if (nt) ntt_inv_onepass_asm<2, true><<<rows, wg, lds, st>>>(in, out, r->d_twk_inv + toff, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Ls, Lso, sc);
+      else ntt_inv_onepass_asm<2, false><<<rows, wg, lds, st>>>(in, out, r->d_twk_inv + toff, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Ls, Lso, sc);
+    }
+    return check_launch("ntt (one pass)");
+  }
   if (!inverse) {
     const u64* src = in;
     if (S1 > 0) {
@@ -508,7 +543,7 @@ int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows,
     const int c = r->auto_span_rows / (Lrows > 0 ? Lrows : 1) > 0 ? r->auto_span_rows / Lrows : 1;   // 128 polys at 16 limbs (measured optimum: 64..128)
     chunk = npoly > c ? c : 0;
   }
-  const bool two_pass = r->logN > LT;
+  const bool two_pass = r->logN > LT && !one_pass_ok(r);
   if (chunk > 0 && two_pass && phase == 0 && !inverse && !lazy && npoly > chunk)
     return std_ntt_fwd_pipelined(r, in, out, npoly, Lrows, limb0, chunk);
   if (chunk > 0 && two_pass && phase == 0 && inverse && r->asm_tile && r->inv_scale && npoly > chunk)
@@ -829,7 +864,7 @@ extern "C" int rh_ring_ntt_many(rh_ring* r, const uint64_t* const* in, uint64_t*
   const int Lrows = level + 1;
   int chunk = r->chunk_polys;
   if (chunk < 0) chunk = r->auto_span_rows / Lrows > 0 ? r->auto_span_rows / Lrows : 1;
-  if (r->kind == RH_RING_STANDARD && r->logN > LT && chunk > 0 && total > chunk) {
+  if (r->kind == RH_RING_STANDARD && r->logN > LT && !one_pass_ok(r) && chunk > 0 && total > chunk) {
     std::vector<NttSeg> segs;
     for (int k = 0; k < nblocks; ++k) if (npoly[k] > 0) segs.push_back(NttSeg{in[k], out[k], npoly[k]});
     return std_ntt_fwd_pipelined_segs(r, segs.data(), (int)segs.size(), Lrows, 0, chunk);
@@ -1058,6 +1093,7 @@ extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
     return RH_OK;
   }
   if (!strcmp(key, "asm_cols")) { r->asm_cols = (int)value; return RH_OK; }
+  if (!strcmp(key, "one_pass")) { r->one_pass = value != 0; return RH_OK; }          // 0: the two-pass launches at N = 2^13 / 2^14 too (A/B runs)
   if (!strcmp(key, "nt_streams")) { r->nt_streams = value != 0; if (r->kind == RH_RING_3N) rh_ring3n_set_nt_streams(r, value != 0); return RH_OK; }     // 0: default cache policy everywhere (A/B runs: bench.py --tune nt_streams=0)
   return rh_fail(RH_ERR_ARG, "set_tuning: unknown key %s", key);
 }

@@ -263,6 +263,7 @@ def test_fused_pipeline_spans_give_identical_results(rh, oracle, logN, chunk):
     a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
     p = rh.DevicePoly.from_numpy(ring, a)
     ref = ring.NewPoly(B)
+    ring.set_tuning("one_pass", 0)                    # (N = 2^13 would take the one-pass kernel, which has no spans)
     ring.NTT(p, ref)
     ring.set_tuning("chunk_polys", chunk)
     ring.NTT(p, p)                                    # in place, 7 polys in spans of `chunk`
@@ -288,6 +289,8 @@ def test_ntt_many_blocks_equal_separate_calls(rh, oracle, logN, chunk):
         ring.set_tuning("chunk_polys", chunk)
     else:
         ring.set_tuning("auto_span_rows", 6)          # spans of 2 polys: 10 polys in three blocks are pipelined
+    if logN == 13:
+        ring.set_tuning("one_pass", 0)                # the pipeline through several blocks is the two-pass rings' path
     ps = [rh.DevicePoly.from_numpy(ring, a) for a in blocks]
     outs = [ps[0], ring.NewPoly(sizes[1]), ps[2]]     # blocks 0 and 2 in place, block 1 out of place
     ring.NTTMany(list(zip(ps, outs)))
@@ -333,6 +336,7 @@ def test_inverse_asm_and_pipeline_equal_cxx(rh, oracle, logN, B):
     a[1, :, ::2] += np.array(mods, dtype=np.uint64)[:, None]            # < 2q: accepted like the reference's invbutterfly
     p = rh.DevicePoly.from_numpy(ring, a)
     o1, o2 = ring.NewPoly(B), ring.NewPoly(B)
+    ring.set_tuning("one_pass", 0)
     ring.set_tuning("asm_tile", 1); ring.INTT(p, o1)
     ring.set_tuning("asm_tile", 0); ring.INTT(p, o2)
     x1 = o1.numpy()
@@ -355,6 +359,7 @@ def test_asm_column_stages_identical(rh, oracle, logN, L, B):
     a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
     p = rh.DevicePoly.from_numpy(ring, a)
     ref, o = ring.NewPoly(B), ring.NewPoly(B)
+    ring.set_tuning("one_pass", 0)                      # (N = 2^14 would take the one-pass kernel: this test is about the two-pass launches)
     ring.set_tuning("asm_cols", 0); ring.NTT(p, ref)
     ring.set_tuning("asm_cols", 1); ring.NTT(p, o); ring.sync()
     assert np.array_equal(o.numpy(), ref.numpy())
@@ -374,11 +379,56 @@ def test_asm_inverse_column_stages_identical(rh, oracle, logN, L, B):
     a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
     p = rh.DevicePoly.from_numpy(ring, a)
     ref, o = ring.NewPoly(B), ring.NewPoly(B)
+    ring.set_tuning("one_pass", 0)
     ring.set_tuning("asm_cols", 0); ring.INTT(p, ref)
     ring.set_tuning("asm_cols", 1); ring.INTT(p, o); ring.sync()
     assert np.array_equal(o.numpy(), ref.numpy())
     sr = oracle.SubRingConsts(N, mods[L - 1])
     assert np.array_equal(o.numpy()[B - 1, L - 1], oracle.intt(a[B - 1, L - 1], sr))
     ring.INTT(p, p); ring.NTT(p, p); ring.sync()        # in place, and back
+    assert np.array_equal(p.numpy(), a)
+    ring.close()
+
+
+@pytest.mark.parametrize("logN,L,B", [(13, 3, 3), (14, 3, 3), (13, 16, 40), (14, 5, 300), (13, 2, 4200), (14, 2, 2100)])
+def test_one_pass_kernels_identical_to_two_pass(rh, oracle, logN, L, B):
+    # N = 2^13 / 2^14: the whole limb row in one workgroup's LDS (ntt_fwd_onepass_asm / ntt_inv_onepass_asm, the default) against the two-pass
+    # launches and the oracle: worst-case inputs, in place, inverse inputs < 2q, and batches >= 512 MiB (the non-temporal bodies)
+    N, mods = 1 << logN, QI60[:L]
+    ring = rh.Ring(N, mods)
+    rng = np.random.default_rng(1000 * logN + L + B)
+    qv = np.array(mods, dtype=np.uint64)[:, None]
+    if B <= 300:
+        a = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(B)])
+    else:                                                  # big batch: a few random polys, tiled
+        base = np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(7)])
+        a = np.concatenate([base] * (B // 7 + 1))[:B].copy()
+    a[0] = qv - np.uint64(1)
+    a[1, :, ::2] = 0
+    p = rh.DevicePoly.from_numpy(ring, a)
+    f1, f2 = ring.NewPoly(B), ring.NewPoly(B)
+    ring.set_tuning("one_pass", 1); ring.NTT(p, f1)
+    ring.set_tuning("one_pass", 0); ring.NTT(p, f2); ring.sync()
+    x1 = f1.numpy()
+    assert np.array_equal(x1, f2.numpy())
+    srs = [oracle.SubRingConsts(N, q) for q in mods]
+    for k in (0, 1, B - 1):
+        for i in (0, L - 1):
+            assert np.array_equal(x1[k, i], oracle.ntt(a[k, i], srs[i]))
+    # inverse: canonical inputs and inputs < 2q
+    y = x1.copy()
+    y[2, :, 1::2] += qv
+    py = rh.DevicePoly.from_numpy(ring, y)
+    g1, g2 = ring.NewPoly(B), ring.NewPoly(B)
+    ring.set_tuning("one_pass", 1); ring.INTT(py, g1)
+    ring.set_tuning("one_pass", 0); ring.INTT(py, g2); ring.sync()
+    z1 = g1.numpy()
+    assert np.array_equal(z1, g2.numpy())
+    assert np.array_equal(z1, a)
+    # in place, forward then back
+    ring.set_tuning("one_pass", 1)
+    ring.NTT(p, p); ring.sync()
+    assert np.array_equal(p.numpy(), x1)
+    ring.INTT(p, p); ring.sync()
     assert np.array_equal(p.numpy(), a)
     ring.close()

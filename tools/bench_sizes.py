@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Ring.NTT / INTT rate by ring degree (N = 2^12 .. 2^17, 16 limbs, 4 GiB batches): does every size the reference's parameter sets use
-(ring/ring.go:318: N up to 2^17) sit near the headline's fraction of HBM?  JSON on stdout."""
+(ring/ring.go:318: N up to 2^17) sit near the headline's fraction of HBM?  JSON on stdout.
+Arguments: key=value tuning pairs applied to every ring (e.g. one_pass=0: the two-pass launches at N = 2^13 / 2^14 too), logn=13,14 to pick sizes."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,10 +12,14 @@ from bench import QI60
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream()
 res = []
-for logn in (12, 13, 14, 15, 16, 17):
+tunes = [a.split("=") for a in sys.argv[1:] if "=" in a and not a.startswith("logn=")]
+sizes = [int(v) for a in sys.argv[1:] if a.startswith("logn=") for v in a[5:].split(",")] or [12, 13, 14, 15, 16, 17]
+for logn in sizes:
     N, L = 1 << logn, 16
     B = (4 << 30) // (N * L * 8)
     ring = rh.Ring(N, QI60[:L]); ring.set_stream(stream.cuda_stream)
+    for k, v in tunes:
+        ring.set_tuning(k, int(v))
     x = torch.randint(0, 1 << 60, (B, L, N), dtype=torch.int64, device=dev)
     p = rh.DevicePoly.from_torch(ring, x)
     row = {"logN": logn, "batch": B}

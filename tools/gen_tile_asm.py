@@ -246,7 +246,7 @@ INV_SLOT_ORDER = list(range(7, 15)) + list(range(3, 7)) + [1, 2] + [0]      # co
 INV_NEED = {3: 8, 2: 12, 1: 14, 0: 15}                                      # twiddle quads needed before stage u
 
 
-def gen_inverse(mul=False, from_registers=False):
+def gen_inverse(mul=False, from_registers=False, lds_out=False):
     """first 12 stages (t = 1..2048) of the inverse transform on a 4096-tile; values leave < 4q (no scaling):
     mirror image of gen(); same LDS layout and kernel-order twiddle table (built from RootsBackward).
     mul: the input is the pointwise Montgomery product of two blocks (pin, pin2), formed on load (rh_ring_intt_mul); the second
@@ -323,6 +323,11 @@ def gen_inverse(mul=False, from_registers=False):
     emit("s_waitcnt lgkmcnt(0)")
     emit("; ---- round A' (t = 256 .. 2048), twiddles in SGPRs")
     round16_inv(lambda slot: (None, ("s%d" % (36 + 4 * slot), "s%d" % (37 + 4 * slot), "s%d" % (38 + 4 * slot), "s%d" % (39 + 4 * slot))))
+    if lds_out:          # one-pass transform: the tile stays in LDS (layout A, the thread's own slots of round A') for the column stages of the same kernel
+        for k in range(16):
+            emit("ds_write_b64 v%d, %s offset:%d" % (A3, pair(X(k)), 2176 * k))
+        emit("s_waitcnt lgkmcnt(0)")
+        return
     emit("v_lshlrev_b32 v%d, 3, %%[tid]" % A0)
     for j in range(4):
         emit("v_add_u32 v%d, %d, v%d" % (SCR + j, 8192 * j + 4096, A0))
@@ -395,8 +400,14 @@ def csub_all(const_name):
             emit("v_bfi_b32 v%d, v%d, v%d, v%d" % (X(kk) + 1, t.M, X(kk) + 1, t.T + 1))
 
 
-def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True, epilogue=None, lazy_out=False, stop_after_reduce=False, barrier_before_lds=False, reduce_below_2q=False):
+def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True, epilogue=None, lazy_out=False, stop_after_reduce=False, barrier_before_lds=False, reduce_below_2q=False,
+        lds_in=False):
+    """lds_in: the tile already sits in the workgroup's LDS in layout A (word tid + (tid >> 4) + 272 k holds coefficient tid + 256 k), written
+    by the column stages of the same kernel (one-pass transform of N = 2^13 / 2^14): the 16 data loads become ds_reads of the thread's OWN slots,
+    which round A then overwrites -- no barrier in between"""
     A0, A1, A2, A3 = ADDR, ADDR + 1, ADDR + 2, ADDR + 3
+    if lds_in:
+        preloaded = True
     emit("; ---- prologue: zero halves of the zero-extended pairs, addresses")
     if PRIO in (1, 2):
         emit("s_setprio 3")                                   # a young wave issues its loads ahead of the older waves' butterflies
@@ -410,6 +421,13 @@ def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True, epilogue
     emit("v_lshlrev_b32 v%d, 3, %%[tid]" % A0)
     for j in range(4):
         emit("v_add_u32 v%d, %d, v%d" % (SCR + j, 8192 * j + 4096, A0))
+    if lds_in:
+        emit("v_lshrrev_b32 v%d, 4, %%[tid]" % A1)            # hi4
+        emit("v_add_u32 v%d, %%[tid], v%d" % (A3, A1))
+        emit("v_lshlrev_b32 v%d, 3, v%d" % (A3, A3))          # addrA
+        emit("v_add_u32 v%d, %%[lds], v%d" % (A3, A3))
+        for k in range(16):
+            emit("ds_read_b64 %s, v%d offset:%d" % (pair(X(k)), A3, 2176 * k))
     for kk in range(16):
         if preloaded:
             break                                             # x[k] already sits in v[2k:2k+1] (loaded by the caller)
@@ -1154,6 +1172,13 @@ for _suffix, _flags in (("", ""), ("_NT", " nt")):
     del out[:]
     gen_polymul()
     polymul = list(out)
+    del out[:]
+    gen(lds_in=True)
+    fwd_ldsin = list(out)
+    del out[:]
+    gen_inverse(lds_out=True)
+    inv_ldsout = list(out)
+    bodies_text += render("NTT_TILE_LDSIN_ASM_BODY" + _suffix, fwd_ldsin) + render("NTT_TILE_INV_LDSOUT_ASM_BODY" + _suffix, inv_ldsout)
     bodies_text += render("NTT_TILE_POLYMUL_ASM_BODY" + _suffix, polymul)
     bodies_text += (render("NTT_TILE_ASM_BODY" + _suffix, fwd) + render("NTT_TILE_LAZY_ASM_BODY" + _suffix, fwd_lazy) + render("NTT_TILE_SUBMUL_ASM_BODY" + _suffix, fwd_sm)
                     + render("NTT_TILE_SUBMUL_ADD_ASM_BODY" + _suffix, fwd_sma)
