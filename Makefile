@@ -8,7 +8,7 @@ SRCS  := $(CSRC)/engine.hip $(CSRC)/ntt3n.hip $(CSRC)/bext.hip $(CSRC)/rescale.h
 HDRS  := $(wildcard $(CSRC)/*.hip.hpp) $(wildcard $(CSRC)/*.inc) $(wildcard $(CSRC)/*.hpp) $(wildcard include/*.h)
 
 ROCM ?= /opt/rocm
-all: $(LIB) oracle tests/cpp/test_ring_cpp tests/cpp/test_sharded_host
+all: $(LIB) oracle tests/cpp/test_ring_cpp tests/cpp/test_sharded_host tests/cpp/libabort_trace.so
 
 $(CSRC)/ntt_tile_asm.inc: tools/gen_tile_asm.py
 	python3 tools/gen_tile_asm.py $@
@@ -23,6 +23,10 @@ tests/cpp/test_ring_cpp: tests/cpp/test_ring_cpp.cpp tests/cpp/golden_vectors.in
 # a compiled host with threads as ranks and a plain-C all-gather callback: the limb-sharded key switch through the C ABI alone
 tests/cpp/test_sharded_host: tests/cpp/test_sharded_host.cpp include/ringhip.h $(LIB)
 	g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -Iinclude -I$(ROCM)/include $< -L$(PKG)/lib -lringhip -L$(ROCM)/lib -lamdhip64 -lpthread -Wl,-rpath,'$$ORIGIN/../../$(PKG)/lib' -Wl,-rpath,$(ROCM)/lib -o $@
+
+# test infrastructure: native call stack on SIGABRT (tests/conftest.py loads it when it is there)
+tests/cpp/libabort_trace.so: tests/cpp/abort_trace.c
+	gcc -O1 -g -fPIC -shared $< -o $@
 
 oracle: oracle/libring_oracle.so
 oracle/libring_oracle.so: oracle/ring_oracle.c oracle/ring_oracle.h include/ringhip_ops.h

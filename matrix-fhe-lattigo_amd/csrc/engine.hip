@@ -116,6 +116,7 @@ static int validate_degree(int kind, int N) {
   return rh_fail(RH_ERR_ARG, "unknown ring kind %d", kind);
 }
 
+static bool one_pass_ok(rh_ring* r);
 extern "C" int rh_ring_create(rh_ring** out, int device, int kind, int N, int L, const uint64_t* moduli, const uint64_t* mred,
                               const uint64_t* bred, const uint64_t* ninv, const uint64_t* roots_fwd, const uint64_t* roots_bwd,
                               const uint64_t* omega3n) {
@@ -204,6 +205,7 @@ extern "C" int rh_ring_create(rh_ring** out, int device, int kind, int N, int L,
   if (!rc) rc = upload(&r->d_consts, hc);
   if (rc) { rh_ring_destroy(r); return rc; }
   r->hconsts = hc;
+  (void)one_pass_ok(r);          // N = 2^13 / 2^14: raise the one-pass kernels' dynamic-LDS limit now, while one thread owns the handle
   *out = r;
   return RH_OK;
 }

@@ -7,6 +7,21 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The HIP runtime aborts SILENTLY on an asynchronous queue error at its default log level; level 1 (errors only; nothing is printed on a
+# healthy run) makes it say which one.  Set before the first HIP call of the session; a value from the environment wins.
+os.environ.setdefault("AMD_LOG_LEVEL", "1")
+os.environ.setdefault("LIBC_FATAL_STDERR_", "1")      # glibc's own fatal messages (heap consistency checks) to stderr, not to the controlling terminal
+
+
+def _install_abort_trace():
+    """native call stack on SIGABRT (tests/cpp/abort_trace.c, built by `make`): installed after pytest's faulthandler, which it chains to"""
+    import ctypes
+    so = os.path.join(ROOT, "tests", "cpp", "libabort_trace.so")
+    if os.path.exists(so):
+        try:
+            ctypes.CDLL(so).abort_trace_install()
+        except OSError:
+            pass
 
 # Qi60 / Pi60: the reference's 61-bit NTT-friendly test primes (ring/test_params.go:15-32), data only.
 QI60 = [0x1fffffffffe00001, 0x1fffffffffc80001, 0x1fffffffffb40001, 0x1fffffffff500001,
@@ -29,6 +44,10 @@ PI60 = [0x1ffffffff6c80001, 0x1ffffffff6140001, 0x1ffffffff5f40001, 0x1ffffffff5
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    _install_abort_trace()
 
 
 def uniform_mod(rng, q, shape):

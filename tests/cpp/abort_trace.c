@@ -1,0 +1,43 @@
+// abort_trace.c -- TEST INFRASTRUCTURE (loaded by tests/conftest.py through ctypes; not part of libringhip.so).
+// A SIGABRT in the GPU suite comes without a word when a runtime library calls abort() directly: this handler writes the native call stack
+// of the aborting thread to stderr (module + offset per frame: resolve with llvm-symbolizer against the same image), then hands over to the
+// handler that was installed before (Python's faulthandler), which prints the Python stack and lets the process die with SIGABRT as before.
+#define _GNU_SOURCE
+#include <execinfo.h>
+#include <signal.h>
+#include <string.h>
+#include <unistd.h>
+
+static struct sigaction prev_abrt;
+
+static void on_abort(int sig, siginfo_t* info, void* ctx) {
+  static const char head[] = "\n==== SIGABRT: native call stack of the aborting thread (tests/cpp/abort_trace.c) ====\n";
+  void* frames[96];
+  int n;
+  (void)!write(2, head, sizeof head - 1);
+  n = backtrace(frames, 96);
+  backtrace_symbols_fd(frames, n, 2);
+  {
+    static const char tail[] = "==== end of native call stack ====\n";
+    (void)!write(2, tail, sizeof tail - 1);
+  }
+  if (prev_abrt.sa_flags & SA_SIGINFO) {
+    if (prev_abrt.sa_sigaction) { prev_abrt.sa_sigaction(sig, info, ctx); return; }
+  } else if (prev_abrt.sa_handler != SIG_DFL && prev_abrt.sa_handler != SIG_IGN) {
+    prev_abrt.sa_handler(sig);
+    return;
+  }
+  signal(SIGABRT, SIG_DFL);
+  raise(SIGABRT);
+}
+
+int abort_trace_install(void) {
+  struct sigaction sa;
+  void* warm[4];
+  (void)backtrace(warm, 4);              // loads libgcc's unwinder now, not inside the handler
+  memset(&sa, 0, sizeof sa);
+  sa.sa_sigaction = on_abort;
+  sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+  sigemptyset(&sa.sa_mask);
+  return sigaction(SIGABRT, &sa, &prev_abrt);
+}
