@@ -391,16 +391,17 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
     const size_t lds = ((size_t)LDS_WORDS * 8) << S1;
     const dim3 wg(256u << S1);
     const int sc = r->inv_scale ? 1 : 0;
+    const unsigned grid = rows;
     if (!inverse) {
-      if (S1 == 1 && nt) ntt_fwd_onepass_asm<1, true><<<rows, wg, lds, st>>>(in, out, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, Ls, Lso);
-      else if (S1 == 1) ntt_fwd_onepass_asm<1, false><<<rows, wg, lds, st>>>(in, out, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, Ls, Lso);
-      else if (nt) ntt_fwd_onepass_asm<2, true><<<rows, wg, lds, st>>>(in, out, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, Ls, Lso);
-      else ntt_fwd_onepass_asm<2, false><<<rows, wg, lds, st>>>(in, out, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, Ls, Lso);
+      if (S1 == 1 && nt) ntt_fwd_onepass_asm<1, true><<<grid, wg, lds, st>>>(in, out, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, Ls, Lso);
+      else if (S1 == 1) ntt_fwd_onepass_asm<1, false><<<grid, wg, lds, st>>>(in, out, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, Ls, Lso);
+      else if (nt) ntt_fwd_onepass_asm<2, true><<<grid, wg, lds, st>>>(in, out, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, Ls, Lso);
+      else ntt_fwd_onepass_asm<2, false><<<grid, wg, lds, st>>>(in, out, r->d_tw_fwd + toff, r->d_twk_fwd + toff, c, Lrows, Ls, Lso);
     } else {
-      if (S1 == 1 && nt) ntt_inv_onepass_asm<1, true><<<rows, wg, lds, st>>>(in, out, r->d_twk_inv + toff, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Ls, Lso, sc);
-      else if (S1 == 1) ntt_inv_onepass_asm<1, false><<<rows, wg, lds, st>>>(in, out, r->d_twk_inv + toff, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Ls, Lso, sc);
-      else if (nt) ntt_inv_onepass_asm<2, true><<<rows, wg, lds, st>>>(in, out, r->d_twk_inv + toff, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Ls, Lso, sc);
-      else ntt_inv_onepass_asm<2, false><<<rows, wg, lds, st>>>(in, out, r->d_twk_inv + toff, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Ls, Lso, sc);
+      if (S1 == 1 && nt) ntt_inv_onepass_asm<1, true><<<grid, wg, lds, st>>>(in, out, r->d_twk_inv + toff, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Ls, Lso, sc);
+      else if (S1 == 1) ntt_inv_onepass_asm<1, false><<<grid, wg, lds, st>>>(in, out, r->d_twk_inv + toff, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Ls, Lso, sc);
+      else if (nt) ntt_inv_onepass_asm<2, true><<<grid, wg, lds, st>>>(in, out, r->d_twk_inv + toff, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Ls, Lso, sc);
+      else ntt_inv_onepass_asm<2, false><<<grid, wg, lds, st>>>(in, out, r->d_twk_inv + toff, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Ls, Lso, sc);
     }
     return check_launch("ntt (one pass)");
   }
@@ -1095,7 +1096,7 @@ extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
     return RH_OK;
   }
   if (!strcmp(key, "asm_cols")) { r->asm_cols = (int)value; return RH_OK; }
-  if (!strcmp(key, "one_pass")) { r->one_pass = value != 0; return RH_OK; }          // 0: the two-pass launches at N = 2^13 / 2^14 too (A/B runs)
+  if (!strcmp(key, "one_pass")) { r->one_pass = value != 0; return RH_OK; }
   if (!strcmp(key, "nt_streams")) { r->nt_streams = value != 0; if (r->kind == RH_RING_3N) rh_ring3n_set_nt_streams(r, value != 0); return RH_OK; }     // 0: default cache policy everywhere (A/B runs: bench.py --tune nt_streams=0)
   return rh_fail(RH_ERR_ARG, "set_tuning: unknown key %s", key);
 }

@@ -497,64 +497,65 @@ ci_col0_kernel(const u64* in, u64* out, const tw2* __restrict__ twn, const tw2* 
 // Contract: ring/ntt.go:209-552 + reducevec / :554-714 + NInv, outputs canonical -- identical to the two-pass launches (tests: every N = 2^13 / 2^14 case).
 // ---------------------------------------------------------------------------------------------------------------
 RH_DEV u32 lds_word_a(u32 j) { const u32 t = j & 255u; return t + (t >> 4) + 272u * (j >> 8); }
-
 template <int S1, bool NT>
 __global__ void __launch_bounds__(256 << S1)
 ntt_fwd_onepass_asm(const u64* in, u64* out, const tw2* __restrict__ twn, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts,
                     int L, int Ls, int Lso) {
   extern __shared__ u64 op_lds[];                     // (1 << S1) * LDS_WORDS
   constexpr int R = 1 << S1, logN = LT + S1, T = 256 << S1, PER = 16 >> S1;
-  const u32 b = blockIdx.x;
-  const u32 limb = b % (u32)L, poly = b / (u32)L;
   if (Ls == 0) Ls = L;
   if (Lso == 0) Lso = Ls;
-  const size_t base = ((size_t)poly * Ls + limb) << logN;
   {
-    const tw2* tw = twn + ((size_t)limb << logN);
-    ShoupPolicy p; p.init(consts[limb]);
-    u64 x[PER][R];
+    const u32 b = blockIdx.x;
+    const u32 limb = b % (u32)L, poly = b / (u32)L;
+    const size_t base = ((size_t)poly * Ls + limb) << logN;
+    {
+      const tw2* tw = twn + ((size_t)limb << logN);
+      ShoupPolicy p; p.init(consts[limb]);
+      u64 x[PER][R];
 #pragma unroll
-    for (int i = 0; i < PER; ++i)
+      for (int i = 0; i < PER; ++i)
 #pragma unroll
-      for (int c = 0; c < R; ++c) {
-        const u64* src = in + base + ((size_t)c << LT) + i * T + threadIdx.x;
-        x[i][c] = NT ? __builtin_nontemporal_load(src) : *src;
+        for (int c = 0; c < R; ++c) {
+          const u64* src = in + base + ((size_t)c << LT) + i * T + threadIdx.x;
+          x[i][c] = NT ? __builtin_nontemporal_load(src) : *src;
+        }
+#pragma unroll
+      for (int s = 0; s < S1; ++s) {
+        const int h = R >> (s + 1);
+#pragma unroll
+        for (int g = 0; g < (1 << s); ++g) {
+          const tw2 w = tw[(1 << s) + g];
+#pragma unroll
+          for (int e = 0; e < h; ++e)
+#pragma unroll
+            for (int i = 0; i < PER; ++i) p.fwd(x[i][g * 2 * h + e], x[i][g * 2 * h + e + h], w, false);
+        }
       }
 #pragma unroll
-    for (int s = 0; s < S1; ++s) {
-      const int h = R >> (s + 1);
+      for (int i = 0; i < PER; ++i) {
+        const u32 wa = lds_word_a((u32)(i * T) + threadIdx.x);
 #pragma unroll
-      for (int g = 0; g < (1 << s); ++g) {
-        const tw2 w = tw[(1 << s) + g];
-#pragma unroll
-        for (int e = 0; e < h; ++e)
-#pragma unroll
-          for (int i = 0; i < PER; ++i) p.fwd(x[i][g * 2 * h + e], x[i][g * 2 * h + e + h], w, false);
+        for (int c = 0; c < R; ++c) op_lds[c * LDS_WORDS + wa] = x[i][c];
       }
     }
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const u32 wa = lds_word_a((u32)(i * T) + threadIdx.x);
-#pragma unroll
-      for (int c = 0; c < R; ++c) op_lds[c * LDS_WORDS + wa] = x[i][c];
-    }
-  }
-  __syncthreads();
-  const u32 g = uni32(threadIdx.x >> 8);              // this wave's tile
-  const u32 tid = threadIdx.x & 255u;
-  const u64 pout = uni64((u64)(size_t)(out + (((size_t)poly * Lso + limb) << logN) + ((size_t)g << LT)));
-  const u64 pin = pout;                               // (unused by the body)
-  const u64 tw = uni64((u64)(size_t)(twk + ((size_t)limb << logN) + ((size_t)g << LT)));
-  const u64 q = uni64(consts[limb].q);
-  const u64 nq = (u64)0 - q, nq2 = (u64)0 - 2 * q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
-  const u32 lds_off = uni32((u32)(size_t)(op_lds + g * LDS_WORDS));
+    __syncthreads();
+    const u32 g = uni32(threadIdx.x >> 8);              // this wave's tile
+    const u32 tid = threadIdx.x & 255u;
+    const u64 pout = uni64((u64)(size_t)(out + (((size_t)poly * Lso + limb) << logN) + ((size_t)g << LT)));
+    const u64 pin = pout;                               // (unused by the body)
+    const u64 tw = uni64((u64)(size_t)(twk + ((size_t)limb << logN) + ((size_t)g << LT)));
+    const u64 q = uni64(consts[limb].q);
+    const u64 nq = (u64)0 - q, nq2 = (u64)0 - 2 * q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
+    const u32 lds_off = uni32((u32)(size_t)(op_lds + g * LDS_WORDS));
 #define RH_TILE_LDSIN_ASM(BODY)                                                                                         \
   asm volatile(BODY : : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw),             \
                [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)), [nq0] "s"((u32)nq),                    \
                [nq1] "s"((u32)(nq >> 32)), [nq] "s"(nq), [nq2] "s"(nq2), [nq4] "s"(nq4), [q4] "s"(q4) : NTT_TILE_ASM_CLOBBERS)
-  if constexpr (NT) RH_TILE_LDSIN_ASM(NTT_TILE_LDSIN_ASM_BODY_NT);
-  else RH_TILE_LDSIN_ASM(NTT_TILE_LDSIN_ASM_BODY);
+    if constexpr (NT) RH_TILE_LDSIN_ASM(NTT_TILE_LDSIN_ASM_BODY_NT);
+    else RH_TILE_LDSIN_ASM(NTT_TILE_LDSIN_ASM_BODY);
 #undef RH_TILE_LDSIN_ASM
+  }
 }
 
 // scale: 1 = the last stage folds N^-1 in and reduces canonically (inv_cols_body); 0 = plain last stage, values stay < 4q
@@ -564,68 +565,70 @@ ntt_inv_onepass_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const 
                     const LimbConsts* __restrict__ consts, int L, int Ls, int Lso, int scale) {
   extern __shared__ u64 op_lds[];
   constexpr int R = 1 << S1, logN = LT + S1, T = 256 << S1, PER = 16 >> S1;
-  const u32 b = blockIdx.x;
-  const u32 limb = b % (u32)L, poly = b / (u32)L;
   if (Ls == 0) Ls = L;
   if (Lso == 0) Lso = Ls;
   {
-    const u32 g = uni32(threadIdx.x >> 8);
-    const u32 tid = threadIdx.x & 255u;
-    const u64 pin = uni64((u64)(size_t)(in + (((size_t)poly * Ls + limb) << logN) + ((size_t)g << LT)));
-    const u64 pout = pin;                             // (unused by the body)
-    const u64 tw = uni64((u64)(size_t)(twk + ((size_t)limb << logN) + ((size_t)g << LT)));
-    const u64 q = uni64(consts[limb].q);
-    const u64 nq = (u64)0 - q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
-    const u32 lds_off = uni32((u32)(size_t)(op_lds + g * LDS_WORDS));
+    const u32 b = blockIdx.x;
+    const u32 limb = b % (u32)L, poly = b / (u32)L;
+    {
+      const u32 g = uni32(threadIdx.x >> 8);
+      const u32 tid = threadIdx.x & 255u;
+      const u64 pin = uni64((u64)(size_t)(in + (((size_t)poly * Ls + limb) << logN) + ((size_t)g << LT)));
+      const u64 pout = pin;                             // (unused by the body)
+      const u64 tw = uni64((u64)(size_t)(twk + ((size_t)limb << logN) + ((size_t)g << LT)));
+      const u64 q = uni64(consts[limb].q);
+      const u64 nq = (u64)0 - q, nq4 = (u64)0 - 4 * q, q4 = 4 * q;
+      const u32 lds_off = uni32((u32)(size_t)(op_lds + g * LDS_WORDS));
 #define RH_TILE_INV_LDSOUT_ASM(BODY)                                                                                              \
   asm volatile(BODY : : [tid] "v"(tid), [lds] "s"(lds_off), [pin] "s"(pin), [pout] "s"(pout), [tw] "s"(tw),                          \
                [twlo] "s"((u32)(size_t)tw), [twhi] "s"((u32)((size_t)tw >> 32)), [nq0] "s"((u32)nq), [nq1] "s"((u32)(nq >> 32)),     \
                [nq4] "s"(nq4), [q4] "s"(q4) : NTT_TILE_ASM_CLOBBERS)
-    if constexpr (NT) RH_TILE_INV_LDSOUT_ASM(NTT_TILE_INV_LDSOUT_ASM_BODY_NT);
-    else RH_TILE_INV_LDSOUT_ASM(NTT_TILE_INV_LDSOUT_ASM_BODY);
+      if constexpr (NT) RH_TILE_INV_LDSOUT_ASM(NTT_TILE_INV_LDSOUT_ASM_BODY_NT);
+      else RH_TILE_INV_LDSOUT_ASM(NTT_TILE_INV_LDSOUT_ASM_BODY);
 #undef RH_TILE_INV_LDSOUT_ASM
-  }
-  __syncthreads();
-  const size_t obase = ((size_t)poly * Lso + limb) << logN;
-  const tw2* tw = twn + ((size_t)limb << logN);
-  const LimbConsts c = consts[limb];
-  ShoupPolicy p; p.init(c);
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const u32 j = (u32)(i * T) + threadIdx.x;
-    const u32 wa = lds_word_a(j);
-    u64 x[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k) x[k] = op_lds[k * LDS_WORDS + wa];
-#pragma unroll
-    for (int s = S1 - 1; s >= 1; --s) {
-      const int hh = R >> (s + 1);
-#pragma unroll
-      for (int g = 0; g < (1 << s); ++g) {
-        const tw2 w = tw[(1 << s) + g];
-#pragma unroll
-        for (int e = 0; e < hh; ++e) p.inv(x[g * 2 * hh + e], x[g * 2 * hh + e + hh], w);
-      }
     }
-    constexpr int hh = R >> 1;
-    if (scale) {
-      const tw2 wl = lastw[limb];
+    __syncthreads();
+    const size_t obase = ((size_t)poly * Lso + limb) << logN;
+    const tw2* tw = twn + ((size_t)limb << logN);
+    const LimbConsts c = consts[limb];
+    ShoupPolicy p; p.init(c);
 #pragma unroll
-      for (int e = 0; e < hh; ++e) {
-        const u64 U = x[e], V = x[e + hh];
-        const u64 d = U + p.q4 - V;
-        x[e] = canon4(shoup_mul(U + V, c.ninv_w, c.ninv_wp, c.nq), c.q);
-        x[e + hh] = canon4(shoup_mul(d, wl.w, wl.wp, c.nq), c.q);
+    for (int i = 0; i < PER; ++i) {
+      const u32 j = (u32)(i * T) + threadIdx.x;
+      const u32 wa = lds_word_a(j);
+      u64 x[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) x[k] = op_lds[k * LDS_WORDS + wa];
+#pragma unroll
+      for (int s = S1 - 1; s >= 1; --s) {
+        const int hh = R >> (s + 1);
+#pragma unroll
+        for (int g = 0; g < (1 << s); ++g) {
+          const tw2 w = tw[(1 << s) + g];
+#pragma unroll
+          for (int e = 0; e < hh; ++e) p.inv(x[g * 2 * hh + e], x[g * 2 * hh + e + hh], w);
+        }
       }
-    } else {
-      const tw2 w1 = tw[1];
+      constexpr int hh = R >> 1;
+      if (scale) {
+        const tw2 wl = lastw[limb];
 #pragma unroll
-      for (int e = 0; e < hh; ++e) p.inv(x[e], x[e + hh], w1);
-    }
+        for (int e = 0; e < hh; ++e) {
+          const u64 U = x[e], V = x[e + hh];
+          const u64 d = U + p.q4 - V;
+          x[e] = canon4(shoup_mul(U + V, c.ninv_w, c.ninv_wp, c.nq), c.q);
+          x[e + hh] = canon4(shoup_mul(d, wl.w, wl.wp, c.nq), c.q);
+        }
+      } else {
+        const tw2 w1 = tw[1];
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-      u64* dst = out + obase + ((size_t)k << LT) + j;
-      if (NT) __builtin_nontemporal_store(x[k], dst); else *dst = x[k];
+        for (int e = 0; e < hh; ++e) p.inv(x[e], x[e + hh], w1);
+      }
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        u64* dst = out + obase + ((size_t)k << LT) + j;
+        if (NT) __builtin_nontemporal_store(x[k], dst); else *dst = x[k];
+      }
     }
   }
 }

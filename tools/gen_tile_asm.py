@@ -1173,7 +1173,7 @@ for _suffix, _flags in (("", ""), ("_NT", " nt")):
     gen_polymul()
     polymul = list(out)
     del out[:]
-    gen(lds_in=True)
+    gen(lds_in=True, tail_wait=False)                     # (the persistent one-pass kernel goes on to its next row while these stores drain)
     fwd_ldsin = list(out)
     del out[:]
     gen_inverse(lds_out=True)
