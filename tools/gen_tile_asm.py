@@ -20,6 +20,7 @@ import os
 import sys
 
 EXP = int(os.environ.get("RH_ASM_EXP", "0"))     # TIMING EXPERIMENTS ONLY (wrong results): 1 no LDS exchanges, 2 no round-B/C twiddle loads, 4 no final reduction, 8 no barriers, 16 no round C
+NOTAIL = int(os.environ.get("RH_ASM_NOTAIL", "0"))   # A/B: forward tile bodies end with their stores in flight (no trailing s_waitcnt vmcnt(0))
 PRIO = int(os.environ.get("RH_ASM_PRIO", "0"))   # s_setprio around the load-issue and store phases (0 = off, for A/B runs)
 out = []
 
@@ -520,7 +521,7 @@ def gen(load_flags="", store_flags="", preloaded=False, tail_wait=True, epilogue
         j, rem = divmod(k, 4)
         emit("s_waitcnt lgkmcnt(%d)" % (15 - k))
         emit("global_store_dwordx2 v%d, %s, %%[pout] offset:%d%s" % (SCR + j, pair(X(k)), rem * 2048 - 4096, store_flags))
-    if tail_wait:
+    if tail_wait and not NOTAIL:
         emit("s_waitcnt vmcnt(0)")
 
 
