@@ -433,7 +433,12 @@ static int std_ntt_launch_span(rh_ring* r, const u64* in, u64* out, int npoly, i
   } else {
     if (phase != 1) {
       // the hand-scheduled body leaves values < 4q unscaled: right whenever column stages follow, and for N = 4096
-      // sub-rings of the 3N transform (inv_scale = false), which scale in their own last layer
+      // sub-rings of the 3N transform (inv_scale = false), which scale in their own last layer; N = 4096 WITH scaling: the same body, then N^-1 out of LDS
+      if (r->asm_tile && S1 == 0 && r->inv_scale && r->one_pass && phase == 0) {
+        if (nt) ntt_inv_onepass_asm<0, true><<<rows, 256, (size_t)LDS_WORDS * 8, st>>>(in, out, r->d_twk_inv + toff, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Ls, Lso, 1);
+        else ntt_inv_onepass_asm<0, false><<<rows, 256, (size_t)LDS_WORDS * 8, st>>>(in, out, r->d_twk_inv + toff, r->d_tw_inv + toff, r->d_lastw + limb0, c, Lrows, Ls, Lso, 1);
+        return check_launch("ntt (N = 4096, inverse)");
+      }
       if (r->asm_tile && (S1 > 0 || !r->inv_scale) && nt) ntt_inv_tile_asm<true><<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly, Ls, Lso);
       else if (r->asm_tile && (S1 > 0 || !r->inv_scale)) ntt_inv_tile_asm<false><<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, npoly, Ls, Lso);
       else ntt_inv_tile<<<tiles, 256, 0, st>>>(in, out, r->d_twk_inv + toff, c, Lrows, logN, (S1 == 0 && r->inv_scale) ? 1 : 0, npoly, Ls, Lso);

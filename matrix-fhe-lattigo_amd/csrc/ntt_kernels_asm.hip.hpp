@@ -493,7 +493,7 @@ ci_col0_kernel(const u64* in, u64* out, const tw2* __restrict__ twn, const tw2* 
 // layout A (word t + (t >> 4) + 272 k of a tile holds its coefficient t + 256 k); then each group of 256 threads runs the hand-scheduled tile body
 // on its own tile, reading its first round from LDS (tools/gen_tile_asm.py: gen(lds_in=True)) -- every thread overwrites only the slots it read,
 // so one __syncthreads separates the two phases.  The body's s_barriers span the whole workgroup; every group executes the same number.
-// Inverse: mirror image (gen_inverse(lds_out=True)).  Occupancy as for the tile kernels: 4 waves per SIMD (<= 128 VGPRs), 136 KiB of LDS per CU.
+// Inverse: mirror image (gen_inverse(lds_out=True)); S1 = 0 (N = 4096) is the hand-scheduled inverse body followed by the N^-1 scaling out of LDS.  Occupancy as for the tile kernels: 4 waves per SIMD (<= 128 VGPRs), 136 KiB of LDS per CU.
 // Contract: ring/ntt.go:209-552 + reducevec / :554-714 + NInv, outputs canonical -- identical to the two-pass launches (tests: every N = 2^13 / 2^14 case).
 // ---------------------------------------------------------------------------------------------------------------
 RH_DEV u32 lds_word_a(u32 j) { const u32 t = j & 255u; return t + (t >> 4) + 272u * (j >> 8); }
@@ -610,7 +610,9 @@ ntt_inv_onepass_asm(const u64* in, u64* out, const tw2* __restrict__ twk, const 
         }
       }
       constexpr int hh = R >> 1;
-      if (scale) {
+      if constexpr (S1 == 0) {        // N = 4096: the body ran ALL twelve stages; what is left is N^-1 and the canonical reduction (scale = 1 only)
+        x[0] = canon4(shoup_mul(x[0], c.ninv_w, c.ninv_wp, c.nq), c.q);
+      } else if (scale) {
         const tw2 wl = lastw[limb];
 #pragma unroll
         for (int e = 0; e < hh; ++e) {
