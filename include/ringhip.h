@@ -182,6 +182,8 @@ int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int
  *   auto_span_rows  span size of the auto rule in (poly, limb) rows (2048)
  *   asm_tile / asm_cols   1: generated hand-scheduled bodies (default), 0: the C++ kernels
  *   fuse_submul     1: ModDown / rescale subtract-multiply in the forward tile kernel's epilogue (default)
+ *   one_pass        1: N = 2^13 / 2^14 (and the inverse at N = 4096) keep the whole limb row in one workgroup's LDS between the column and the tile
+ *                   stages: one HBM pass per transform instead of two (default); 0: the two-pass launches
  *   fuse_ci         1: conjugate-invariant rings fold inside the column stages instead of in a pass of their own (default; N = 2^14..2^16)
  *   digit_pipeline  1: key switch transforms all digit blocks with one software-pipelined stream of launches (default; N = 2^14..2^16)
  *   fuse3n          1: 3N rings, split + radix-3 layer fused with the sub-transforms' column stages (default)
