@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Single-ciphertext latency (the way the reference's callers issue work: one ct per call) at the config 5 ring, N = 2^16, Q = 24, P = 6 limbs:
+the hybrid key switch (rlwe.Evaluator.GadgetProduct) and a few ring calls behind it, issued (a) call by call and (b) as ONE HIP graph
+replay captured by the caller on the stream handed to rh_ring_set_stream.  JSON on stdout -> profiles/r03_latency_batch1.json"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import matrix_fhe_lattigo_amd as rh
+from bench import QI60, PI60
+
+dev = torch.device("cuda", 0)
+N, Q, P = 1 << 16, QI60[:24], PI60[:6]
+res = {"what": "wall-clock per call, one ciphertext component per call, N=2^16 Q=24 P=6 (beta=4); eager = call by call, graph = one hipGraph replay", "rows": []}
+
+
+def uniform(shape, mods):
+    t = torch.randint(0, 1 << 62, shape, dtype=torch.int64, device=dev)
+    return t % torch.tensor(mods, dtype=torch.int64, device=dev).view(*([1] * (len(shape) - 2)), len(mods), 1)
+
+
+for B in (1, 2, 4):
+    rq, rp = rh.Ring(N, Q), rh.Ring(N, P)
+    be = rh.BasisExtender(rq, rp)
+    beta = (len(Q) - 1 + len(P)) // len(P)
+    cx = uniform((B, len(Q), N), Q)
+    kq, kp = uniform((beta * 2, len(Q), N), Q), uniform((beta * 2, len(P), N), P)
+    c0, c1 = torch.zeros_like(cx), torch.zeros_like(cx)
+    pcx, p0, p1 = (rh.DevicePoly.from_torch(rq, t) for t in (cx, c0, c1))
+    side = torch.cuda.Stream()
+
+    def work():
+        be.GadgetProduct(len(Q) - 1, len(P) - 1, pcx, kq.data_ptr(), kp.data_ptr(), beta, p0, p1)
+
+    with torch.cuda.stream(side):
+        rq.set_stream(side.cuda_stream); rp.set_stream(side.cuda_stream)
+        for _ in range(3):
+            work()
+        side.synchronize()
+        ref = (c0.clone(), c1.clone())
+        reps = 200
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            work()
+        side.synchronize()
+        eager = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(50):
+            work(); side.synchronize()
+        eager_sync = (time.perf_counter() - t0) / 50
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            work()
+        c0.zero_(); c1.zero_()
+        g.replay(); side.synchronize()
+        same = torch.equal(c0, ref[0]) and torch.equal(c1, ref[1])
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.replay()
+        side.synchronize()
+        graph = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(50):
+            g.replay(); side.synchronize()
+        graph_sync = (time.perf_counter() - t0) / 50
+    row = {"op": "GadgetProduct", "polys": B, "eager_us_back_to_back": eager * 1e6, "eager_us_with_sync": eager_sync * 1e6,
+           "graph_us_back_to_back": graph * 1e6, "graph_us_with_sync": graph_sync * 1e6, "graph_equals_eager": bool(same)}
+    res["rows"].append(row)
+    sys.stderr.write(json.dumps(row) + "\n")
+    del g
+    be.close(); rq.close(); rp.close()
+print(json.dumps(res, indent=1))
