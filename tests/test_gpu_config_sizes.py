@@ -181,13 +181,15 @@ def test_headline_launch_shape_vs_oracle(rh, oracle):
     ring.close()
 
 
-def test_config4_ring_all_24_limbs(rh, oracle):
-    """config 4: 3N ring N = 3*2^16 with all 24 moduli, batch 2: forward / inverse transform on 3 spot limbs vs the oracle's
+@pytest.mark.parametrize("N", [3 << 16, 3 << 14], ids=["N=3*2^16", "N=3*2^14"])
+def test_config4_ring_all_24_limbs(rh, oracle, N):
+    """config 4: 3N ring with all 24 moduli at BOTH readings of its "logN = 16" (SURVEY 8(d): logN := Order2 gives N = 3*2^16, the headline;
+    N = 3*2^14 = 49152 is the other), batch 2: forward / inverse transform on 3 spot limbs vs the oracle's
     fast restatement (itself pinned to integer_dft.py fixtures and the Horner definition in tests/test_oracle_ntt3n.py),
     round trip on every limb, and matrix_ckks.Evaluator.Mul (degree 1 x degree 1) vs the oracle call sequence
     (schemes/matrix_ckks/evaluator.go:114-192) on the same limbs.  Mul end-to-end stays parity-unpinned by the reference."""
     from test_gpu_schemes import primes_3n, omega_for
-    N, L, B = 3 << 16, 24, 2
+    L, B = 24, 2
     mods = primes_3n(oracle, N, L)
     om = [omega_for(q, N) for q in mods]
     ring = rh.Ring(N, mods, kind=rh.Matrix3N, omega3n=om)

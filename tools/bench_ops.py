@@ -162,7 +162,7 @@ be.close(); rq.close(); rp.close(); torch.cuda.empty_cache()
 # ---- config 2 / 4 rings: 3N transform ----
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from primes3n import moduli_3n
-for N, L, B in ((3 << 13, 1, 1024), (3 << 16, 24, 16)):
+for N, L, B in ((3 << 13, 1, 1024), (3 << 16, 24, 16), (3 << 14, 24, 64)):       # config 2; config 4 at both readings of its "logN = 16" (SURVEY 8(d)), the same bytes per batch
     mods = moduli_3n(N, L)
     ring = rh.Ring(N, mods, kind=rh.Matrix3N); ring.set_stream(stream.cuda_stream)
     x = rand_block(B, mods, N)
