@@ -182,6 +182,8 @@ struct rh_bext {
   rh_ring* Q = nullptr; rh_ring* P = nullptr;
   std::map<std::array<int, 5>, BextPlan> plans;
   u64* buf[9] = {}; size_t buf_words[9] = {};      // 0,1: ModDownNTT buffers; 2..8: gadget product (keyswitch.hip)
+  // small batches (keyswitch.hip: a few polys leave most of the chip idle): independent pieces of one key switch run side by side on these
+  hipStream_t side[RH_BEXT_SIDE] = {}; hipEvent_t ev_fork = nullptr; hipEvent_t ev_join[RH_BEXT_SIDE] = {}; bool side_ready = false;
   std::recursive_mutex mu;
 };
 
@@ -250,6 +252,8 @@ extern "C" void rh_bext_destroy(rh_bext* be) {
     for (void* q : ptrs) if (q) (void)hipFree(q);
   }
   for (int i = 0; i < 9; ++i) if (be->buf[i]) (void)hipFree(be->buf[i]);
+  for (int k = 0; k < RH_BEXT_SIDE; ++k) { if (be->side[k]) (void)hipStreamDestroy(be->side[k]); if (be->ev_join[k]) (void)hipEventDestroy(be->ev_join[k]); }
+  if (be->ev_fork) (void)hipEventDestroy(be->ev_fork);
   delete be;
 }
 
@@ -272,6 +276,19 @@ extern "C" int rh_bext_reserve(rh_bext* be, int npoly) {
   const size_t beta = be->P ? (size_t)(be->Q->L + be->P->L - 1) / be->P->L : 1;
   const size_t need[9] = {2 * wq, 2 * wp, wq, beta * wq, beta * wp, 2 * wp, 0, wq, wq};
   for (int i = 0; i < 9; ++i) if (need[i]) if (int rc = ensure_buf(be, i, need[i])) return rc;
+  return RH_OK;
+}
+// side streams + fork / join events of the small-batch paths, created on first use (not inside a stream capture: warm the handle up first)
+int rh_bext_side_streams(rh_bext* be, hipStream_t** side, hipEvent_t* fork, hipEvent_t** join) {
+  if (!be->side_ready) {
+    (void)hipSetDevice(be->Q->device);
+    bool ok = hipEventCreateWithFlags(&be->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < RH_BEXT_SIDE && ok; ++k)
+      ok = hipStreamCreateWithFlags(&be->side[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&be->ev_join[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); return rh_fail(RH_ERR_NOMEM, "basis extender: side stream / event creation failed"); }
+    be->side_ready = true;
+  }
+  *side = be->side; *fork = be->ev_fork; *join = be->ev_join;
   return RH_OK;
 }
 rh_ring* rh_bext_ringQ(rh_bext* be) { return be->Q; }

@@ -15,6 +15,8 @@ struct BextTarget {
 };
 
 enum { BEXT_ADD_NONE = 0, BEXT_ADD_CRED = 1, BEXT_ADD_RAW = 2 };
+#define RH_BEXT_SIDE 4                                  // side streams of a basis extender (small-batch key switch: digits side by side)
+int rh_bext_side_streams(rh_bext* be, hipStream_t** side, hipEvent_t* fork, hipEvent_t** join);
 
 struct SignTarget { u64 p, bred0; int buf, limb; };
 struct BextPlan {

@@ -1101,6 +1101,7 @@ extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
     return RH_OK;
   }
   if (!strcmp(key, "asm_cols")) { r->asm_cols = (int)value; return RH_OK; }
+  if (!strcmp(key, "ks_small_rows")) { if (value < 0) return rh_fail(RH_ERR_ARG, "ks_small_rows must be >= 0"); r->ks_small_rows = (int)value; return RH_OK; }
   if (!strcmp(key, "one_pass")) { r->one_pass = value != 0; return RH_OK; }
   if (!strcmp(key, "nt_streams")) { r->nt_streams = value != 0; if (r->kind == RH_RING_3N) rh_ring3n_set_nt_streams(r, value != 0); return RH_OK; }     // 0: default cache policy everywhere (A/B runs: bench.py --tune nt_streams=0)
   return rh_fail(RH_ERR_ARG, "set_tuning: unknown key %s", key);

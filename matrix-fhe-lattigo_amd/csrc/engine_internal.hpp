@@ -57,6 +57,8 @@ struct rh_ring {
   bool asm_tile = true;           // forward tile kernel: hand-scheduled body (ntt_kernels_asm.hip.hpp) vs the C++ one
   bool inv_scale = true;          // false: inverse leaves values < 4q without the N^-1 factor (3N sub-transform)
   int auto_span_rows = 2048;      // chunk_polys = -1: span size of the fused pipeline in (poly, limb) rows
+  int ks_small_rows = 0;          // key switch (keyswitch.hip): blocks of at most this many (poly, limb) rows run their digits side by side on side streams (0: never, the default:
+                                  // it pays under a graph replay, -14 % at one ciphertext, and costs 5 % call by call, where the extra launches are host-bound)
   bool one_pass = true;           // N = 2^13 / 2^14: whole limb row in one workgroup's LDS (ntt_fwd_onepass_asm / ntt_inv_onepass_asm); false: the two-pass launches
   bool one_pass_ready = false;    // ... their dynamic-LDS limit has been raised on this ring's device
   bool nt_streams = true;         // non-temporal data streams for launches beyond the Infinity Cache (the generated _NT bodies); false: default policy everywhere

@@ -166,6 +166,9 @@ static int decompose_single_ntt(rh_bext* be, int levelQ, int levelP, int i, cons
   return rh_ring_ntt_any(RP, c2P, c2P, npoly, LP, 0, false);
 }
 
+// small batch: rows of one block (polys x limbs) at or below the ring's tuning value ks_small_rows (0: never)
+static bool ks_small(const rh_ring* RQ, int npoly, int LQ) { return RQ->ks_small_rows > 0 && (long)npoly * LQ <= RQ->ks_small_rows; }
+
 // DecomposeSingleNTT for every digit: the basis extensions digit by digit, then ONE pipelined transform of all the Q blocks
 // (rh_std_ntt_fwd_digits) and one of all the P blocks (contiguous: beta * npoly polys of LP limbs).
 static int decompose_all_ntt(rh_bext* be, int levelQ, int levelP, int beta, const u64* cx, const u64* cxInv, u64* decQ, u64* decP, int npoly,
@@ -177,6 +180,26 @@ static int decompose_all_ntt(rh_bext* be, int levelQ, int levelP, int beta, cons
     for (int i = 0; i < beta; ++i)
       if (int rc = decompose_single_ntt(be, levelQ, levelP, i, cx, cxInv, decQ + (size_t)i * wq, decP + (size_t)i * wp, npoly, copy_digit)) return rc;
     return RH_OK;
+  }
+  if (ks_small(RQ, npoly, LQ) && beta > 1) {
+    // a few polys (one ciphertext per call, the way the reference's callers issue work): a digit's launches fill a quarter of the chip and the
+    // pipelined stream below is a chain of ~10 dependent launches -- run the digits' chains (extension, transforms) SIDE BY SIDE on side streams
+    // forked from / joined into the caller's stream (capturable; same bits: every block is canonical here, the lazy pipeline's are congruent)
+    hipStream_t* side; hipEvent_t fork; hipEvent_t* join;
+    if (int rc = rh_bext_side_streams(be, &side, &fork, &join)) return rc;
+    hipStream_t main = rh_stream(RQ);
+    if (hipEventRecord(fork, main) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_product: fork failed");
+    int rc = RH_OK;
+    const int ns = beta < RH_BEXT_SIDE ? beta : RH_BEXT_SIDE;
+    for (int k = 0; k < ns && !rc; ++k) if (hipStreamWaitEvent(side[k], fork, 0) != hipSuccess) rc = rh_fail(RH_ERR_DEVICE, "gadget_product: fork failed");
+    for (int i = 0; i < beta && !rc; ++i) {
+      RhCallScope scope(side[i % ns]);
+      rc = decompose_single_ntt(be, levelQ, levelP, i, cx, cxInv, decQ + (size_t)i * wq, decP + (size_t)i * wp, npoly, copy_digit);
+    }
+    for (int k = 0; k < ns; ++k)                         // join even after an error: nothing may stay forked
+      if ((hipEventRecord(join[k], side[k]) != hipSuccess || hipStreamWaitEvent(main, join[k], 0) != hipSuccess) && !rc)
+        rc = rh_fail(RH_ERR_DEVICE, "gadget_product: join failed");
+    return rc;
   }
   for (int i = 0; i < beta; ++i)
     if (int rc = rh_bext_decompose_and_split(be, levelQ, levelP, LP, i, cxInv, decQ + (size_t)i * wq, decP + (size_t)i * wp, npoly)) return rc;
@@ -254,8 +277,20 @@ static int hoisted_tail(rh_bext* be, int levelQ, int levelP, const uint64_t* dec
   aP1 = aP0 + wp;
   const size_t evq_stride = (size_t)RQ->L * N, evp_stride = (size_t)RP->L * N;
   ReduceSchedule rs(RQ, levelQ, RP, levelP);
-  if (int rc = mac_all(RQ, decompQ, wq, evkQ, beta, rs.QiOverF, ct0, ct1, npoly, LQ, cx, LP)) return rc;
-  if (int rc = mac_all(RP, decompP, wp, evkP, beta, rs.PiOverF, aP0, aP1, npoly, LP)) return rc;
+  if (ks_small(RQ, npoly, LQ)) {                     // small batch: the P rows' multiply-accumulate beside the Q rows' (side stream 0)
+    hipStream_t* side; hipEvent_t fork; hipEvent_t* join;
+    if (int rc = rh_bext_side_streams(be, &side, &fork, &join)) return rc;
+    hipStream_t main = rh_stream(RQ);
+    if (hipEventRecord(fork, main) != hipSuccess || hipStreamWaitEvent(side[0], fork, 0) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_product: fork failed");
+    int rc;
+    { RhCallScope scope(side[0]); rc = mac_all(RP, decompP, wp, evkP, beta, rs.PiOverF, aP0, aP1, npoly, LP); }
+    if (!rc) rc = mac_all(RQ, decompQ, wq, evkQ, beta, rs.QiOverF, ct0, ct1, npoly, LQ, cx, LP);
+    if ((hipEventRecord(join[0], side[0]) != hipSuccess || hipStreamWaitEvent(main, join[0], 0) != hipSuccess) && !rc) rc = rh_fail(RH_ERR_DEVICE, "gadget_product: join failed");
+    if (rc) return rc;
+  } else {
+    if (int rc = mac_all(RQ, decompQ, wq, evkQ, beta, rs.QiOverF, ct0, ct1, npoly, LQ, cx, LP)) return rc;
+    if (int rc = mac_all(RP, decompP, wp, evkP, beta, rs.PiOverF, aP0, aP1, npoly, LP)) return rc;
+  }
   if (out_ntt) return rh_bext_moddown_ntt_pair(be, levelQ, levelP, ct0, ct1, aP0, out0, out1, npoly, add0, add1);
   // coefficient-domain ciphertext (:114-118, then ModDown INTT -> INTT :62-66): ringQP.INTT on both components, ModDownQPtoQ
   if (add0 || add1) return rh_fail(RH_ERR_UNSUPPORTED, "gadget product: the fused Add exists for NTT-domain ciphertexts only");

@@ -19,8 +19,12 @@ def uniform(shape, mods):
     return t % torch.tensor(mods, dtype=torch.int64, device=dev).view(*([1] * (len(shape) - 2)), len(mods), 1)
 
 
-for B in (1, 2, 4):
+tunes = [a.split("=") for a in sys.argv[1:] if "=" in a]           # e.g. ks_small_rows=0: the pipelined digit stream at every batch size
+res["tuning"] = dict(tunes)
+for B in (1, 2, 4, 8):
     rq, rp = rh.Ring(N, Q), rh.Ring(N, P)
+    for k, v in tunes:
+        rq.set_tuning(k, int(v)); rp.set_tuning(k, int(v))
     be = rh.BasisExtender(rq, rp)
     beta = (len(Q) - 1 + len(P)) // len(P)
     cx = uniform((B, len(Q), N), Q)
