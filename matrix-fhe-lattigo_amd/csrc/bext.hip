@@ -29,10 +29,9 @@ RH_DEV void mac_carry(u64& acc, u32& cnt, u32 a, u32 b) {
 // NS: compile-time bound on the source-limb count (y_i live in registers, loops fully unrolled); EXACT: nsrc == NS.
 // NS == 0: generic fallback with the y_i in dynamic LDS ([limb][thread]).
 template <int NS, bool EXACT>
-__global__ void __launch_bounds__(256)
-bext_kernel(const u64* in, int in_rows, int src_limb0, int nsrc, const BextSource* __restrict__ S,
-            int ntgt_c, int ntgt, const BextTarget* __restrict__ T, const u64* __restrict__ coef, const u64* __restrict__ vt,
-            u64* out0, int out0_rows, u64* out1, int out1_rows, const u64* other, int other_rows, int N, int add_mode, int post) {
+RH_DEV void bext_body(const u64* in, int in_rows, int src_limb0, int nsrc, const BextSource* __restrict__ S,
+                      int ntgt_c, int ntgt, const BextTarget* __restrict__ T, const u64* __restrict__ coef, const u64* __restrict__ vt,
+                      u64* out0, int out0_rows, u64* out1, int out1_rows, const u64* other, int other_rows, int N, int add_mode, int post) {
   // targets [0, ntgt_c) are extended (all with the plan-uniform post step `post`); [ntgt_c, ntgt) are the digit limbs of
   // DecomposeAndSplit: no extension, the centred subtraction applies to what the output already holds
   // dynamic LDS: [ntgt_c * (nsrc + 1)] the vt table (-v*Q mod p for every target and v), then [nsrc][256] the y_i (NS == 0 only).
@@ -136,6 +135,27 @@ bext_kernel(const u64* in, int in_rows, int src_limb0, int nsrc, const BextSourc
   }
 }
 
+template <int NS, bool EXACT>
+__global__ void __launch_bounds__(256)
+bext_kernel(const u64* in, int in_rows, int src_limb0, int nsrc, const BextSource* __restrict__ S,
+            int ntgt_c, int ntgt, const BextTarget* __restrict__ T, const u64* __restrict__ coef, const u64* __restrict__ vt,
+            u64* out0, int out0_rows, u64* out1, int out1_rows, const u64* other, int other_rows, int N, int add_mode, int post) {
+  bext_body<NS, EXACT>(in, in_rows, src_limb0, nsrc, S, ntgt_c, ntgt, T, coef, vt, out0, out0_rows, out1, out1_rows, other, other_rows, N, add_mode, post);
+}
+// Several plans over the same input in ONE launch (blockIdx.z = the plan): every digit of a hybrid key-switch decomposition at once, for batches
+// too small to fill the chip digit by digit (rh_bext_decompose_and_split_all).  Output blocks of plan z: out0 + z * stride0, out1 + z * stride1.
+struct BextMulti {
+  const BextSource* S[8]; const BextTarget* T[8]; const u64* coef[8]; const u64* vt[8];
+  int src_limb0[8], nsrc[8], ntgt_c[8], ntgt[8];
+};
+__global__ void __launch_bounds__(256)
+bext_multi_kernel(const u64* in, int in_rows, BextMulti m, u64* out0, size_t stride0, int out0_rows, u64* out1, size_t stride1, int out1_rows,
+                  int N, int add_mode, int post) {
+  const int z = blockIdx.z;
+  bext_body<8, false>(in, in_rows, m.src_limb0[z], m.nsrc[z], m.S[z], m.ntgt_c[z], m.ntgt[z], m.T[z], m.coef[z], m.vt[z],
+                      out0 + (size_t)z * stride0, out0_rows, out1 + (size_t)z * stride1, out1_rows, nullptr, 0, N, add_mode, post);
+}
+
 #define RH_BEXT_ARGS in, in_rows, src_limb0, p.nsrc, p.d_S, p.ntgt_c, p.ntgt, p.d_T, p.d_coef, p.d_vt, out0, out0_rows, out1, out1_rows, other, other_rows, N, add_mode, p.post
 static void bext_dispatch(dim3 grid, hipStream_t st, const BextPlan& p, const u64* in, int in_rows, int src_limb0, u64* out0, int out0_rows,
                           u64* out1, int out1_rows, const u64* other, int other_rows, int N, int add_mode) {
@@ -182,8 +202,6 @@ struct rh_bext {
   rh_ring* Q = nullptr; rh_ring* P = nullptr;
   std::map<std::array<int, 5>, BextPlan> plans;
   u64* buf[9] = {}; size_t buf_words[9] = {};      // 0,1: ModDownNTT buffers; 2..8: gadget product (keyswitch.hip)
-  // small batches (keyswitch.hip: a few polys leave most of the chip idle): independent pieces of one key switch run side by side on these
-  hipStream_t side[RH_BEXT_SIDE] = {}; hipEvent_t ev_fork = nullptr; hipEvent_t ev_join[RH_BEXT_SIDE] = {}; bool side_ready = false;
   std::recursive_mutex mu;
 };
 
@@ -252,8 +270,6 @@ extern "C" void rh_bext_destroy(rh_bext* be) {
     for (void* q : ptrs) if (q) (void)hipFree(q);
   }
   for (int i = 0; i < 9; ++i) if (be->buf[i]) (void)hipFree(be->buf[i]);
-  for (int k = 0; k < RH_BEXT_SIDE; ++k) { if (be->side[k]) (void)hipStreamDestroy(be->side[k]); if (be->ev_join[k]) (void)hipEventDestroy(be->ev_join[k]); }
-  if (be->ev_fork) (void)hipEventDestroy(be->ev_fork);
   delete be;
 }
 
@@ -276,19 +292,6 @@ extern "C" int rh_bext_reserve(rh_bext* be, int npoly) {
   const size_t beta = be->P ? (size_t)(be->Q->L + be->P->L - 1) / be->P->L : 1;
   const size_t need[9] = {2 * wq, 2 * wp, wq, beta * wq, beta * wp, 2 * wp, 0, wq, wq};
   for (int i = 0; i < 9; ++i) if (need[i]) if (int rc = ensure_buf(be, i, need[i])) return rc;
-  return RH_OK;
-}
-// side streams + fork / join events of the small-batch paths, created on first use (not inside a stream capture: warm the handle up first)
-int rh_bext_side_streams(rh_bext* be, hipStream_t** side, hipEvent_t* fork, hipEvent_t** join) {
-  if (!be->side_ready) {
-    (void)hipSetDevice(be->Q->device);
-    bool ok = hipEventCreateWithFlags(&be->ev_fork, hipEventDisableTiming) == hipSuccess;
-    for (int k = 0; k < RH_BEXT_SIDE && ok; ++k)
-      ok = hipStreamCreateWithFlags(&be->side[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&be->ev_join[k], hipEventDisableTiming) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); return rh_fail(RH_ERR_NOMEM, "basis extender: side stream / event creation failed"); }
-    be->side_ready = true;
-  }
-  *side = be->side; *fork = be->ev_fork; *join = be->ev_join;
   return RH_OK;
 }
 rh_ring* rh_bext_ringQ(rh_bext* be) { return be->Q; }
@@ -500,6 +503,38 @@ extern "C" int rh_bext_decompose_and_split(rh_bext* be, int levelQ, int levelP, 
     return RH_OK;
   }
   return launch_plan(be, p, p0Q, levelQ + 1, st, p1Q, levelQ + 1, p1P, nP, nullptr, 0, npoly, BEXT_ADD_RAW);
+}
+
+// DecomposeAndSplit for digits 0 .. beta-1 in ONE launch (small batches; keyswitch.hip).  Returns 1 (and launches nothing) when a digit is not a
+// register-resident multi-prime plan (single-prime digits, more than 8 source limbs, more than 8 digits): the caller goes digit by digit.
+int rh_bext_decompose_and_split_all(rh_bext* be, int levelQ, int levelP, int nbPi, int beta, const u64* p0Q, u64* p1Q, size_t strideQ,
+                                    u64* p1P, size_t strideP, int npoly) {
+  if (beta < 1 || beta > 8 || !be->P) return 1;
+  RhBextGuard guard(be);
+  BextMulti m; memset(&m, 0, sizeof m);
+  int post = -1; size_t vt_bytes = 0;
+  for (int d = 0; d < beta; ++d) {
+    const int decompLvl = (levelQ > nbPi * (d + 1) - 1) ? nbPi - 2 : (levelQ % nbPi) - 1;
+    if (decompLvl < 0) return 1;
+    if (int rc = rh_bext_decompose_and_split(be, levelQ, levelP, nbPi, d, p0Q, p1Q, p1P, 0)) return rc;      // builds the plan, launches nothing
+    auto it = be->plans.find(std::array<int, 5>{2, levelQ, levelP, nbPi, d});
+    if (it == be->plans.end()) return 1;
+    const BextPlan& p = it->second;
+    if (p.nsrc > 8 || p.ntgt == 0 || (post >= 0 && p.post != post)) return 1;
+    post = p.post;
+    m.S[d] = p.d_S; m.T[d] = p.d_T; m.coef[d] = p.d_coef; m.vt[d] = p.d_vt;
+    m.src_limb0[d] = d * nbPi; m.nsrc[d] = p.nsrc; m.ntgt_c[d] = p.ntgt_c; m.ntgt[d] = p.ntgt;
+    const size_t vb = (size_t)p.ntgt_c * (p.nsrc + 1) * 8;
+    if (vb > vt_bytes) vt_bytes = vb;
+  }
+  if (npoly <= 0) return RH_OK;
+  rh_ring* RQ = be->Q;
+  (void)hipGetLastError();
+  bext_multi_kernel<<<dim3((RQ->N + 255) / 256, npoly, beta), 256, vt_bytes, rh_stream(RQ)>>>(p0Q, levelQ + 1, m, p1Q, strideQ, levelQ + 1, p1P, strideP, levelP + 1,
+                                                                                             RQ->N, BEXT_ADD_RAW, post);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "bext_multi_kernel launch failed: %s", hipGetErrorString(e));
+  return RH_OK;
 }
 
 // ---- internals shared with kshard.hip (bext_internal.hpp) ----

@@ -15,8 +15,8 @@ struct BextTarget {
 };
 
 enum { BEXT_ADD_NONE = 0, BEXT_ADD_CRED = 1, BEXT_ADD_RAW = 2 };
-#define RH_BEXT_SIDE 4                                  // side streams of a basis extender (small-batch key switch: digits side by side)
-int rh_bext_side_streams(rh_bext* be, hipStream_t** side, hipEvent_t* fork, hipEvent_t** join);
+int rh_bext_decompose_and_split_all(rh_bext* be, int levelQ, int levelP, int nbPi, int beta, const u64* p0Q, u64* p1Q, size_t strideQ,
+                                    u64* p1P, size_t strideP, int npoly);      // 0 done, 1 not applicable (go digit by digit), < 0 error
 
 struct SignTarget { u64 p, bred0; int buf, limb; };
 struct BextPlan {

@@ -578,7 +578,7 @@ bool rh_can_ntt_digits(const rh_ring* r) {
   return r->kind == RH_RING_STANDARD && r->asm_tile && r->asm_cols && r->digit_pipeline && S1 >= 2 && S1 <= 4;
 }
 int rh_std_ntt_fwd_blocks(rh_ring* r, u64* data, size_t block_stride, int npoly, int nblocks, int Ls, const int* gap0, const int* gap_len,
-                          bool lazy_out) {                  // block j: npoly polys of Ls rows, rows [gap0[j], gap0[j] + gap_len[j]) left alone
+                          bool lazy_out, int small) {       // small: 1 / 0 = every block in one launch pair / the pipelined stream; -1 = by the ring's ks_small_rows                  // block j: npoly polys of Ls rows, rows [gap0[j], gap0[j] + gap_len[j]) left alone
   if (!rh_can_ntt_digits(r)) return rh_fail(RH_ERR_UNSUPPORTED, "digit-block transform needs the hand-scheduled bodies (2^14 <= N <= 2^16)");
   if (npoly <= 0 || nblocks <= 0) return RH_OK;
   (void)hipGetLastError();
@@ -588,6 +588,25 @@ int rh_std_ntt_fwd_blocks(rh_ring* r, u64* data, size_t block_stride, int npoly,
     GapRows g; g.Ls = Ls; g.gap0 = (u32)gap0[j]; g.gap_len = (u32)gap_len[j]; g.L = Ls - gap_len[j];
     return g;
   };
+  if (small < 0) small = r->ks_small_rows > 0 && (long)npoly * Ls <= r->ks_small_rows;
+  if (small && nblocks <= 8) {     // small batch: every block in ONE launch pair (blockIdx.y = block)
+    GapBlocks gb; gb.Ls = Ls;
+    unsigned n1 = 0, n2 = 0;
+    for (int j = 0; j < 8; ++j) {
+      const GapRows g = j < nblocks ? rows(j) : GapRows{0, Ls, 0, 0};
+      gb.L[j] = g.L; gb.gap0[j] = g.gap0; gb.gap_len[j] = g.gap_len;
+      const unsigned a = (unsigned)npoly * g.L * 16, b = ((unsigned)npoly * g.L) << S1;
+      if (a > n1) n1 = a;
+      if (b > n2) n2 = b;
+    }
+    if (!n1) return RH_OK;
+#define RH_BLK(S) do { ntt_fwd_cols_blocks_asm<S><<<dim3(n1, nblocks), 256, 0, st>>>(data, block_stride, gb, npoly, r->d_tw_fwd, r->d_consts);                           \
+                       if (lazy_out) ntt_fwd_tile_blocks_asm<S, true><<<dim3(n2, nblocks), 256, 0, st>>>(data, block_stride, gb, npoly, r->d_twk_fwd, r->d_consts);          \
+                       else ntt_fwd_tile_blocks_asm<S, false><<<dim3(n2, nblocks), 256, 0, st>>>(data, block_stride, gb, npoly, r->d_twk_fwd, r->d_consts); } while (0)
+    switch (S1) { case 2: RH_BLK(2); break; case 3: RH_BLK(3); break; case 4: RH_BLK(4); break; }
+#undef RH_BLK
+    return check_launch("ntt_fwd_blocks (small batch)");
+  }
   for (int j = 0; j <= nblocks; ++j) {
     GapRows g1 = j < nblocks ? rows(j) : GapRows{1, 1, 0, 0}, g2 = j >= 1 ? rows(j - 1) : GapRows{1, 1, 0, 0};
     const unsigned n1 = j < nblocks ? (unsigned)npoly * g1.L * 16 : 0, n2 = j >= 1 ? ((unsigned)npoly * g2.L) << S1 : 0;
@@ -609,14 +628,14 @@ int rh_std_ntt_fwd_blocks(rh_ring* r, u64* data, size_t block_stride, int npoly,
   }
   return check_launch("ntt_fwd_fused_gap_asm");
 }
-int rh_std_ntt_fwd_digits(rh_ring* r, u64* data, size_t digit_stride, int npoly, int beta, int LQ, int LP, bool lazy_out) {
+int rh_std_ntt_fwd_digits(rh_ring* r, u64* data, size_t digit_stride, int npoly, int beta, int LQ, int LP, bool lazy_out, int small) {
   if (beta <= 0) return RH_OK;
   std::vector<int> g0(beta), gl(beta);
   for (int j = 0; j < beta; ++j) {                  // digit j skips its own limbs [j LP, min((j+1) LP, LQ))
     int n = LQ - j * LP; if (n > LP) n = LP; if (n < 0) n = 0;
     g0[j] = j * LP; gl[j] = n;
   }
-  return rh_std_ntt_fwd_blocks(r, data, digit_stride, npoly, beta, LQ, g0.data(), gl.data(), lazy_out);
+  return rh_std_ntt_fwd_blocks(r, data, digit_stride, npoly, beta, LQ, g0.data(), gl.data(), lazy_out, small);
 }
 
 // Inverse canonical transform of ONE limb of every poly of a block with in_rows limbs per poly into a dense block of npoly rows

@@ -57,8 +57,8 @@ struct rh_ring {
   bool asm_tile = true;           // forward tile kernel: hand-scheduled body (ntt_kernels_asm.hip.hpp) vs the C++ one
   bool inv_scale = true;          // false: inverse leaves values < 4q without the N^-1 factor (3N sub-transform)
   int auto_span_rows = 2048;      // chunk_polys = -1: span size of the fused pipeline in (poly, limb) rows
-  int ks_small_rows = 0;          // key switch (keyswitch.hip): blocks of at most this many (poly, limb) rows run their digits side by side on side streams (0: never, the default:
-                                  // it pays under a graph replay, -14 % at one ciphertext, and costs 5 % call by call, where the extra launches are host-bound)
+  int ks_small_rows = 256;        // key switch (keyswitch.hip): blocks of at most this many (poly, limb) rows (a few ciphertexts) take the small-batch launches: every digit
+                                  // in ONE extension launch and one launch pair of the transforms instead of a chain of ~10 dependent launches (0: never)
   bool one_pass = true;           // N = 2^13 / 2^14: whole limb row in one workgroup's LDS (ntt_fwd_onepass_asm / ntt_inv_onepass_asm); false: the two-pass launches
   bool one_pass_ready = false;    // ... their dynamic-LDS limit has been raised on this ring's device
   bool nt_streams = true;         // non-temporal data streams for launches beyond the Infinity Cache (the generated _NT bodies); false: default policy everywhere
@@ -89,9 +89,9 @@ int rh_std_ntt_launch(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows,
 int rh_ring_ntt_any(rh_ring* r, const u64* in, u64* out, int npoly, int Lrows, int limb0, bool inverse);
 int rh_std_ntt_fwd_strided(rh_ring* r, u64* data, int npoly, int Lrows, int limb0, int Ls);
 bool rh_can_ntt_digits(const rh_ring* r);
-int rh_std_ntt_fwd_digits(rh_ring* r, u64* data, size_t digit_stride, int npoly, int beta, int LQ, int LP, bool lazy_out = false);
+int rh_std_ntt_fwd_digits(rh_ring* r, u64* data, size_t digit_stride, int npoly, int beta, int LQ, int LP, bool lazy_out = false, int small = -1);
 int rh_std_ntt_fwd_blocks(rh_ring* r, u64* data, size_t block_stride, int npoly, int nblocks, int Ls, const int* gap0, const int* gap_len,
-                          bool lazy_out = false);
+                          bool lazy_out = false, int small = -1);
 bool rh_can_intt_limb_strided(const rh_ring* r);
 int rh_std_intt_limb_strided(rh_ring* r, const u64* in, int in_rows, int limb, u64* out, int npoly);
 bool rh_can_fuse_submul(const rh_ring* r);

@@ -181,32 +181,22 @@ static int decompose_all_ntt(rh_bext* be, int levelQ, int levelP, int beta, cons
       if (int rc = decompose_single_ntt(be, levelQ, levelP, i, cx, cxInv, decQ + (size_t)i * wq, decP + (size_t)i * wp, npoly, copy_digit)) return rc;
     return RH_OK;
   }
-  if (ks_small(RQ, npoly, LQ) && beta > 1) {
-    // a few polys (one ciphertext per call, the way the reference's callers issue work): a digit's launches fill a quarter of the chip and the
-    // pipelined stream below is a chain of ~10 dependent launches -- run the digits' chains (extension, transforms) SIDE BY SIDE on side streams
-    // forked from / joined into the caller's stream (capturable; same bits: every block is canonical here, the lazy pipeline's are congruent)
-    hipStream_t* side; hipEvent_t fork; hipEvent_t* join;
-    if (int rc = rh_bext_side_streams(be, &side, &fork, &join)) return rc;
-    hipStream_t main = rh_stream(RQ);
-    if (hipEventRecord(fork, main) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_product: fork failed");
-    int rc = RH_OK;
-    const int ns = beta < RH_BEXT_SIDE ? beta : RH_BEXT_SIDE;
-    for (int k = 0; k < ns && !rc; ++k) if (hipStreamWaitEvent(side[k], fork, 0) != hipSuccess) rc = rh_fail(RH_ERR_DEVICE, "gadget_product: fork failed");
-    for (int i = 0; i < beta && !rc; ++i) {
-      RhCallScope scope(side[i % ns]);
-      rc = decompose_single_ntt(be, levelQ, levelP, i, cx, cxInv, decQ + (size_t)i * wq, decP + (size_t)i * wp, npoly, copy_digit);
-    }
-    for (int k = 0; k < ns; ++k)                         // join even after an error: nothing may stay forked
-      if ((hipEventRecord(join[k], side[k]) != hipSuccess || hipStreamWaitEvent(main, join[k], 0) != hipSuccess) && !rc)
-        rc = rh_fail(RH_ERR_DEVICE, "gadget_product: join failed");
-    return rc;
+  // a few polys (one ciphertext per call, the way the reference's callers issue work): a digit's launches fill a quarter of the chip and the
+  // digit-by-digit sequence is a chain of ~10 dependent launches -- ALL digits in one extension launch (blockIdx.z = digit) and, inside
+  // rh_std_ntt_fwd_digits, one launch pair of the transforms (blockIdx.y = digit block)
+  bool extended = false;
+  const int small = ks_small(RQ, npoly, LQ) ? 1 : 0;        // ringQ's tuning decides for both rings
+  if (small && beta > 1) {
+    const int rc = rh_bext_decompose_and_split_all(be, levelQ, levelP, LP, beta, cxInv, decQ, wq, decP, wp, npoly);
+    if (rc < 0) return rc;
+    extended = rc == 0;
   }
-  for (int i = 0; i < beta; ++i)
+  for (int i = 0; i < beta && !extended; ++i)
     if (int rc = rh_bext_decompose_and_split(be, levelQ, levelP, LP, i, cxInv, decQ + (size_t)i * wq, decP + (size_t)i * wp, npoly)) return rc;
   // internal product (copy_digit == false): the blocks feed the key multiply-accumulate only, whose MRedLazy takes any 64-bit
   // operand and whose closing Reduce is canonical -- the transforms skip their final reduction (outputs < 8q)
   const bool lazy = !copy_digit;
-  if (int rc = rh_std_ntt_fwd_digits(RQ, decQ, wq, npoly, beta, LQ, LP, lazy)) return rc;
+  if (int rc = rh_std_ntt_fwd_digits(RQ, decQ, wq, npoly, beta, LQ, LP, lazy, small)) return rc;
   if (copy_digit)
     for (int i = 0; i < beta; ++i) {
       const int st = i * LP; int ed = st + LP; if (ed > LQ) ed = LQ;
@@ -214,7 +204,7 @@ static int decompose_all_ntt(rh_bext* be, int levelQ, int levelP, int beta, cons
                                       (size_t)(ed - st) * N * 8, npoly, hipMemcpyDeviceToDevice, rh_stream(RQ)) != hipSuccess)
         return rh_fail(RH_ERR_DEVICE, "gadget_product: digit copy failed");
     }
-  if (rh_can_ntt_digits(RP)) return rh_std_ntt_fwd_digits(RP, decP, wp, npoly, beta, LP, 0, lazy);   // no limb skipped
+  if (rh_can_ntt_digits(RP)) return rh_std_ntt_fwd_digits(RP, decP, wp, npoly, beta, LP, 0, lazy, small);   // no limb skipped
   return rh_ring_ntt_any(RP, decP, decP, beta * npoly, LP, 0, false);
 }
 
@@ -277,20 +267,8 @@ static int hoisted_tail(rh_bext* be, int levelQ, int levelP, const uint64_t* dec
   aP1 = aP0 + wp;
   const size_t evq_stride = (size_t)RQ->L * N, evp_stride = (size_t)RP->L * N;
   ReduceSchedule rs(RQ, levelQ, RP, levelP);
-  if (ks_small(RQ, npoly, LQ)) {                     // small batch: the P rows' multiply-accumulate beside the Q rows' (side stream 0)
-    hipStream_t* side; hipEvent_t fork; hipEvent_t* join;
-    if (int rc = rh_bext_side_streams(be, &side, &fork, &join)) return rc;
-    hipStream_t main = rh_stream(RQ);
-    if (hipEventRecord(fork, main) != hipSuccess || hipStreamWaitEvent(side[0], fork, 0) != hipSuccess) return rh_fail(RH_ERR_DEVICE, "gadget_product: fork failed");
-    int rc;
-    { RhCallScope scope(side[0]); rc = mac_all(RP, decompP, wp, evkP, beta, rs.PiOverF, aP0, aP1, npoly, LP); }
-    if (!rc) rc = mac_all(RQ, decompQ, wq, evkQ, beta, rs.QiOverF, ct0, ct1, npoly, LQ, cx, LP);
-    if ((hipEventRecord(join[0], side[0]) != hipSuccess || hipStreamWaitEvent(main, join[0], 0) != hipSuccess) && !rc) rc = rh_fail(RH_ERR_DEVICE, "gadget_product: join failed");
-    if (rc) return rc;
-  } else {
-    if (int rc = mac_all(RQ, decompQ, wq, evkQ, beta, rs.QiOverF, ct0, ct1, npoly, LQ, cx, LP)) return rc;
-    if (int rc = mac_all(RP, decompP, wp, evkP, beta, rs.PiOverF, aP0, aP1, npoly, LP)) return rc;
-  }
+  if (int rc = mac_all(RQ, decompQ, wq, evkQ, beta, rs.QiOverF, ct0, ct1, npoly, LQ, cx, LP)) return rc;
+  if (int rc = mac_all(RP, decompP, wp, evkP, beta, rs.PiOverF, aP0, aP1, npoly, LP)) return rc;
   if (out_ntt) return rh_bext_moddown_ntt_pair(be, levelQ, levelP, ct0, ct1, aP0, out0, out1, npoly, add0, add1);
   // coefficient-domain ciphertext (:114-118, then ModDown INTT -> INTT :62-66): ringQP.INTT on both components, ModDownQPtoQ
   if (add0 || add1) return rh_fail(RH_ERR_UNSUPPORTED, "gadget product: the fused Add exists for NTT-domain ciphertexts only");

@@ -36,15 +36,15 @@ def test_gadget_product_vs_oracle_composition(rh, oracle, N, nq, np_, levelQ, le
     dq = rh.DevicePoly.from_numpy(rq, evkQ.reshape(beta_key * 2, nq, N))
     dp = rh.DevicePoly.from_numpy(rp, evkP.reshape(beta_key * 2, np_, N))
     ct0, ct1 = rh.DevicePoly(rq, npoly, LQ), rh.DevicePoly(rq, npoly, LQ)
+    rq.set_tuning("ks_small_rows", 0)                 # the digit-by-digit extension and the pipelined stream of transforms (large batches)
     be.GadgetProduct(levelQ, levelP, pcx, dq.ptr, dp.ptr, beta_key, ct0, ct1)
     g0, g1 = ct0.numpy(), ct1.numpy()
-    # the small-batch path (tuning ks_small_rows: the digits' chains and the two multiply-accumulates side by side on side streams): the same bits
+    # the small-batch path (tuning ks_small_rows, default 256 rows: every digit in ONE extension launch and one launch pair of the transforms): same bits
     rq.set_tuning("ks_small_rows", 1024)
     s0, s1 = rh.DevicePoly(rq, npoly, LQ), rh.DevicePoly(rq, npoly, LQ)
     for _ in range(2):
         be.GadgetProduct(levelQ, levelP, pcx, dq.ptr, dp.ptr, beta_key, s0, s1)
     assert np.array_equal(s0.numpy(), g0) and np.array_equal(s1.numpy(), g1)
-    rq.set_tuning("ks_small_rows", 0)
     for k in range(npoly):
         e0, e1 = oracle_gadget_product(oracle, rh, N, Q, P, levelQ, levelP, cx[k], evkQ, evkP)
         assert np.array_equal(g0[k], e0)
