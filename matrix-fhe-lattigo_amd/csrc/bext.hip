@@ -435,6 +435,8 @@ int rh_bext_moddown_ntt_pair(rh_bext* be, int levelQ, int levelP, const u64* q0,
   std::vector<u64> sc(levelQ + 1);
   std::vector<u64> Ps(be->P->moduli.begin(), be->P->moduli.begin() + levelP + 1);
   for (int i = 0; i <= levelQ; ++i) sc[i] = be->Q->moduli[i] - moddown_const(Ps, be->Q->moduli[i]);
+  if (be->Q->asm_tile && be->Q->pair_submul && (add0 == nullptr) == (add1 == nullptr))       // both components in one launch
+    return rh_std_ntt_submul_launch_pair(be->Q, buffQ, npoly, levelQ + 1, q0, q1, levelQ + 1, out0, out1, levelQ + 1, sc.data(), add0, add1, levelQ + 1);
   if (int rc = rh_std_ntt_submul_launch(be->Q, buffQ, npoly, levelQ + 1, 0, q0, levelQ + 1, out0, levelQ + 1, sc.data(), true, add0, levelQ + 1)) return rc;
   return rh_std_ntt_submul_launch(be->Q, buffQ + wq, npoly, levelQ + 1, 0, q1, levelQ + 1, out1, levelQ + 1, sc.data(), true, add1, levelQ + 1);
 }

@@ -726,6 +726,27 @@ int rh_std_ntt_expand_cols_launch(rh_ring* r, const u64* tmp, u64* buf, int npol
   return check_launch("ntt_fwd_cols_expand");
 }
 
+// Both components of a ModDown in ONE launch: buf holds 2 * npoly polys (component 0 then component 1, column stages done), component c goes with
+// (y_c, out_c, z_c); z0 and z1 are both given or both null.  Hand-scheduled bodies only (the caller checks rh_can_fuse_submul and asm_tile).
+int rh_std_ntt_submul_launch_pair(rh_ring* r, u64* buf, int npoly, int Lrows, const u64* y0, const u64* y1, int y_rows, u64* out0, u64* out1, int out_rows,
+                                  const u64* scalars_host, const u64* z0, const u64* z1, int z_rows) {
+  if (!rh_can_fuse_submul(r) || !r->asm_tile || (z0 == nullptr) != (z1 == nullptr)) return rh_fail(RH_ERR_UNSUPPORTED, "paired subtract-multiply: hand-scheduled bodies, both addends or none");
+  const unsigned rows = 2u * (unsigned)npoly * (unsigned)Lrows;
+  if (rows == 0) return RH_OK;
+  const int S1 = r->logN - LT;
+  (void)hipGetLastError();
+  LimbShoup sh; memset(&sh, 0, sizeof(sh));
+  for (int i = 0; i < Lrows; ++i) {
+    const u64 q = r->moduli[i];
+    sh.w[i] = rh::imform(scalars_host[i] % q, q); sh.wp[i] = rh::shoup_quotient(sh.w[i], q);
+  }
+  const bool nt = rh_streams_beyond_cache(r, rows / 2);       // (the policy of one component's launch, as before)
+  hipStream_t st = rh_stream(r);
+#define RH_SMP(ADD, NTF) ntt_fwd_tile_submul_asm<ADD, NTF><<<rows << S1, 256, 0, st>>>(buf, r->d_twk_fwd, r->d_consts, Lrows, r->logN, 2 * npoly, y0, y_rows, out0, out_rows, sh, z0, z_rows, npoly, y1, out1, z1)
+  if (z0 && nt) RH_SMP(true, true); else if (z0) RH_SMP(true, false); else if (nt) RH_SMP(false, true); else RH_SMP(false, false);
+#undef RH_SMP
+  return check_launch("ntt_fwd_tile_submul_asm (pair)");
+}
 int rh_std_ntt_submul_launch(rh_ring* r, u64* buf, int npoly, int Lrows, int limb0, const u64* y, int y_rows, u64* out, int out_rows,
                              const u64* scalars_host, bool cols_done, const u64* z, int z_rows) {
   static_assert(RH_MAX_LIMBS_K == RH_MAX_LIMBS, "limb bound mismatch");
@@ -1121,6 +1142,7 @@ extern "C" int rh_ring_set_tuning(rh_ring* r, const char* key, long value) {
   }
   if (!strcmp(key, "asm_cols")) { r->asm_cols = (int)value; return RH_OK; }
   if (!strcmp(key, "ks_small_rows")) { if (value < 0) return rh_fail(RH_ERR_ARG, "ks_small_rows must be >= 0"); r->ks_small_rows = (int)value; return RH_OK; }
+  if (!strcmp(key, "pair_submul")) { r->pair_submul = value != 0; return RH_OK; }
   if (!strcmp(key, "one_pass")) { r->one_pass = value != 0; return RH_OK; }
   if (!strcmp(key, "nt_streams")) { r->nt_streams = value != 0; if (r->kind == RH_RING_3N) rh_ring3n_set_nt_streams(r, value != 0); return RH_OK; }     // 0: default cache policy everywhere (A/B runs: bench.py --tune nt_streams=0)
   return rh_fail(RH_ERR_ARG, "set_tuning: unknown key %s", key);

@@ -59,6 +59,7 @@ struct rh_ring {
   int auto_span_rows = 2048;      // chunk_polys = -1: span size of the fused pipeline in (poly, limb) rows
   int ks_small_rows = 256;        // key switch (keyswitch.hip): blocks of at most this many (poly, limb) rows (a few ciphertexts) take the small-batch launches: every digit
                                   // in ONE extension launch and one launch pair of the transforms instead of a chain of ~10 dependent launches (0: never)
+  bool pair_submul = true;        // ModDown of a ciphertext: both components' transform + subtract-multiply in ONE launch (false: one launch per component; A/B runs)
   bool one_pass = true;           // N = 2^13 / 2^14: whole limb row in one workgroup's LDS (ntt_fwd_onepass_asm / ntt_inv_onepass_asm); false: the two-pass launches
   bool one_pass_ready = false;    // ... their dynamic-LDS limit has been raised on this ring's device
   bool nt_streams = true;         // non-temporal data streams for launches beyond the Infinity Cache (the generated _NT bodies); false: default policy everywhere
@@ -97,6 +98,8 @@ int rh_std_intt_limb_strided(rh_ring* r, const u64* in, int in_rows, int limb, u
 bool rh_can_fuse_submul(const rh_ring* r);
 int rh_std_ntt_submul_launch(rh_ring* r, u64* buf, int npoly, int Lrows, int limb0, const u64* y, int y_rows, u64* out, int out_rows,
                              const u64* scalars_host, bool cols_done = false, const u64* z = nullptr, int z_rows = 0);
+int rh_std_ntt_submul_launch_pair(rh_ring* r, u64* buf, int npoly, int Lrows, const u64* y0, const u64* y1, int y_rows, u64* out0, u64* out1, int out_rows,
+                                  const u64* scalars_host, const u64* z0, const u64* z1, int z_rows);
 int rh_std_ntt_expand_cols_launch(rh_ring* r, const u64* tmp, u64* buf, int npoly, int Lrows, const void* table_dev, int mode, u64 qL);
 int rh_vec_launch(rh_ring* r, int opcode, const u64* p1, const u64* p2, u64* p3, int npoly, int Lrows, int limb0,
                   const u64* s0, const u64* s1, int rows1 = 0, int rows2 = 0, int rows3 = 0, int half = 0);

@@ -131,15 +131,19 @@ struct LimbShoup { u64 w[RH_MAX_LIMBS_K], wp[RH_MAX_LIMBS_K]; };
 template <bool ADD, bool NT = false>
 __global__ void __launch_bounds__(256)
 ntt_fwd_tile_submul_asm(const u64* in, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts, int L, int logN, int npoly,
-                        const u64* y, int y_rows, u64* out, int out_rows, LimbShoup sc, const u64* z, int z_rows) {
+                        const u64* y, int y_rows, u64* out, int out_rows, LimbShoup sc, const u64* z, int z_rows,
+                        int npoly_a = 0, const u64* y_b = nullptr, u64* out_b = nullptr, const u64* z_b = nullptr) {
+  // npoly_a > 0: TWO operand sets in one launch (both components of a ModDown): polys [0, npoly_a) of `in` go with (y, out, z), the rest with (y_b, out_b, z_b)
   __shared__ u64 lds[LDS_WORDS];
   const u32 b = blockIdx.x;
   const u32 limb = b % (u32)L;
   const u32 r = b / (u32)L;
-  const u32 poly = r % (u32)npoly;
+  const u32 poly_in = r % (u32)npoly;
   const u32 tile = r / (u32)npoly;
   const size_t toff = (size_t)tile << LT;
-  const u64 pin = uni64((u64)(size_t)(in + (((size_t)poly * L + limb) << logN) + toff));
+  const u64 pin = uni64((u64)(size_t)(in + (((size_t)poly_in * L + limb) << logN) + toff));
+  u32 poly = poly_in;
+  if (npoly_a > 0 && poly_in >= (u32)npoly_a) { poly = poly_in - (u32)npoly_a; y = y_b; out = out_b; z = z_b; }
   const u64 py = uni64((u64)(size_t)(y + (((size_t)poly * y_rows + limb) << logN) + toff));
   const u64 pout = uni64((u64)(size_t)(out + (((size_t)poly * out_rows + limb) << logN) + toff));
   const u64 pz = ADD ? uni64((u64)(size_t)(z + (((size_t)poly * z_rows + limb) << logN) + toff)) : 0;
