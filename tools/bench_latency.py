@@ -67,8 +67,31 @@ for B in (1, 2, 4, 8):
         for _ in range(50):
             g.replay(); side.synchronize()
         graph_sync = (time.perf_counter() - t0) / 50
+    # the operations a reference caller issues on ONE ciphertext: ct x ct multiply + relinearise + rescale (schemes/ckks/evaluator.go:786-881, 500-535)
+    # and a rotation (core/rlwe/evaluator_automorphism.go:25-60), call by call with a synchronisation each (the latency a caller sees)
+    extra = {}
+    if B == 1:
+        gct = rh.rlwe.GadgetCiphertext.__new__(rh.rlwe.GadgetCiphertext)
+        gct.digits, gct.levelQ, gct.levelP = beta, len(Q) - 1, len(P) - 1
+        gct.Q, gct.P = rh.DevicePoly.from_torch(rq, kq), rh.DevicePoly.from_torch(rp, kp)
+        cev = rh.ckks.Evaluator(rq, rp, rlk=gct)
+        kev = rh.rlwe.Evaluator(rq, rp, galois_keys={5: gct})
+        mk = lambda: rh.DevicePoly.from_torch(rq, uniform((1, len(Q), N), Q))
+        ctA, ctB, ctO, ctR = (rh.Ciphertext([mk(), mk()], is_ntt=True) for _ in range(4))
+        with torch.cuda.stream(side):
+            def timed_sync(fn, reps=50):
+                fn(); fn(); side.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn(); side.synchronize()
+                return (time.perf_counter() - t0) / reps * 1e6
+            extra["ckks_MulRelin_us_with_sync"] = timed_sync(lambda: cev.MulRelin(ctA, ctB, ctO, relin=True))
+            extra["ckks_Rescale_us_with_sync"] = timed_sync(lambda: cev.Rescale(ctO, ctR))
+            extra["rlwe_Automorphism_us_with_sync"] = timed_sync(lambda: kev.Automorphism(ctA, 5, ctO))
+        kev.close(); cev.close()
     row = {"op": "GadgetProduct", "polys": B, "eager_us_back_to_back": eager * 1e6, "eager_us_with_sync": eager_sync * 1e6,
            "graph_us_back_to_back": graph * 1e6, "graph_us_with_sync": graph_sync * 1e6, "graph_equals_eager": bool(same)}
+    row.update(extra)
     res["rows"].append(row)
     sys.stderr.write(json.dumps(row) + "\n")
     del g
