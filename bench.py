@@ -10,6 +10,8 @@
   ranks (rh_kshard_gadget_product behind the C ABI; the one path with a real exchange step: all-gather of the source limbs and of the P
   part, RCCL over xGMI, chunked so that an exchange runs under the other chunk's arithmetic).  --shard batch: the batch divided, the 120 MiB
   key replicated, no collective (DESIGN.md 7 prices both).  value = key switches per second of the whole job (strong scaling).
+--workload polymul (BASELINE config 3): a step = c = INTT(NTT(a) . NTT(b)) over `--batch` poly pairs of 16 limbs at N = 2^15 (Ring.PolyMul: the sequence
+  NTT, NTT, MForm, MulCoeffsMontgomery, INTT of schemes/ckks/evaluator.go:821-834); batch-sharded like the metric, no data-path collective.
 --gather (ntt workload): after the timed region, the north star's one collective -- the final gather of `--gather-polys` result polys per
   rank as ONE all_gather_into_tensor on device memory (sharding.gather_polys) -- timed on its own and reported OUTSIDE `value`.
 
@@ -46,7 +48,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="ntt", choices=["ntt", "keyswitch"])
+    ap.add_argument("--workload", default="ntt", choices=["ntt", "keyswitch", "polymul"])
     ap.add_argument("--batch", type=int, default=-1, help="ntt: polys per GPU per step (default 1024 -> 8 GiB, >> 256 MiB Infinity Cache); "
                                                            "keyswitch: polys per step of the whole job (default 64)")
     ap.add_argument("--logn", type=int, default=16)
@@ -504,6 +506,105 @@ def run_ntt(args):
         dist.destroy_process_group()
 
 
+# ------------------------------------------------------------------------------------------------ workload: polymul (BASELINE config 3)
+def run_polymul(args):
+    """a step = c = INTT(NTT(a) . NTT(b)) on a batch of polys at N = 2^15, 16 limbs (schemes/ckks/evaluator.go:821-834: NTT, NTT, MForm,
+    MulCoeffsMontgomery, INTT) through Ring.PolyMul; batch-sharded like the metric: every rank its own batch, no data-path collective"""
+    import numpy as np
+    import torch
+    import matrix_fhe_lattigo_amd as rh
+    rank, local_rank, world, dist, dev, ranks_seen = init_dist(args)
+    logn = args.logn if any(a.startswith("--logn") for a in sys.argv) else 15     # config 3's ring degree unless --logn says otherwise
+    N, L = 1 << logn, args.limbs
+    B = args.batch if args.batch > 0 else 512
+    mods = QI60[:L]
+    ring = rh.Ring(N, mods, device=local_rank)
+    stream = torch.cuda.current_stream()
+    ring.set_stream(stream.cuda_stream)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        ring.set_tuning(k, int(v))
+    g = torch.Generator(device=dev); g.manual_seed(0xc3 + rank)
+    qs = torch.tensor(mods, dtype=torch.int64, device=dev).view(1, L, 1)
+    mk = lambda: torch.randint(0, 1 << 62, (B, L, N), dtype=torch.int64, device=dev, generator=g) % qs
+    ta, tb = mk(), mk()
+    tc = torch.empty_like(ta)
+    pa, pb, pc = (rh.DevicePoly.from_torch(ring, t) for t in (ta, tb, tc))
+    ka, kb = ta.clone(), tb.clone()                            # (PolyMul transforms its operands in place: every step starts from these)
+
+    def step():
+        ta.copy_(ka); tb.copy_(kb)
+        ring.PolyMul(pa, pb, pc)
+
+    # the two restore copies ride in the timed steps, are timed apart right after, and are subtracted: `value` is the product alone
+    wall, dev_ms, per_rank = timed_region(step, args, dist, dev, stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(args.steps):
+        ta.copy_(ka); tb.copy_(kb)
+    e1.record(stream); torch.cuda.synchronize()
+    copy_ms = e0.elapsed_time(e1)
+    ring.sync()
+    verified = None
+    spots = sorted({(0, 0), (min(B - 1, B // 2 + 1), min(L - 1, 7)), (B - 1, L - 1)})
+    if not args.no_verify:
+        import oracle
+        MUL, MFORM = rh.OPS["MUL_MONT"], rh.OPS["MFORM"]
+        ok = True
+        z = np.zeros(N, dtype=np.uint64)
+        for (p_, l) in spots:
+            sr = oracle.SubRingConsts(N, mods[l])
+            xa, xb = (t[p_, l].cpu().numpy().view(np.uint64) for t in (ka, kb))
+            fa, fb = oracle.ntt(xa, sr), oracle.ntt(xb, sr)
+            prod = oracle.vec_op(MUL, oracle.vec_op(MFORM, fa, z, z, 0, 0, mods[l]), fb, z, 0, 0, mods[l])
+            if not np.array_equal(tc[p_, l].cpu().numpy().view(np.uint64), oracle.intt(prod, sr)):
+                ok = False
+        if not ok:
+            sys.stderr.write("bench.py: rank %d: POLY-MUL MISMATCH vs oracle\n" % rank)
+        verified = all_ranks_ok(ok, args, dist, dev)
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    dev_step_ms = (dev_ms - copy_ms) / args.steps               # the product alone (device time); the wall clock keeps the restore copies in
+    wall_prod = max(wall - copy_ms * 1e-3, 1e-9)
+    value = world * B * args.steps / wall_prod
+    seq_bytes, fused_bytes, moved_bytes = 88.0 * N * L * B, 24.0 * N * L * B, 72.0 * N * L * B      # SURVEY 8(d); 72: what Ring.PolyMul moves (DESIGN 4)
+    achieved = seq_bytes / (dev_step_ms * 1e-3) / 1e9
+    out = {
+        "metric": "poly-mul/s at N=2^%d, %d RNS limbs (c = INTT(NTT(a) . NTT(b)), BASELINE config 3)" % (logn, L),
+        "value": value, "unit": "poly-mul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall_prod * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic", "verified": verified,
+        "config": {"workload": "Ring.PolyMul, N=2^%d, %d limbs (Qi60[0:%d]), batch %d polys/GPU, device-resident; operands restored before every step (their restore copies timed apart and subtracted)" % (logn, L, L, B),
+                   "parallelism": "batch-shard x%d, no data-path collective" % world,
+                   "dist_backend": args.dist_backend if (world > 1 or args.force_dist) else None, "rccl_ranks" if args.dist_backend == "nccl" else "dist_ranks": ranks_seen,
+                   "per_rank_device_ms_per_step": per_rank, "verified_on": "every rank (%d spot rows of its own batch vs the oracle's NTT, NTT, MForm, MulCoeffsMontgomery, INTT)" % len(spots)},
+        "roofline": {"bound": "hbm", "limited_by": "power/valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_step": seq_bytes, "note": "algorithmic bytes = the reference's kernel sequence, 88*N*L per product (SURVEY 8(d))",
+                     "frac_vs_fused_lower_bound_24NL": fused_bytes / (dev_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "bytes_moved_by_this_implementation_per_step": moved_bytes, "device_ms_per_step": dev_step_ms},
+    }
+    if world == 1 and not args.no_cpu:
+        import oracle
+        MUL, MFORM = rh.OPS["MUL_MONT"], rh.OPS["MFORM"]
+        srs = [oracle.SubRingConsts(N, q) for q in mods]
+        xa = [ka[0, l].cpu().numpy().view(np.uint64) for l in range(L)]
+        xb = [kb[0, l].cpu().numpy().view(np.uint64) for l in range(L)]
+        z = np.zeros(N, dtype=np.uint64)
+        reps, t0 = 0, time.perf_counter()
+        while reps < 1 or time.perf_counter() - t0 < min(args.cpu_seconds, 10.0):
+            for l in range(L):
+                fa, fb = oracle.ntt(xa[l], srs[l]), oracle.ntt(xb[l], srs[l])
+                oracle.intt(oracle.vec_op(MUL, oracle.vec_op(MFORM, fa, z, z, 0, 0, mods[l]), fb, z, 0, 0, mods[l]), srs[l])
+            reps += 1
+        out["cpu_baseline"] = {"value": reps / (time.perf_counter() - t0), "unit": "poly-mul/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+                               "sample": "%d products of one %d-limb N=2^%d poly pair through the C restatement (oracle/ring_oracle.c), single thread" % (reps, L, logn)}
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------------------------ workload: keyswitch
 def run_keyswitch(args):
     import numpy as np
@@ -617,6 +718,8 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)
+    if args.workload == "polymul":
+        return run_polymul(args)
     if args.workload == "keyswitch":
         return run_keyswitch(args)
     return run_ntt(args)

@@ -46,6 +46,17 @@ def test_bench_keyswitch_workload_two_ranks():
     assert j["config"]["dist_ranks"] == 2
 
 
+def test_bench_polymul_workload_one_gpu_and_two_ranks():
+    # BASELINE config 3 through bench.py: the JSON contract with roofline + cpu_baseline at N = 1; two ranks batch-sharded, every rank verifies
+    j = run_bench("--workload", "polymul", "--batch", "40", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1")
+    assert j["unit"] == "poly-mul/s" and j["n_gpus"] == 1 and j["verified"] is True and j["scaling"] == "weak" and "2^15" in j["metric"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac_vs_fused_lower_bound_24NL"] < r["frac"]
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
+    j = run_bench("--workload", "polymul", "--gpus", "2", "--single-device", "--dist-backend", "gloo", "--batch", "6", "--steps", "1", "--warmup", "1", "--logn", "13", "--no-cpu")
+    assert j["n_gpus"] == 2 and j["config"]["dist_ranks"] == 2 and j["verified"] is True and "2^13" in j["metric"]
+
+
 # ---- pre-flight of the first real 8-GPU run: the driver's N > 1 form rehearsed with MANY ranks on this box's one GPU over
 # gloo.  The GPU box's process guard allows 6 processes on the card at once and this pytest process already holds a context, so the rehearsal
 # runs 5 ranks there (RH_BENCH_REHEARSE_RANKS overrides where no guard applies); everything that depends on the rank count -- rendezvous, shards
