@@ -12,6 +12,8 @@
   key replicated, no collective (DESIGN.md 7 prices both).  value = key switches per second of the whole job (strong scaling).
 --workload polymul (BASELINE config 3): a step = c = INTT(NTT(a) . NTT(b)) over `--batch` poly pairs of 16 limbs at N = 2^15 (Ring.PolyMul: the sequence
   NTT, NTT, MForm, MulCoeffsMontgomery, INTT of schemes/ckks/evaluator.go:821-834); batch-sharded like the metric, no data-path collective.
+--workload ctmul (BASELINE config 4): a step = matrix_ckks.Evaluator.Mul on `--batch` ciphertext pairs (default 128 = one GPU's share of 1024) over the 3N ring
+  N = 3*2^16 (`--logn 14`: N = 3*2^14), 24 limbs; batch-sharded, no data-path collective.
 --gather (ntt workload): after the timed region, the north star's one collective -- the final gather of `--gather-polys` result polys per
   rank as ONE all_gather_into_tensor on device memory (sharding.gather_polys) -- timed on its own and reported OUTSIDE `value`.
 
@@ -48,7 +50,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="ntt", choices=["ntt", "keyswitch", "polymul"])
+    ap.add_argument("--workload", default="ntt", choices=["ntt", "keyswitch", "polymul", "ctmul"])
     ap.add_argument("--batch", type=int, default=-1, help="ntt: polys per GPU per step (default 1024 -> 8 GiB, >> 256 MiB Infinity Cache); "
                                                            "keyswitch: polys per step of the whole job (default 64)")
     ap.add_argument("--logn", type=int, default=16)
@@ -605,6 +607,115 @@ def run_polymul(args):
         dist.destroy_process_group()
 
 
+# ------------------------------------------------------------------------------------------------ workload: ctmul (BASELINE config 4)
+def run_ctmul(args):
+    """a step = matrix_ckks.Evaluator.Mul (schemes/matrix_ckks/evaluator.go:114-192) on `--batch` pairs of degree-1 ciphertexts over the 3N ring
+    N = 3*2^16 (`--logn 14`: the other reading, 3*2^14), 24 limbs: 4 forward 3N transforms, the tensoring, 3 inverse transforms; batch-sharded
+    (BASELINE: 1024 pairs over 8 GPUs = 128 per GPU, the default batch), no data-path collective"""
+    import numpy as np
+    import torch
+    import matrix_fhe_lattigo_amd as rh
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from primes3n import moduli_3n
+    rank, local_rank, world, dist, dev, ranks_seen = init_dist(args)
+    N, L = 3 << args.logn, (args.limbs if any(a.startswith("--limbs") for a in sys.argv) else 24)
+    B = args.batch if args.batch > 0 else 128
+    mods = moduli_3n(N, L)
+    ring = rh.Ring(N, mods, kind=rh.Matrix3N, device=local_rank)
+    stream = torch.cuda.current_stream()
+    ring.set_stream(stream.cuda_stream)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        ring.set_tuning(k, int(v))
+    om = [int(w) for w in ring.constants()["omega3n"]]
+    g = torch.Generator(device=dev); g.manual_seed(0xc4 + rank)
+    qs = torch.tensor(mods, dtype=torch.int64, device=dev).view(1, L, 1)
+
+    def mk(rand=True):
+        t = torch.empty((B, L, N), dtype=torch.int64, device=dev)
+        for b0 in range(0, B, 16):
+            n = min(16, B - b0)
+            t[b0:b0 + n] = (torch.randint(0, 1 << 62, (n, L, N), dtype=torch.int64, device=dev, generator=g) % qs) if rand else 0
+        return t
+    tin = [mk() for _ in range(4)]
+    tout = [mk(False) for _ in range(3)]
+    pin = [rh.DevicePoly.from_torch(ring, t) for t in tin]
+    ct0, ct1 = rh.Ciphertext(pin[0:2]), rh.Ciphertext(pin[2:4])
+    out = rh.Ciphertext([rh.DevicePoly.from_torch(ring, t) for t in tout])
+    ev = rh.MatrixCKKSEvaluator(ring)                           # the default evaluator: block-order device NTT domain, carried as per-block tags
+
+    def step():
+        # Mul transforms coefficient-domain inputs IN PLACE (evaluator.go:136-149); the next step reads what it left as coefficient-domain
+        # input again (canonical residues either way), so every step is the full 4 NTT + tensoring + 3 INTT
+        ct0.IsNTT = ct1.IsNTT = False
+        ev.Mul(ct0, ct1, out)
+
+    wall, dev_ms, per_rank = timed_region(step, args, dist, dev, stream)
+    ring.sync()
+    verified = None
+    spots = sorted({(0, 0), (B - 1, L - 1)})
+    if not args.no_verify:
+        # one more step of the same launch sequence on the same buffers, its inputs snapshotted first (raw device rows: what the step reads)
+        import oracle
+        snap = {s_: [t[s_[0], s_[1]].cpu().numpy().view(np.uint64).copy() for t in tin] for s_ in spots}
+        step(); ring.sync()
+        MUL, MULADD = rh.OPS["MUL_MONT"], rh.OPS["MUL_MONT_THEN_ADD"]
+        z = np.zeros(N, dtype=np.uint64)
+        ok = True
+        for (p_, l), xs in snap.items():
+            q, w = mods[l], om[l]
+            A0, A1, B0, B1 = (oracle.ntt3n_forward(x, q, w) for x in xs)
+            e = [oracle.vec_op(MUL, A0, B0, z, 0, 0, q),
+                 oracle.vec_op(MULADD, A1, B0, oracle.vec_op(MUL, A0, B1, z, 0, 0, q), 0, 0, q),
+                 oracle.vec_op(MUL, A1, B1, z, 0, 0, q)]
+            for c in range(3):
+                if not np.array_equal(tout[c][p_, l].cpu().numpy().view(np.uint64), oracle.ntt3n_backward(e[c], q, w)):
+                    ok = False
+        if not ok:
+            sys.stderr.write("bench.py: rank %d: ct x ct Mul MISMATCH vs oracle\n" % rank)
+        verified = all_ranks_ok(ok, args, dist, dev)
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    dev_step_ms = dev_ms / args.steps
+    value = world * B * args.steps / wall
+    alg_bytes = (7 * 16.0 + 3 * 24.0 + 32.0) * N * L * B       # 7 transforms (16 N per limb), 3 MulCoeffsMontgomery (24 N), 1 ...ThenAdd (32 N): SURVEY 8(d)
+    achieved = alg_bytes / (dev_step_ms * 1e-3) / 1e9
+    res = {
+        "metric": "ct x ct Mul/s on the 3N ring N=%d, %d RNS limbs (matrix_ckks.Evaluator.Mul, BASELINE config 4)" % (N, L),
+        "value": value, "unit": "ct-mul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic", "verified": verified,
+        "config": {"workload": "matrix_ckks.Evaluator.Mul, N=3*2^%d, %d limbs (the first %d primes = 1 mod 3N above 2^60), batch %d ciphertext pairs/GPU, device-resident, "
+                               "default evaluator (block-order NTT domain)" % (args.logn, L, L, B),
+                   "parallelism": "batch-shard x%d, no data-path collective" % world,
+                   "dist_backend": args.dist_backend if (world > 1 or args.force_dist) else None, "rccl_ranks" if args.dist_backend == "nccl" else "dist_ranks": ranks_seen,
+                   "per_rank_device_ms_per_step": per_rank,
+                   "verified_on": "every rank: one more step of the same sequence on the same buffers right after timing, %d spot (pair, limb) rows of its 3 outputs vs the oracle's transforms and products" % len(spots)},
+        "roofline": {"bound": "hbm", "limited_by": "power/valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_step": alg_bytes, "device_ms_per_step": dev_step_ms,
+                     "note": "algorithmic bytes = the reference's sequence: 7 transforms x 16 N + 3 x 24 N + 32 N per limb (SURVEY 8(d))"},
+    }
+    if world == 1 and not args.no_cpu:
+        import oracle
+        MUL, MULADD = rh.OPS["MUL_MONT"], rh.OPS["MUL_MONT_THEN_ADD"]
+        xs = [t[0, 0].cpu().numpy().view(np.uint64) for t in tin]
+        z = np.zeros(N, dtype=np.uint64)
+        q, w = mods[0], om[0]
+        t0 = time.perf_counter()
+        A0, A1, B0, B1 = (oracle.ntt3n_forward(x, q, w) for x in xs)
+        for e in (oracle.vec_op(MUL, A0, B0, z, 0, 0, q), oracle.vec_op(MULADD, A1, B0, oracle.vec_op(MUL, A0, B1, z, 0, 0, q), 0, 0, q), oracle.vec_op(MUL, A1, B1, z, 0, 0, q)):
+            oracle.ntt3n_backward(e, q, w)
+        t_limb = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": 1.0 / (t_limb * L), "unit": "ct-mul/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+                               "sample": "ONE of the %d limbs of one ciphertext pair timed (%.2f s: 7 transforms by the oracle's O(N log N) restatement + the 4 products), "
+                                         "scaled by %d; single thread (the reference's own 3N transform is O(N^2) big-integer Horner: not runnable at this size)" % (L, t_limb, L)}
+    print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------------------------ workload: keyswitch
 def run_keyswitch(args):
     import numpy as np
@@ -720,6 +831,8 @@ def main():
         return spawn_ranks(args)
     if args.workload == "polymul":
         return run_polymul(args)
+    if args.workload == "ctmul":
+        return run_ctmul(args)
     if args.workload == "keyswitch":
         return run_keyswitch(args)
     return run_ntt(args)

@@ -57,6 +57,16 @@ def test_bench_polymul_workload_one_gpu_and_two_ranks():
     assert j["n_gpus"] == 2 and j["config"]["dist_ranks"] == 2 and j["verified"] is True and "2^13" in j["metric"]
 
 
+def test_bench_ctmul_workload_one_gpu_and_two_ranks():
+    # BASELINE config 4 through bench.py at a reduced ring (N = 3*2^13, 3 limbs): contract fields, verification on every rank
+    j = run_bench("--workload", "ctmul", "--logn", "13", "--limbs", "3", "--batch", "3", "--steps", "2", "--warmup", "1")
+    assert j["unit"] == "ct-mul/s" and j["n_gpus"] == 1 and j["verified"] is True and "N=24576" in j["metric"]
+    assert j["roofline"]["bound"] == "hbm" and j["cpu_baseline"]["value"] > 0
+    j = run_bench("--workload", "ctmul", "--logn", "13", "--limbs", "2", "--batch", "2", "--steps", "1", "--warmup", "1", "--gpus", "2", "--single-device",
+                  "--dist-backend", "gloo", "--no-cpu")
+    assert j["n_gpus"] == 2 and j["config"]["dist_ranks"] == 2 and j["verified"] is True
+
+
 # ---- pre-flight of the first real 8-GPU run: the driver's N > 1 form rehearsed with MANY ranks on this box's one GPU over
 # gloo.  The GPU box's process guard allows 6 processes on the card at once and this pytest process already holds a context, so the rehearsal
 # runs 5 ranks there (RH_BENCH_REHEARSE_RANKS overrides where no guard applies); everything that depends on the rank count -- rendezvous, shards
