@@ -13,14 +13,22 @@ os.environ.setdefault("AMD_LOG_LEVEL", "1")
 os.environ.setdefault("LIBC_FATAL_STDERR_", "1")      # glibc's own fatal messages (heap consistency checks) to stderr, not to the controlling terminal
 
 
-def _install_abort_trace():
-    """native call stack on SIGABRT (tests/cpp/abort_trace.c, built by `make`): installed after pytest's faulthandler, which it chains to"""
+def _install_abort_trace(config):
+    """native call stack on SIGABRT (tests/cpp/abort_trace.c, built by `make`): installed after pytest's faulthandler, which it chains to.
+    It writes where faulthandler writes -- the real stderr that plugin duplicated before the capture took fd 2 -- and appends the tail of the
+    CAPTURED stderr of the dying test (the last words of glibc or the HIP runtime go there and are lost with the process otherwise)."""
     import ctypes
     so = os.path.join(ROOT, "tests", "cpp", "libabort_trace.so")
     if os.path.exists(so):
         try:
-            ctypes.CDLL(so).abort_trace_install()
-        except OSError:
+            fd = 2
+            try:
+                from _pytest.faulthandler import fault_handler_stderr_fd_key
+                fd = config.stash.get(fault_handler_stderr_fd_key, 2)
+            except Exception:       # noqa: BLE001 (another pytest: plain stderr)
+                pass
+            ctypes.CDLL(so).abort_trace_install_fd(int(fd))
+        except (OSError, AttributeError):
             pass
 
 # Qi60 / Pi60: the reference's 61-bit NTT-friendly test primes (ring/test_params.go:15-32), data only.
@@ -47,7 +55,7 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    _install_abort_trace()
+    _install_abort_trace(session.config)
 
 
 def uniform_mod(rng, q, shape):

@@ -9,17 +9,33 @@
 #include <unistd.h>
 
 static struct sigaction prev_abrt;
+static int out_fd = 2;          /* where the report goes: the REAL stderr (pytest's capture has fd 2 pointing at a temporary file) */
 
 static void on_abort(int sig, siginfo_t* info, void* ctx) {
   static const char head[] = "\n==== SIGABRT: native call stack of the aborting thread (tests/cpp/abort_trace.c) ====\n";
   void* frames[96];
   int n;
-  (void)!write(2, head, sizeof head - 1);
+  (void)!write(out_fd, head, sizeof head - 1);
   n = backtrace(frames, 96);
-  backtrace_symbols_fd(frames, n, 2);
+  backtrace_symbols_fd(frames, n, out_fd);
   {
     static const char tail[] = "==== end of native call stack ====\n";
-    (void)!write(2, tail, sizeof tail - 1);
+    (void)!write(out_fd, tail, sizeof tail - 1);
+  }
+  if (out_fd != 2) {          /* what the dying test wrote to its CAPTURED stderr (glibc's and the HIP runtime's last words land there): the tail of that file */
+    static char buf[8192];
+    off_t end = lseek(2, 0, SEEK_CUR);
+    if (end > 0) {
+      size_t want = end > (off_t)sizeof buf ? sizeof buf : (size_t)end;
+      ssize_t got = pread(2, buf, want, end - (off_t)want);
+      if (got > 0) {
+        static const char h2[] = "==== captured stderr of the running test (tail) ====\n";
+        static const char t2[] = "\n==== end of captured stderr ====\n";
+        (void)!write(out_fd, h2, sizeof h2 - 1);
+        (void)!write(out_fd, buf, (size_t)got);
+        (void)!write(out_fd, t2, sizeof t2 - 1);
+      }
+    }
   }
   if (prev_abrt.sa_flags & SA_SIGINFO) {
     if (prev_abrt.sa_sigaction) { prev_abrt.sa_sigaction(sig, info, ctx); return; }
@@ -31,7 +47,10 @@ static void on_abort(int sig, siginfo_t* info, void* ctx) {
   raise(SIGABRT);
 }
 
-int abort_trace_install(void) {
+int abort_trace_install_fd(int fd);
+int abort_trace_install(void) { return abort_trace_install_fd(2); }
+int abort_trace_install_fd(int fd) {
+  out_fd = fd;
   struct sigaction sa;
   void* warm[4];
   (void)backtrace(warm, 4);              // loads libgcc's unwinder now, not inside the handler
