@@ -95,8 +95,11 @@ def test_whole_poly_vs_oracle_pageable_and_pinned(rh, oracle, logN, L):
     ring.NTTLazyHost(limbs(a), out)
     for i in (0, L - 1):
         assert np.array_equal(out[i], ring.SubRings[i].NTTLazy(a[i]))
-    # a registered (rh_host_register) ordinary allocation
-    own = np.zeros((L, N), dtype=np.uint64)
+    # a registered (rh_host_register) ordinary allocation: whole pages of its own (an anonymous mapping, as a Go runtime hands out large slices) --
+    # registering part of a page pins bytes of unrelated heap objects with it (ringhip.h)
+    import mmap
+    mm = mmap.mmap(-1, max(L * N * 8, mmap.PAGESIZE))
+    own = np.frombuffer(mm, dtype=np.uint64, count=L * N).reshape(L, N)
     own[:] = a
     assert rh.lib().rh_host_register(own.ctypes.data, own.size) == 0
     try:
@@ -105,6 +108,8 @@ def test_whole_poly_vs_oracle_pageable_and_pinned(rh, oracle, logN, L):
         assert np.array_equal(own, want)
     finally:
         assert rh.lib().rh_host_unregister(own.ctypes.data) == 0
+    del r2, own
+    mm.close()
     pin.free()
     ring.close()
 
