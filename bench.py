@@ -137,7 +137,9 @@ def spawn_ranks(args):
 
 
 def init_dist(args):
+    import signal
     import torch
+    signal.signal(signal.SIGTERM, _on_sigterm)          # see _leave_if_stopped
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,10 +166,29 @@ def init_dist(args):
     return rank, local_rank, world, dist, dev, ranks_seen
 
 
+_STOP = [False]       # set by SIGTERM (the parent stopping its ranks after one of them died): leave at the next step boundary, with the GPU idle
+
+
+def _on_sigterm(signum, frame):
+    _STOP[0] = True
+
+
+def _leave_if_stopped():
+    """a rank told to stop finishes the step it is in, drains its stream and exits: a process must not die with kernels in flight on a shared GPU
+    (tearing down queues with running waves is the one thing on this path that can disturb OTHER processes on the card)"""
+    if _STOP[0]:
+        import torch
+        torch.cuda.synchronize()
+        sys.stderr.write("bench.py: rank %s stopping on SIGTERM\n" % os.environ.get("RANK", "0"))
+        sys.stderr.flush()
+        os._exit(143)
+
+
 def timed_region(step, args, dist, dev, stream):
     """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks"""
     import torch
     for _ in range(args.warmup):
+        _leave_if_stopped()
         step()
     torch.cuda.synchronize()
     if dist is not None:
@@ -177,6 +198,8 @@ def timed_region(step, args, dist, dev, stream):
     t0 = time.perf_counter()
     e0.record(stream)
     for _ in range(args.steps):
+        if _STOP[0]:
+            _leave_if_stopped()
         step()
     e1.record(stream)
     torch.cuda.synchronize()

@@ -135,7 +135,10 @@ def test_bench_parent_fails_fast_when_a_rank_dies():
     try:
         assert victim is not None, "no rank process found"
         time.sleep(20.0)                                                   # let the ranks get into their timed loop
-        os.kill(victim, signal.SIGKILL)                                    # the exact PID of one rank
+        # the exact PID of one rank, and SIGTERM, not SIGKILL: the rank leaves at its next step boundary with its stream drained (bench.py:
+        # _leave_if_stopped) -- for the parent and the other ranks a rank that died mid-run all the same, but no process is torn down with kernels in
+        # flight on the GPU this pytest process shares with it
+        os.kill(victim, signal.SIGTERM)
         t0 = time.time()
         try:
             _out, err = p.communicate(timeout=120)
@@ -143,7 +146,17 @@ def test_bench_parent_fails_fast_when_a_rank_dies():
             raise AssertionError("parent still waiting 120 s after a rank died")
         assert p.returncode != 0 and "rank exit codes" in err and time.time() - t0 < 120
     finally:                                                               # whatever happened: no rank of this test outlives it (exact PIDs, never a pattern)
-        for pid in rank_pids():
+        left = rank_pids()
+        for pid in left:                                                   # first the polite way (drain, then exit) ...
+            try:
+                os.kill(pid, signal.SIGTERM)
+            except OSError:
+                pass
+        t1 = time.time()
+        while left and time.time() - t1 < 30:
+            time.sleep(0.5)
+            left = rank_pids()
+        for pid in left:                                                   # ... SIGKILL only for what is left (blocked in a host-side collective: GPU idle)
             try:
                 os.kill(pid, signal.SIGKILL)
             except OSError:
