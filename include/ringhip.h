@@ -117,7 +117,8 @@ int rh_ntt_backward_lazy(rh_ring* r, int limb, const uint64_t* p1, uint64_t* p2)
 int rh_ntt_poly_forward(rh_ring* r, int level, const uint64_t* const* p1, uint64_t* const* p2, int lazy);
 int rh_ntt_poly_backward(rh_ring* r, int level, const uint64_t* const* p1, uint64_t* const* p2, int lazy);
 /* Page-locked host memory for Poly.Coeffs backing arrays (a Go slice over it: unsafe.Slice): such limbs skip the staging copy.
- * rh_host_register page-locks memory the caller already owns (it must stay allocated and unmoved until rh_host_unregister).  Register WHOLE PAGES
+ * rh_host_register page-locks memory the caller already owns (it must stay allocated and unmoved until rh_host_unregister).  WHOLE 4 KiB PAGES only
+ * (pointer and byte count multiples of 4096, else RH_ERR_ARG), pages
  * the caller owns exclusively (a page-aligned mapping or allocation: a Go slice of a megabyte or more sits in spans of its own): the runtime pins and
  * maps every page the range touches, and a page shared with unrelated heap objects drags those into the GPU mapping for the registration's lifetime. */
 int rh_host_alloc(size_t words, uint64_t** hptr);

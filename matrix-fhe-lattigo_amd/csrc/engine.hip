@@ -1325,6 +1325,8 @@ extern "C" int rh_host_alloc(size_t words, uint64_t** hptr) {
 extern "C" int rh_host_free(uint64_t* hptr) { if (hptr) (void)hipHostFree(hptr); return RH_OK; }
 extern "C" int rh_host_register(uint64_t* hptr, size_t words) {
   if (!hptr || !words) return rh_fail(RH_ERR_ARG, "rh_host_register: null argument");
+  // whole pages only: the runtime pins and GPU-maps every page the range touches, and a page shared with unrelated heap objects would be dragged along
+  if (((uintptr_t)hptr & 4095u) || ((words * 8) & 4095u)) return rh_fail(RH_ERR_ARG, "rh_host_register: register whole 4 KiB pages (pointer %p, %zu bytes)", (void*)hptr, words * 8);
   hipError_t e = hipHostRegister(hptr, words * 8, hipHostRegisterDefault);
   if (e != hipSuccess) { (void)hipGetLastError(); return rh_fail(RH_ERR_DEVICE, "hipHostRegister: %s", hipGetErrorString(e)); }
   return RH_OK;

@@ -98,10 +98,12 @@ def test_whole_poly_vs_oracle_pageable_and_pinned(rh, oracle, logN, L):
     # a registered (rh_host_register) ordinary allocation: whole pages of its own (an anonymous mapping, as a Go runtime hands out large slices) --
     # registering part of a page pins bytes of unrelated heap objects with it (ringhip.h)
     import mmap
-    mm = mmap.mmap(-1, max(L * N * 8, mmap.PAGESIZE))
+    nbytes = -(-(L * N * 8) // 4096) * 4096
+    mm = mmap.mmap(-1, nbytes)
     own = np.frombuffer(mm, dtype=np.uint64, count=L * N).reshape(L, N)
     own[:] = a
-    assert rh.lib().rh_host_register(own.ctypes.data, own.size) == 0
+    assert rh.lib().rh_host_register(own.ctypes.data + 8, nbytes // 8) == -1 and b"whole 4 KiB pages" in rh.lib().rh_last_error()   # not in the middle of a page
+    assert rh.lib().rh_host_register(own.ctypes.data, nbytes // 8) == 0
     try:
         r2 = [own[i] for i in range(L)]
         ring.NTTHost(r2, r2)
