@@ -13,6 +13,9 @@ N = 1 << 16
 rq, rp = rh.Ring(N, QI60[:24]), rh.Ring(N, PI60[:6])
 for r in (rq, rp):
     r.set_stream(stream.cuda_stream); r.set_tuning("auto_span_rows", span)
+for kv in os.environ.get("RH_KS_TUNE", "").split(","):          # RH_KS_TUNE=ks_small_rows=0[,key=value...]: ring tunings for the whole run
+    if "=" in kv:
+        rq.set_tuning(kv.split("=")[0], int(kv.split("=")[1])); rp.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 be = rh.BasisExtender(rq, rp)
 def rb(n, mods):
     qs = torch.tensor(mods, dtype=torch.int64, device=dev).view(1, len(mods), 1)
