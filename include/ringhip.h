@@ -185,9 +185,10 @@ int rh_ring_ntt_phase(rh_ring* r, const uint64_t* in_dev, uint64_t* out_dev, int
  *   auto_span_rows  span size of the auto rule in (poly, limb) rows (2048)
  *   asm_tile / asm_cols   1: generated hand-scheduled bodies (default), 0: the C++ kernels
  *   fuse_submul     1: ModDown / rescale subtract-multiply in the forward tile kernel's epilogue (default)
- *   ks_small_rows   n: key switches whose blocks have at most n (poly, limb) rows (a few ciphertexts per call) run every digit of the decomposition in ONE
- *                   basis-extension launch and one launch pair of the transforms instead of digit by digit (default 256; 0: never).  One ciphertext at
- *                   N = 2^16, 24 + 6 limbs: 0.38 -> 0.26 ms; at 16 and more ciphertexts the pipelined stream of launches is the faster one (set on ringQ)
+ *   ks_small_rows   n: key switches whose blocks have at most n (poly, limb) rows (up to ~20 ciphertexts at 24 limbs) run every digit of the decomposition in ONE
+ *                   basis-extension launch and the transforms of all digit blocks of BOTH rings in one launch pair instead of digit by digit (default 512; 0: never).
+ *                   One ciphertext at N = 2^16, 24 + 6 limbs: 0.38 -> 0.24 ms; eight: 1.26 -> 1.15 ms; from ~24 ciphertexts on the pipelined stream of launches
+ *                   is as fast or faster (set on ringQ)
  *   one_pass        1: N = 2^13 / 2^14 (and the inverse at N = 4096) keep the whole limb row in one workgroup's LDS between the column and the tile
  *                   stages: one HBM pass per transform instead of two (default); 0: the two-pass launches
  *   fuse_ci         1: conjugate-invariant rings fold inside the column stages instead of in a pass of their own (default; N = 2^14..2^16)

@@ -148,11 +148,12 @@ struct BextMulti {
   const BextSource* S[8]; const BextTarget* T[8]; const u64* coef[8]; const u64* vt[8];
   int src_limb0[8], nsrc[8], ntgt_c[8], ntgt[8];
 };
+template <int NS, bool EXACT>                      // EXACT: every plan has exactly NS source limbs (the usual case: all digits full)
 __global__ void __launch_bounds__(256)
 bext_multi_kernel(const u64* in, int in_rows, BextMulti m, u64* out0, size_t stride0, int out0_rows, u64* out1, size_t stride1, int out1_rows,
                   int N, int add_mode, int post) {
   const int z = blockIdx.z;
-  bext_body<8, false>(in, in_rows, m.src_limb0[z], m.nsrc[z], m.S[z], m.ntgt_c[z], m.ntgt[z], m.T[z], m.coef[z], m.vt[z],
+  bext_body<NS, EXACT>(in, in_rows, m.src_limb0[z], m.nsrc[z], m.S[z], m.ntgt_c[z], m.ntgt[z], m.T[z], m.coef[z], m.vt[z],
                       out0 + (size_t)z * stride0, out0_rows, out1 + (size_t)z * stride1, out1_rows, nullptr, 0, N, add_mode, post);
 }
 
@@ -532,8 +533,17 @@ int rh_bext_decompose_and_split_all(rh_bext* be, int levelQ, int levelP, int nbP
   if (npoly <= 0) return RH_OK;
   rh_ring* RQ = be->Q;
   (void)hipGetLastError();
-  bext_multi_kernel<<<dim3((RQ->N + 255) / 256, npoly, beta), 256, vt_bytes, rh_stream(RQ)>>>(p0Q, levelQ + 1, m, p1Q, strideQ, levelQ + 1, p1P, strideP, levelP + 1,
-                                                                                             RQ->N, BEXT_ADD_RAW, post);
+  bool uniform = true;
+  for (int d = 1; d < beta; ++d) uniform &= m.nsrc[d] == m.nsrc[0];
+  const dim3 grid((RQ->N + 255) / 256, npoly, beta);
+  hipStream_t st = rh_stream(RQ);
+#define RH_BM(NS, EX) bext_multi_kernel<NS, EX><<<grid, 256, vt_bytes, st>>>(p0Q, levelQ + 1, m, p1Q, strideQ, levelQ + 1, p1P, strideP, levelP + 1, RQ->N, BEXT_ADD_RAW, post)
+  switch (uniform ? m.nsrc[0] : 0) {
+    case 2: RH_BM(2, true); break; case 3: RH_BM(3, true); break; case 4: RH_BM(4, true); break; case 5: RH_BM(5, true); break;
+    case 6: RH_BM(6, true); break; case 7: RH_BM(7, true); break; case 8: RH_BM(8, true); break;
+    default: RH_BM(8, false); break;
+  }
+#undef RH_BM
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rh_fail(RH_ERR_DEVICE, "bext_multi_kernel launch failed: %s", hipGetErrorString(e));
   return RH_OK;

@@ -577,6 +577,41 @@ bool rh_can_ntt_digits(const rh_ring* r) {
   const int S1 = r->logN - LT;
   return r->kind == RH_RING_STANDARD && r->asm_tile && r->asm_cols && r->digit_pipeline && S1 >= 2 && S1 <= 4;
 }
+// Small batches: every block of ring r -- and, when r2 is given, every (gap-free) block of a second ring of the same degree: the P blocks of a key switch
+// beside its Q blocks -- in ONE launch of the column stages and one of the tile stages (blockIdx.y = block).  At most 8 blocks per ring.
+int rh_std_ntt_fwd_blocks_small(rh_ring* r, u64* data, size_t block_stride, int nblocks, int Ls, const int* gap0, const int* gap_len,
+                                rh_ring* r2, u64* data2, size_t block_stride2, int nblocks2, int Ls2, int npoly, bool lazy_out) {
+  if (!rh_can_ntt_digits(r) || (r2 && (!rh_can_ntt_digits(r2) || r2->logN != r->logN)) || nblocks > 8 || nblocks2 > 8)
+    return rh_fail(RH_ERR_UNSUPPORTED, "small-batch block transform: hand-scheduled bodies, one ring degree, at most 8 blocks per ring");
+  if (npoly <= 0 || nblocks <= 0) return RH_OK;
+  (void)hipGetLastError();
+  const int S1 = r->logN - LT;
+  hipStream_t st = rh_stream(r);
+  unsigned n1 = 0, n2 = 0;
+  auto fill = [&](BlockSet& bs, rh_ring* R, u64* d, size_t stride, int nb, int rows, const int* g0, const int* gl, bool cols) {
+    memset(&bs, 0, sizeof bs);
+    if (!R) return;
+    bs.data = d; bs.stride = stride; bs.tw = cols ? R->d_tw_fwd : R->d_twk_fwd; bs.consts = R->d_consts; bs.nblocks = nb; bs.g.Ls = rows;
+    for (int j = 0; j < nb; ++j) {
+      const int gl_j = gl ? gl[j] : 0;
+      bs.g.L[j] = rows - gl_j; bs.g.gap0[j] = (u32)(g0 ? g0[j] : 0); bs.g.gap_len[j] = (u32)gl_j;
+      const unsigned a = (unsigned)npoly * bs.g.L[j] * 16, b = ((unsigned)npoly * bs.g.L[j]) << S1;
+      if (a > n1) n1 = a;
+      if (b > n2) n2 = b;
+    }
+  };
+  BlockSet ca, cb, ta, tb;
+  fill(ca, r, data, block_stride, nblocks, Ls, gap0, gap_len, true); fill(cb, r2, data2, block_stride2, nblocks2, Ls2, nullptr, nullptr, true);
+  fill(ta, r, data, block_stride, nblocks, Ls, gap0, gap_len, false); fill(tb, r2, data2, block_stride2, nblocks2, Ls2, nullptr, nullptr, false);
+  if (!n1) return RH_OK;
+  const unsigned ny = (unsigned)(nblocks + (r2 ? nblocks2 : 0));
+#define RH_BLK(S) do { ntt_fwd_cols_blocks_asm<S><<<dim3(n1, ny), 256, 0, st>>>(ca, cb, npoly);                                  \
+                       if (lazy_out) ntt_fwd_tile_blocks_asm<S, true><<<dim3(n2, ny), 256, 0, st>>>(ta, tb, npoly);                \
+                       else ntt_fwd_tile_blocks_asm<S, false><<<dim3(n2, ny), 256, 0, st>>>(ta, tb, npoly); } while (0)
+  switch (S1) { case 2: RH_BLK(2); break; case 3: RH_BLK(3); break; case 4: RH_BLK(4); break; }
+#undef RH_BLK
+  return check_launch("ntt_fwd_blocks (small batch)");
+}
 int rh_std_ntt_fwd_blocks(rh_ring* r, u64* data, size_t block_stride, int npoly, int nblocks, int Ls, const int* gap0, const int* gap_len,
                           bool lazy_out, int small) {       // small: 1 / 0 = every block in one launch pair / the pipelined stream; -1 = by the ring's ks_small_rows                  // block j: npoly polys of Ls rows, rows [gap0[j], gap0[j] + gap_len[j]) left alone
   if (!rh_can_ntt_digits(r)) return rh_fail(RH_ERR_UNSUPPORTED, "digit-block transform needs the hand-scheduled bodies (2^14 <= N <= 2^16)");
@@ -589,24 +624,7 @@ int rh_std_ntt_fwd_blocks(rh_ring* r, u64* data, size_t block_stride, int npoly,
     return g;
   };
   if (small < 0) small = r->ks_small_rows > 0 && (long)npoly * Ls <= r->ks_small_rows;
-  if (small && nblocks <= 8) {     // small batch: every block in ONE launch pair (blockIdx.y = block)
-    GapBlocks gb; gb.Ls = Ls;
-    unsigned n1 = 0, n2 = 0;
-    for (int j = 0; j < 8; ++j) {
-      const GapRows g = j < nblocks ? rows(j) : GapRows{0, Ls, 0, 0};
-      gb.L[j] = g.L; gb.gap0[j] = g.gap0; gb.gap_len[j] = g.gap_len;
-      const unsigned a = (unsigned)npoly * g.L * 16, b = ((unsigned)npoly * g.L) << S1;
-      if (a > n1) n1 = a;
-      if (b > n2) n2 = b;
-    }
-    if (!n1) return RH_OK;
-#define RH_BLK(S) do { ntt_fwd_cols_blocks_asm<S><<<dim3(n1, nblocks), 256, 0, st>>>(data, block_stride, gb, npoly, r->d_tw_fwd, r->d_consts);                           \
-                       if (lazy_out) ntt_fwd_tile_blocks_asm<S, true><<<dim3(n2, nblocks), 256, 0, st>>>(data, block_stride, gb, npoly, r->d_twk_fwd, r->d_consts);          \
-                       else ntt_fwd_tile_blocks_asm<S, false><<<dim3(n2, nblocks), 256, 0, st>>>(data, block_stride, gb, npoly, r->d_twk_fwd, r->d_consts); } while (0)
-    switch (S1) { case 2: RH_BLK(2); break; case 3: RH_BLK(3); break; case 4: RH_BLK(4); break; }
-#undef RH_BLK
-    return check_launch("ntt_fwd_blocks (small batch)");
-  }
+  if (small && nblocks <= 8) return rh_std_ntt_fwd_blocks_small(r, data, block_stride, nblocks, Ls, gap0, gap_len, nullptr, nullptr, 0, 0, 0, npoly, lazy_out);
   for (int j = 0; j <= nblocks; ++j) {
     GapRows g1 = j < nblocks ? rows(j) : GapRows{1, 1, 0, 0}, g2 = j >= 1 ? rows(j - 1) : GapRows{1, 1, 0, 0};
     const unsigned n1 = j < nblocks ? (unsigned)npoly * g1.L * 16 : 0, n2 = j >= 1 ? ((unsigned)npoly * g2.L) << S1 : 0;

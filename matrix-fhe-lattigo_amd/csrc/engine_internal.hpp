@@ -57,7 +57,7 @@ struct rh_ring {
   bool asm_tile = true;           // forward tile kernel: hand-scheduled body (ntt_kernels_asm.hip.hpp) vs the C++ one
   bool inv_scale = true;          // false: inverse leaves values < 4q without the N^-1 factor (3N sub-transform)
   int auto_span_rows = 2048;      // chunk_polys = -1: span size of the fused pipeline in (poly, limb) rows
-  int ks_small_rows = 256;        // key switch (keyswitch.hip): blocks of at most this many (poly, limb) rows (a few ciphertexts) take the small-batch launches: every digit
+  int ks_small_rows = 512;        // key switch (keyswitch.hip): blocks of at most this many (poly, limb) rows (a few ciphertexts) take the small-batch launches: every digit
                                   // in ONE extension launch and one launch pair of the transforms instead of a chain of ~10 dependent launches (0: never)
   bool pair_submul = true;        // ModDown of a ciphertext: both components' transform + subtract-multiply in ONE launch (false: one launch per component; A/B runs)
   bool one_pass = true;           // N = 2^13 / 2^14: whole limb row in one workgroup's LDS (ntt_fwd_onepass_asm / ntt_inv_onepass_asm); false: the two-pass launches
@@ -93,6 +93,8 @@ bool rh_can_ntt_digits(const rh_ring* r);
 int rh_std_ntt_fwd_digits(rh_ring* r, u64* data, size_t digit_stride, int npoly, int beta, int LQ, int LP, bool lazy_out = false, int small = -1);
 int rh_std_ntt_fwd_blocks(rh_ring* r, u64* data, size_t block_stride, int npoly, int nblocks, int Ls, const int* gap0, const int* gap_len,
                           bool lazy_out = false, int small = -1);
+int rh_std_ntt_fwd_blocks_small(rh_ring* r, u64* data, size_t block_stride, int nblocks, int Ls, const int* gap0, const int* gap_len,
+                                rh_ring* r2, u64* data2, size_t block_stride2, int nblocks2, int Ls2, int npoly, bool lazy_out);
 bool rh_can_intt_limb_strided(const rh_ring* r);
 int rh_std_intt_limb_strided(rh_ring* r, const u64* in, int in_rows, int limb, u64* out, int npoly);
 bool rh_can_fuse_submul(const rh_ring* r);

@@ -196,7 +196,12 @@ static int decompose_all_ntt(rh_bext* be, int levelQ, int levelP, int beta, cons
   // internal product (copy_digit == false): the blocks feed the key multiply-accumulate only, whose MRedLazy takes any 64-bit
   // operand and whose closing Reduce is canonical -- the transforms skip their final reduction (outputs < 8q)
   const bool lazy = !copy_digit;
-  if (int rc = rh_std_ntt_fwd_digits(RQ, decQ, wq, npoly, beta, LQ, LP, lazy, small)) return rc;
+  const bool both = small && beta <= 8 && rh_can_ntt_digits(RP) && RP->logN == RQ->logN;      // small batch: the Q blocks and the P blocks in ONE launch pair
+  if (both) {
+    int g0[8], gl[8];
+    for (int j = 0; j < beta; ++j) { int n = LQ - j * LP; if (n > LP) n = LP; if (n < 0) n = 0; g0[j] = j * LP; gl[j] = n; }      // digit j skips its own limbs
+    if (int rc = rh_std_ntt_fwd_blocks_small(RQ, decQ, wq, beta, LQ, g0, gl, RP, decP, wp, beta, LP, npoly, lazy)) return rc;
+  } else if (int rc = rh_std_ntt_fwd_digits(RQ, decQ, wq, npoly, beta, LQ, LP, lazy, small)) return rc;
   if (copy_digit)
     for (int i = 0; i < beta; ++i) {
       const int st = i * LP; int ed = st + LP; if (ed > LQ) ed = LQ;
@@ -204,6 +209,7 @@ static int decompose_all_ntt(rh_bext* be, int levelQ, int levelP, int beta, cons
                                       (size_t)(ed - st) * N * 8, npoly, hipMemcpyDeviceToDevice, rh_stream(RQ)) != hipSuccess)
         return rh_fail(RH_ERR_DEVICE, "gadget_product: digit copy failed");
     }
+  if (both) return RH_OK;
   if (rh_can_ntt_digits(RP)) return rh_std_ntt_fwd_digits(RP, decP, wp, npoly, beta, LP, 0, lazy, small);   // no limb skipped
   return rh_ring_ntt_any(RP, decP, decP, beta * npoly, LP, 0, false);
 }

@@ -196,24 +196,30 @@ ntt_fwd_fused_gap_asm(u64* data1, unsigned n1, GapRows g1, u64* data2, unsigned 
 // Small batches (a key switch of a few ciphertexts: one digit block fills a fraction of the chip, and the pipelined stream above is a chain of
 // nblocks + 1 dependent launches): ALL the blocks in one launch of the column stages and one of the tile stages, blockIdx.y = the block.
 struct GapBlocks { int L[8]; u32 gap0[8], gap_len[8]; int Ls; };
+// one ring's blocks of such a launch; a launch carries up to TWO sets (the Q blocks and the P blocks of a key switch: two rings, one launch pair)
+struct BlockSet { u64* data; size_t stride; const tw2* tw; const LimbConsts* consts; GapBlocks g; int nblocks; };
 template <int S1>
 __global__ void __launch_bounds__(256)
-ntt_fwd_cols_blocks_asm(u64* data, size_t block_stride, GapBlocks g, int npoly, const tw2* __restrict__ twn, const LimbConsts* __restrict__ consts) {
-  const u32 y = blockIdx.y;
+ntt_fwd_cols_blocks_asm(BlockSet a, BlockSet b, int npoly) {
+  const bool first = blockIdx.y < (unsigned)a.nblocks;
+  const u32 y = first ? blockIdx.y : blockIdx.y - (unsigned)a.nblocks;
+  const GapBlocks& g = first ? a.g : b.g;
   const int L = g.L[y];
   if (blockIdx.x >= (unsigned)npoly * (unsigned)L * 16u) return;
-  u64* d = data + (size_t)y * block_stride;
-  fwd_cols_asm_body<S1, false>(blockIdx.x, d, d, twn, consts, L, g.Ls, g.gap0[y], g.gap_len[y]);
+  u64* d = (first ? a.data : b.data) + (size_t)y * (first ? a.stride : b.stride);
+  fwd_cols_asm_body<S1, false>(blockIdx.x, d, d, first ? a.tw : b.tw, first ? a.consts : b.consts, L, g.Ls, g.gap0[y], g.gap_len[y]);
 }
 template <int S1, bool LAZY>
 __global__ void __launch_bounds__(256)
-ntt_fwd_tile_blocks_asm(u64* data, size_t block_stride, GapBlocks g, int npoly, const tw2* __restrict__ twk, const LimbConsts* __restrict__ consts) {
+ntt_fwd_tile_blocks_asm(BlockSet a, BlockSet b, int npoly) {
   __shared__ u64 lds[LDS_WORDS];
-  const u32 y = blockIdx.y;
+  const bool first = blockIdx.y < (unsigned)a.nblocks;
+  const u32 y = first ? blockIdx.y : blockIdx.y - (unsigned)a.nblocks;
+  const GapBlocks& g = first ? a.g : b.g;
   const int L = g.L[y];
   if (blockIdx.x >= ((unsigned)npoly * (unsigned)L) << S1) return;
-  u64* d = data + (size_t)y * block_stride;
-  fwd_tile_asm_body<LAZY, false>(lds, blockIdx.x, d, d, twk, consts, L, LT + S1, npoly, g.Ls, g.gap0[y], g.gap_len[y]);
+  u64* d = (first ? a.data : b.data) + (size_t)y * (first ? a.stride : b.stride);
+  fwd_tile_asm_body<LAZY, false>(lds, blockIdx.x, d, d, first ? a.tw : b.tw, first ? a.consts : b.consts, L, LT + S1, npoly, g.Ls, g.gap0[y], g.gap_len[y]);
 }
 
 // ---- inverse: first 12 stages (t = 1..2048) on a 4096-tile, values leave < 4q (N^-1 is applied by ntt_inv_cols).

@@ -9,13 +9,13 @@ from conftest import QI60, PI60, uniform_mod
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("small_rows", [0, 256], ids=["digit-pipeline", "all-digits-per-launch"])
+@pytest.mark.parametrize("small_rows", [0, 512], ids=["digit-pipeline", "all-digits-per-launch"])
 def test_key_switch_and_polymul_replayed_from_a_graph(rh, small_rows):
     import torch
     N, nq, np_, B = 4096, 6, 2, 2
     Q, P = QI60[:nq], PI60[:np_]
     rq, rp = rh.Ring(N, Q), rh.Ring(N, P)
-    rq.set_tuning("ks_small_rows", small_rows)       # 0: the large-batch launch sequence; 256 (the default): the small-batch one
+    rq.set_tuning("ks_small_rows", small_rows)       # 0: the large-batch launch sequence; 512 (the default): the small-batch one
     be = rh.BasisExtender(rq, rp)
     rng = np.random.default_rng(11)
     beta = (nq - 1 + np_) // np_

@@ -39,7 +39,7 @@ def test_gadget_product_vs_oracle_composition(rh, oracle, N, nq, np_, levelQ, le
     rq.set_tuning("ks_small_rows", 0)                 # the digit-by-digit extension and the pipelined stream of transforms (large batches)
     be.GadgetProduct(levelQ, levelP, pcx, dq.ptr, dp.ptr, beta_key, ct0, ct1)
     g0, g1 = ct0.numpy(), ct1.numpy()
-    # the small-batch path (tuning ks_small_rows, default 256 rows: every digit in ONE extension launch and one launch pair of the transforms): same bits
+    # the small-batch path (tuning ks_small_rows, default 512 rows: every digit in ONE extension launch, the transforms of both rings' digit blocks in one launch pair): same bits
     rq.set_tuning("ks_small_rows", 1024)
     s0, s1 = rh.DevicePoly(rq, npoly, LQ), rh.DevicePoly(rq, npoly, LQ)
     for _ in range(2):
