@@ -236,6 +236,8 @@ def test_fuzz_gadget_product_shapes(rh, oracle, case):
     key = lambda mods: np.stack([np.stack([np.stack([uniform_mod(rng, q, N) for q in mods]) for _ in range(2)]) for _ in range(beta_key)])
     evkQ, evkP = key(Q), key(P)
     rq, rp = rh.Ring(N, Q), rh.Ring(N, P)
+    if case % 3 == 0:
+        rq.set_tuning("ks_small_rows", 0)            # the large-batch launch sequence (digit by digit + pipelined transforms) on these small batches too
     be = rh.BasisExtender(rq, rp)
     pcx = rh.DevicePoly.from_numpy(rq.AtLevel(levelQ), cx)
     dq = rh.DevicePoly.from_numpy(rq, evkQ.reshape(beta_key * 2, nq, N))
